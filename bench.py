@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py — input bases/sec counted by the MI355X `count` hot path.
+
+One "step" = one pass of the hot path (fused encode + probe + increment kernel,
+through the C-ABI qm2_submit_device) over one batch of synthetic reads that is
+already resident in HBM.  Workloads (BASELINE.json `configs`):
+
+  c2  chr22-like dictionary: 50.8 Mb synthetic reference, k=30, H=2^28
+      (2 GiB keys + 1 GiB u32 counters), batches of 10 M x 150 bp reads
+  c3  hg38-like dictionary: 3.1 Gb synthetic reference, k=30, H=2^32
+      (32 GiB keys + 16 GiB counters), same batches
+  c5  c3's dictionary, HiFi-like reads U(15k, 20k) bp
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): replicas — every
+rank holds the whole dictionary (it always fits: <= 48 GiB)
+and counts its own batches; the only exchange is one RCCL all-reduce of the
+u32 counters at the end of the timed region.  scaling = weak.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "quick-mer2_amd"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "c2": dict(genome=50_818_468, lgH=28, reads=10_000_000, len_lo=150, len_hi=150, sub=0.005,
+               desc="chr22-like 50.8 Mb synthetic reference, k=30, H=2^28; 10M x 150 bp reads per step"),
+    "c3": dict(genome=3_100_000_000, lgH=32, reads=10_000_000, len_lo=150, len_hi=150, sub=0.005,
+               desc="hg38-like 3.1 Gb synthetic reference, k=30, H=2^32; 10M x 150 bp reads per step"),
+    "c5": dict(genome=3_100_000_000, lgH=32, reads=80_000, len_lo=15_000, len_hi=20_000, sub=0.001,
+               desc="hg38-like dictionary (H=2^32), HiFi-like reads U(15k,20k) bp, 80k reads per step"),
+    "tiny": dict(genome=2_000_000, lgH=22, reads=200_000, len_lo=150, len_hi=150, sub=0.005,
+                 desc="2 Mb synthetic reference, H=2^22 (plumbing check only)"),
+}
+
+
+def genome_layout(n):
+    """N blocks and duplicated segments of the synthetic reference: ~23 % N in a
+    few blocks (chr22: 11.6 of 50.8 Mb), 2 % of the sequence in duplicated 1-20 kb segments."""
+    n_blocks = [(0, int(0.205 * n)), (int(0.59 * n), int(0.012 * n)), (n - int(0.0102 * n), int(0.0102 * n))]
+    dups = []
+    target, at, src, i = int(0.02 * n), int(0.75 * n), int(0.25 * n), 0
+    while target > 0:
+        ln = 1000 + (i * 7919) % 19000
+        dups.append((at, src, ln))
+        at += ln + 50_000
+        src += ln + 31_337
+        target -= ln
+        i += 1
+        if at + 20_000 >= n - int(0.0102 * n) or src + 20_000 >= int(0.58 * n):
+            break
+    return n_blocks, dups
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("QM2_WORKLOAD", "c2"), choices=sorted(WORKLOADS))
+    ap.add_argument("--batches", type=int, default=4, help="distinct read batches kept resident and cycled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=6, help="probe workers (reference recommends 6)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import pyqm2
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the count path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    wl = WORKLOADS[args.workload]
+    k, H, n = 30, 1 << wl["lgH"], wl["genome"]
+
+    # ---- untimed set-up: reference, dictionary, read batches, all made on the device -------
+    t_setup = time.time()
+    genome = torch.empty(n, dtype=torch.uint8, device=dev)
+    n_blocks, dups = genome_layout(n)
+    pyqm2.tools.genome_generate(genome.data_ptr(), n, seed=22, n_blocks=n_blocks, dups=dups)
+    keys = torch.empty(H, dtype=torch.int64, device=dev)
+    scratch = torch.empty(H, dtype=torch.int64, device=dev)
+    n_distinct, n_unique = pyqm2.tools.dict_build(genome.data_ptr(), n, k, keys.data_ptr(), H, scratch.data_ptr())
+    del scratch
+    torch.cuda.empty_cache()
+    counters = torch.zeros(H, dtype=torch.int32, device=dev)
+
+    n_batches = max(1, min(args.batches, args.steps + args.warmup))
+    batches = []
+    for b in range(n_batches):
+        first = (rank * 1000 + b) * wl["reads"]          # every rank / batch draws its own reads
+        off = pyqm2.tools.read_offsets(wl["reads"], first, wl["len_lo"], wl["len_hi"], 22)
+        nbytes = int(off[-1])
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        d_off = None
+        if wl["len_lo"] != wl["len_hi"]:
+            d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+        pyqm2.tools.reads_generate(genome.data_ptr(), n, buf.data_ptr(), d_off.data_ptr() if d_off is not None else None,
+                                   wl["reads"], first, wl["len_lo"], wl["len_hi"], 22, sub_rate=wl["sub"])
+        batches.append((buf, nbytes, nbytes - wl["reads"]))
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    ctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=pyqm2.FLAG_TIMING,
+                        ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def step(i):
+        buf, nbytes, _ = batches[i % n_batches]
+        ctx.submit_device(buf.data_ptr(), nbytes)
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.sync()
+    _, st0 = ctx.finish(want_depth=False)
+    prof0 = ctx.profile()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ctx.sync()
+    if world > 1:
+        dist.all_reduce(counters)          # the replicas' one exchange: RCCL sum of u32 counters
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    _, st1 = ctx.finish(want_depth=False)
+    prof1 = ctx.profile()
+    d = {a: st1[a] - st0[a] for a in st1}
+    bases_rank = d["n_bases"]
+    total_bases = bases_rank
+    if world > 1:
+        tb = torch.tensor([bases_rank], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb)
+        total_bases = int(tb.item())
+    assert bases_rank == sum(batches[(args.warmup + i) % n_batches][2] for i in range(args.steps))
+
+    # ---- roofline of the dominant (only) kernel: algorithmic bytes / HIP-event kernel time ---
+    launches = prof1["n_launches"] - prof0["n_launches"]
+    kern_ms = prof1["kernel_ms"] - prof0["kernel_ms"]
+    b_alg = d["n_bases"] + 8 * d["n_probes"] + 4 * d["n_hits"]
+    achieved = b_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic = None
+    tr_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tr_file):
+        try:
+            traffic = json.load(open(tr_file)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel": "qm2::count_kernel<true>", "launches": launches,
+                "avg_launch_ms": round(kern_ms / max(1, launches), 4),
+                "algorithmic_bytes_per_launch": b_alg // max(1, launches),
+                "bytes_per_base": round(b_alg / max(1, d["n_bases"]), 3),
+                "kernel_only_bases_per_s": round(d["n_bases"] / (kern_ms * 1e-3), 1) if kern_ms > 0 else None}
+
+    # ---- CPU baseline: the oracle's reference-model threaded counter on a bounded sample ------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+        hk = keys.cpu().numpy().view(np.uint64)
+        buf, nbytes, _ = batches[0]
+        line = wl["len_lo"] + 1 if wl["len_lo"] == wl["len_hi"] else None
+        # calibrate on a small slice, then size the sample for ~cpu_seconds
+        probe_bytes = min(nbytes, 20_000 * 151)
+        host = buf[:probe_bytes].cpu().numpy().tobytes()
+        host = host[:host.rfind(b"\n") + 1]
+        tA = time.perf_counter()
+        ol.count_lines(hk, k, host, threads=args.cpu_threads)
+        rate = len(host) / max(1e-6, time.perf_counter() - tA)
+        want = int(min(nbytes, max(len(host), rate * args.cpu_seconds)))
+        host = buf[:want].cpu().numpy().tobytes()
+        host = host[:host.rfind(b"\n") + 1]
+        tA = time.perf_counter()
+        cdepth, cst = ol.count_lines(hk, k, host, threads=args.cpu_threads)
+        cpu_s = time.perf_counter() - tA
+        # the same sample through the GPU path must give the same counters (bit-exact)
+        chk = pyqm2.Counter(None, hash_size=H, k=k, device=local, ext_keys=keys.data_ptr())
+        chk.submit(host)
+        gdepth, gst = chk.finish()
+        chk.close()
+        same = bool(np.array_equal(gdepth, cdepth) and gst["n_kmers"] == cst["n_kmers"] and gst["n_hits"] >= 0)
+        cpu = {"value": round(cst["n_bases"] / cpu_s, 1), "unit": "bases/s", "cores": args.cpu_threads + 1,
+               "kind": "port", "host_cores": os.cpu_count(),
+               "sample": "first %d reads (%d bases) of batch 0, oracle threaded model: 1 producer + %d probe workers, %.1f s"
+                         % (host.count(b"\n"), cst["n_bases"], args.cpu_threads, cpu_s),
+               "gpu_counts_identical_on_sample": same}
+        del hk
+
+    if rank == 0:
+        out = {
+            "metric": "input bases/sec counted vs hg38 k=30 dict",
+            "value": round(total_bases / elapsed, 1),
+            "unit": "bases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": args.workload + ": " + wl["desc"], "k": k, "hash_size": H,
+                       "dict_kmers": n_unique, "fill": round(n_unique / H, 4),
+                       "reads_per_step_per_gpu": wl["reads"], "bases_per_step_per_gpu": batches[0][2],
+                       "kmers_per_base": round(d["n_kmers"] / max(1, d["n_bases"]), 4),
+                       "probes_per_kmer": round(d["n_probes"] / max(1, d["n_kmers"]), 4),
+                       "hit_fraction": round(d["n_hits"] / max(1, d["n_kmers"]), 4),
+                       "parallelism": "replicas x%d (dictionary replicated, reads partitioned, one RCCL all-reduce)" % world
+                       if world > 1 else "1 GPU", "inputs": "resident in HBM", "setup_s": round(t_setup, 1)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+/*
+ * qm2.h — C-ABI of the MI355X-native `quicKmer2 count` counting phase.
+ *
+ * The reference (KiddLab/QuicK-mer2, one C file) has no plugin or FFI seam:
+ * main_count is monolithic and its workers reach the table through globals
+ * (QuicKmer.c:14-23).  This header DEFINES the seam the replacement binds at:
+ * the whole counting phase, between "dictionary loaded" (QuicKmer.c:366) and
+ * "dump count file" (QuicKmer.c:482).  Inputs are the loaded key array and the
+ * stream of sequence lines; the output is the filled Kmer_depth[H].
+ *
+ *   reference region replaced                          entry point
+ *   -------------------------------------------------  -------------------------
+ *   Kmer_hash/Kmer_depth alloc, QuicKmer.c:353-366      qm2_open
+ *   thread pool start-up, :368-384                      qm2_open
+ *   per-line encode + dispatch loop, :397-456           qm2_submit / qm2_submit_device
+ *     rolling 2-bit encoder + canonicaliser, :399-420
+ *     Kmer_count_TSK batch worker, :256-296
+ *     DJBHash_encode :66-76, Find_hash :90-99
+ *     counter increment, :291 / :443
+ *   drain + join, :458-479                              qm2_finish
+ *   "total %lu kmers" bookkeeping, :445, :481           qm2_stats
+ *   free, :519-520                                      qm2_close
+ *
+ * Plain C types only: no torch / HIP types cross this boundary (device
+ * pointers and streams travel as void*).  The library that implements it is
+ * quick-mer2_amd/libqm2_hip.so (hand-written gfx950 kernels).  There is no CPU
+ * implementation of this ABI in the product: if no HIP device is usable every
+ * entry point fails loudly (non-zero + message), it never falls back.
+ *
+ * Error convention (mirrors QuicKmer.c:354-358, `puts(msg); return 1;`):
+ * 0 on success; non-zero after printing one line to stdout.  The same line is
+ * available from qm2_last_error().  No exceptions, no abort().
+ *
+ * Threading: one caller thread per context.  Work is asynchronous inside the
+ * backend; results are independent of batch boundaries, batch sizes and
+ * scheduling (integer adds commute).  qm2_finish/qm2_sync are the only points
+ * where the caller observes completion.
+ */
+#ifndef QM2_H
+#define QM2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QM2_ABI_VERSION 1
+
+typedef struct qm2_ctx qm2_ctx;
+
+/* flags for qm2_opts.flags */
+#define QM2_FLAG_TIMING      0x1u  /* bracket every kernel launch with HIP events
+                                      on its own stream (qm2_get_profile)       */
+#define QM2_FLAG_NO_STATS    0x2u  /* do not collect n_probes / n_hits          */
+
+typedef struct {
+    uint32_t struct_size;     /* = sizeof(qm2_opts); 0-filled fields = defaults  */
+    int32_t  device;          /* HIP device ordinal; <0 = current device         */
+    uint32_t flags;           /* QM2_FLAG_*                                      */
+    uint32_t n_staging;       /* pinned host staging buffers for qm2_submit
+                                 (default 3; each has its own stream)            */
+    uint64_t staging_bytes;   /* size of each staging buffer (default 64 MiB)    */
+    void    *ext_keys;        /* optional: device pointer to H x u64 keys that are
+                                 ALREADY resident (then `keys` may be NULL)      */
+    void    *ext_counters;    /* optional: device pointer to H x u32 counters
+                                 owned by the caller (e.g. a tensor handed to
+                                 RCCL for the replica reduce); zeroed by caller  */
+    void    *stream;          /* optional hipStream_t used by qm2_submit_device /
+                                 qm2_encode_device / qm2_probe_device; NULL =
+                                 a stream owned by the context                   */
+    uint64_t span_lo;         /* hash-range shard: the slots      */
+    uint64_t span_hi;         /* [span_lo, span_hi) of the table that are resident
+                                 on this device; `keys`/ext_keys/ext_counters then
+                                 hold span_hi - span_lo entries, slot span_lo first.
+                                 Both 0 = the whole table.  Only k-mers whose probe
+                                 walk stays inside the span may be fed (see
+                                 qm2_shard_span for how the span is chosen).     */
+} qm2_opts;
+
+typedef struct {
+    uint64_t n_bases;   /* sequence characters consumed (incl. 'N'), no newlines */
+    uint64_t n_kmers;   /* k-mers emitted == the reference's process_kmers (:445) */
+    uint64_t n_probes;  /* table slots inspected (Find_hash loop, :96-98)         */
+    uint64_t n_hits;    /* counter increments (:291 / :443)                       */
+} qm2_stats;
+
+typedef struct {
+    uint64_t n_launches;      /* count-kernel launches timed                      */
+    double   kernel_ms;       /* sum of their HIP-event durations                 */
+    double   last_kernel_ms;  /* duration of the most recent one                  */
+} qm2_profile;
+
+/* Create a counting context for a dictionary of `hash_size` slots (power of
+ * two, <= 2^32: the on-disk chain is uint32, QuicKmer.c:20) and k-mer size k
+ * (1..31; k = 32 is undefined behaviour in the reference, :419, and rejected).
+ * `keys` is the host array read from the .qm at offset 24 (QuicKmer.c:353-359);
+ * it is uploaded and the caller may reuse the buffer at once (the reference
+ * re-uses it for the chain, :483).  Counters start at zero (calloc, :360). */
+int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
+             uint32_t k, const qm2_opts *opts);
+
+/* Feed sequence lines from HOST memory: `n` bytes made of whole lines, each
+ * '\n'-terminated, headers and quality lines already removed (what
+ * QuicKmer.c:397-398/:451-455 hands to the loop at :403).  Any byte other than
+ * '\n' and 'N' is a base, exactly as in the reference (:411).  Copies into
+ * pinned staging and returns; the caller's buffer is free on return.  Lines of
+ * any length are accepted (the reference's uint16 run counter, :402, is
+ * reproduced: SURVEY B.3). */
+int qm2_submit(qm2_ctx *c, const char *seq_bytes, size_t n);
+
+/* Same, for bytes ALREADY in device memory (any alignment).  Asynchronous on
+ * the context's stream; the buffer must stay valid until qm2_sync/qm2_finish.
+ * `suppress`/`n_suppress` (device pointer to sorted u64 byte offsets, or
+ * NULL/0) carries the positions whose windows the reference's uint16 run
+ * counter drops; callers whose lines are all < 65536 bases pass NULL. */
+int qm2_submit_device(qm2_ctx *c, const void *d_seq_bytes, size_t n,
+                      const uint64_t *d_suppress, uint64_t n_suppress);
+
+/* Block until everything submitted so far has been counted. */
+int qm2_sync(qm2_ctx *c);
+
+/* Drain, then write the H counters truncated to uint16 (the reference's
+ * counters wrap mod 65536, :23/:291; 32-bit accumulation then truncation is
+ * exact) into depth_out (may be NULL) and the totals into st (may be NULL).
+ * The context stays usable; counts keep accumulating until qm2_reset. */
+int qm2_finish(qm2_ctx *c, uint16_t *depth_out, qm2_stats *st);
+
+/* Zero counters and statistics (a fresh calloc, :360). */
+int qm2_reset(qm2_ctx *c);
+
+void qm2_close(qm2_ctx *c);
+
+/* Device pointers, for callers that reduce counters across GPUs with RCCL or
+ * keep inputs resident: H x u32 counters, H x u64 keys. */
+void *qm2_counters_device(qm2_ctx *c);
+void *qm2_keys_device(qm2_ctx *c);
+
+int qm2_get_profile(qm2_ctx *c, qm2_profile *p);
+
+/* ---- split path for hash-range sharding (multi-GPU) ------- *
+ * The fused kernel of qm2_submit does encode+probe in one launch.  When the
+ * table is range-partitioned over G devices the two halves run on different
+ * devices with an all-to-all in between, so they are also exported alone.     */
+
+/* Encode device-resident sequence lines into canonical k-mers (same rules as
+ * qm2_submit), bucketed by owner = home_slot >> (log2(H) - log2(n_buckets)).
+ * d_out has n_buckets regions of `bucket_cap` u64 each; d_counts[n_buckets]
+ * (u64, device) receives the fill of each and must be zero on entry.
+ * k-mers beyond bucket_cap are dropped and reported by a non-zero return from
+ * the next qm2_sync (size bucket_cap for the worst case: n k-mers). */
+int qm2_encode_device(qm2_ctx *c, const void *d_seq_bytes, size_t n,
+                      const uint64_t *d_suppress, uint64_t n_suppress,
+                      uint64_t *d_out, uint64_t bucket_cap, uint32_t n_buckets,
+                      uint64_t *d_counts);
+
+/* Probe + increment for an array of canonical k-mers already on this device
+ * (QuicKmer.c:283-293: the worker's batch loop).  d_n (device u64, may be
+ * NULL) overrides n with a device-side count (avoids a host round trip after
+ * the exchange). */
+int qm2_probe_device(qm2_ctx *c, const uint64_t *d_kmers, uint64_t n,
+                     const uint64_t *d_n);
+
+/* Pure host helper (no device needed): the slot range shard g of n_shards
+ * OWNS, [*own_lo, *own_hi) = [g*H/G, (g+1)*H/G), and the range it must hold,
+ * [*span_lo, *span_hi): the owned range extended on its middle-facing side
+ * (probes walk towards the middle of the table, QuicKmer.c:93-95) up to and
+ * including the first empty slot, so that every walk that starts in the owned
+ * range ends inside the span. */
+int qm2_shard_span(const uint64_t *keys, uint64_t hash_size, uint32_t n_shards,
+                   uint32_t g, uint64_t *own_lo, uint64_t *own_hi,
+                   uint64_t *span_lo, uint64_t *span_hi);
+
+const char *qm2_last_error(void);
+uint32_t    qm2_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QM2_H */

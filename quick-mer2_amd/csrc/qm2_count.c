@@ -1,0 +1,87 @@
+/*
+ * qm2_count.c — `quicKmer2 count [-h] [-t N] ref.fa sample.fast[a/q] Out_prefix`
+ * with the counting phase on the MI355X behind include/qm2.h.
+ * Follows main_count, QuicKmer.c:304-545: same positional arguments taken from
+ * the end (:335, :338, :342), same stdout lines, same output files.
+ */
+#define _GNU_SOURCE
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "qm2_host.h"
+
+static void help_count(void)
+{
+    puts("\nquicKmer2 count [Options] ref.fa sample.fast[a/q] Out_prefix\n\nOptions:");   /* :299 */
+    puts("-h\t\tShow this help information");
+    puts("-t [num]\tNumber of threads");
+}
+
+static int submit_sink(void *user, const char *lines, size_t n)
+{
+    return qm2_submit((qm2_ctx *)user, lines, n);
+}
+
+int qm2_main_count(int argc, char **argv)
+{
+    unsigned thread_count = 0;
+    if (argc < 2) { help_count(); return 1; }                /* :309-312 */
+    int opt;
+    optind = 1;
+    while ((opt = getopt(argc, argv, "ht:")) != -1) {        /* :314 */
+        switch (opt) {
+        case 'h': help_count(); return 1;
+        case 't':
+            thread_count = (unsigned)atoi(optarg) & 0xFFu;   /* uint8_t in the reference (:306) */
+            printf("[Option] Set %u threads\n", thread_count);
+            break;
+        case '?':
+            puts("Option error, check help");
+            help_count();
+            return 1;
+        default: return 1;
+        }
+    }
+    if (argc < 4) { help_count(); return 1; }
+    const char *ref_prefix = argv[argc - 3], *reads = argv[argc - 2], *out_prefix = argv[argc - 1];
+    (void)thread_count;  /* -t is accepted for command-line compatibility: the
+                            probing workers it sized (:372-384) are GPU waves now */
+
+    qm2_dict_file d;
+    if (qm2_dict_open(ref_prefix, &d)) return 1;
+    if (d.k < 1 || d.k > 31) {
+        printf("Dictionary k=%u is not supported (1..31)\n", d.k);
+        qm2_dict_close(&d);
+        return 1;
+    }
+    uint16_t *depth = calloc(d.hash_size, sizeof(uint16_t));  /* :360 */
+    if (!depth) { puts("Memory allocation failed"); qm2_dict_close(&d); return 1; }
+
+    qm2_ctx *ctx = NULL;
+    qm2_opts o;
+    memset(&o, 0, sizeof o);
+    o.struct_size = sizeof o;
+    o.device = -1;
+    if (qm2_open(&ctx, d.keys, d.hash_size, d.k, &o)) { free(depth); qm2_dict_close(&d); return 1; }
+
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);                      /* :386-387 */
+    int rc = qm2_stream_reads(reads, (size_t)64 << 20, submit_sink, ctx);
+    qm2_stats st;
+    memset(&st, 0, sizeof st);
+    if (!rc) rc = qm2_finish(ctx, depth, &st);                /* :458-479 */
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    qm2_close(ctx);
+    if (rc) { free(depth); qm2_dict_close(&d); return 1; }
+    printf("Counting elapse %u sec, total %lu kmers\n",       /* :481 */
+           (unsigned)(t1.tv_sec - t0.tv_sec), (unsigned long)st.n_kmers);
+
+    rc = qm2_write_outputs(&d, depth, ref_prefix, out_prefix);
+    free(depth);
+    qm2_dict_close(&d);
+    if (rc) return 1;
+    puts("Exit quicK-mer2 count");                            /* :543 */
+    return 0;
+}

@@ -1,0 +1,282 @@
+/*
+ * qm2_device.hip.h — device-side building blocks of the MI355X `count` path.
+ * gfx950 only (wave64).  No reference code: the behaviour follows SURVEY.md
+ * Appendix B; reference lines are cited where a rule comes from.
+ *
+ * Data flow of one wave-step (one "tile" = 992 sequence bytes):
+ *
+ *   64 lanes x 16 B coalesced load  (1 KiB per wave instruction; lanes 0-1 are
+ *        |                           the 32-byte look-back halo of the tile)
+ *   SWAR 2-bit pack: 16 bases -> one u32 (MSB-first) + a 16-bit reset mask
+ *        |                          ('N' and '\n' are the only resets, :403-408)
+ *   wave shuffles: each lane also gets the packed words of lanes -1 and -2
+ *        |                          => a 48-base window in three registers
+ *   16 x { funnel-shift out the forward k-mer and the reverse complement of
+ *          the last 30 bases (:412-416), min (:420), DJB (:66-76) -> home slot }
+ *        |
+ *   probe rounds: all first probes of the 16 k-mers are issued back to back
+ *          (16 independent 8-byte gathers in flight per lane), later rounds
+ *          only for the unresolved ones (Find_hash, :90-99)
+ *        |
+ *   no-return global atomic add on the 32-bit counter of each hit (:291)
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qm2 {
+
+constexpr int      kWave          = 64;
+constexpr int      kBlock         = 256;                     /* 4 waves per workgroup */
+constexpr int      kBytesPerLane  = 16;
+constexpr int      kHaloLanes     = 2;                       /* 32 B look-back >= 30 */
+constexpr int      kTileBytes     = (kWave - kHaloLanes) * kBytesPerLane; /* 992 */
+constexpr uint64_t kMask60        = (1ull << 60) - 1;
+
+struct TableView {
+    const uint64_t *keys;      /* slots [span_lo, span_hi) of the table          */
+    uint32_t       *counters;  /* same span, 32-bit accumulators                 */
+    uint64_t        span_lo;   /* global slot index of keys[0]                   */
+    uint32_t        hmask;     /* H - 1 (H <= 2^32)                              */
+    uint32_t        hhalf;     /* H >> 1                                         */
+};
+
+struct SeqView {
+    const uint8_t  *base;      /* 16-byte aligned pointer at or before the data  */
+    uint64_t        lead;      /* bytes [0, lead) are before the buffer: '\n'    */
+    uint64_t        emit_from; /* windows ending before this byte emit nothing   */
+    uint64_t        n_total;   /* lead + payload bytes                           */
+    const uint64_t *suppress;  /* sorted byte positions (relative to payload byte
+                                  0 = base + lead) whose windows the uint16 run
+                                  counter drops (:402)                           */
+    uint64_t        n_suppress;
+};
+
+/* stats block in device memory */
+struct DevStats {
+    unsigned long long n_bases, n_kmers, n_probes, n_hits, overflow;
+};
+
+/* ---- SWAR helpers ---------------------------------------------------------- */
+
+/* 0x80 in every byte of x that is zero (exact, no cross-byte borrow). */
+__host__ __device__ __forceinline__ uint32_t zero_bytes(uint32_t x)
+{
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+
+/* Four ASCII bytes (little-endian in w) -> 8 bits, first byte in the top pair.
+ * code = (c >> 1) & 3  (:411): A,a->0  C,c->1  T,t->2  G,g,n->3, any byte works. */
+__host__ __device__ __forceinline__ uint32_t pack4(uint32_t w)
+{
+    return ((((w >> 1) & 0x03030303u) * 0x40100401u) >> 24);
+}
+
+/* Four bytes -> 4 flag bits (first byte in bit 3) from a zero_bytes() result. */
+__host__ __device__ __forceinline__ uint32_t flags4(uint32_t z)
+{
+    return (((z >> 7) * 0x08040201u) >> 24) & 0xFu;
+}
+
+struct Packed {
+    uint32_t fwd;   /* 16 bases, base 0 in bits 31:30                            */
+    uint32_t bad;   /* 16 bits, base 0 in bit 15: 'N' or '\n'                    */
+    uint32_t nl;    /* 16 bits, base 0 in bit 15: '\n' only                      */
+};
+
+__host__ __device__ __forceinline__ Packed pack16(uint4 v)
+{
+    Packed p;
+    p.fwd = (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w);
+    uint32_t nx = zero_bytes(v.x ^ 0x0A0A0A0Au), ny = zero_bytes(v.y ^ 0x0A0A0A0Au);
+    uint32_t nz = zero_bytes(v.z ^ 0x0A0A0A0Au), nw = zero_bytes(v.w ^ 0x0A0A0A0Au);
+    p.nl = (flags4(nx) << 12) | (flags4(ny) << 8) | (flags4(nz) << 4) | flags4(nw);
+    uint32_t bx = zero_bytes(v.x ^ 0x4E4E4E4Eu), by = zero_bytes(v.y ^ 0x4E4E4E4Eu);
+    uint32_t bz = zero_bytes(v.z ^ 0x4E4E4E4Eu), bw = zero_bytes(v.w ^ 0x4E4E4E4Eu);
+    p.bad = p.nl | (flags4(bx) << 12) | (flags4(by) << 8) | (flags4(bz) << 4) | flags4(bw);
+    return p;
+}
+
+/* Low 32 bits of (hi:lo) >> s, 0 <= s < 32 (one v_alignbit_b32). */
+__host__ __device__ __forceinline__ uint32_t funnel_r(uint32_t lo, uint32_t hi, int s)
+{
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> s);
+}
+
+/* Reverse-complement image of a packed word: base i moves to bits [2i+1:2i]
+ * and is complemented (comp = code ^ 2, :414). */
+__host__ __device__ __forceinline__ uint32_t rc_word(uint32_t x)
+{
+    uint32_t r = __builtin_bitreverse32(x);
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    return r ^ 0xAAAAAAAAu;
+}
+
+/* Low 32 bits of DJBHash_encode (:66-76).  Only hash & (H-1) is ever used and
+ * H <= 2^32, and h*33+b mod 2^32 needs only h mod 2^32. */
+__host__ __device__ __forceinline__ uint32_t djb32(uint64_t kmer)
+{
+    uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
+    uint32_t h = 5381u;
+    h = h * 33u + (lo & 0xFFu);
+    h = h * 33u + ((lo >> 8) & 0xFFu);
+    h = h * 33u + ((lo >> 16) & 0xFFu);
+    h = h * 33u + (lo >> 24);
+    h = h * 33u + (hi & 0xFFu);
+    h = h * 33u + ((hi >> 8) & 0xFFu);
+    h = h * 33u + ((hi >> 16) & 0xFFu);
+    h = h * 33u + (hi >> 24);
+    return h;
+}
+
+/* Load the 16 bytes of lane-slot `g` (byte offset from sv.base, may be
+ * negative or beyond the end): bytes outside [lead, n_total) read as '\n'. */
+__host__ __device__ __forceinline__ uint4 load16(const SeqView &sv, int64_t g)
+{
+    const uint4 nl4 = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+    if (g + 16 <= (int64_t)sv.lead || g >= (int64_t)sv.n_total) return nl4;
+    if (g >= (int64_t)sv.lead && g + 16 <= (int64_t)sv.n_total) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(sv.base + g));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    /* ragged edge (first / last 16 bytes of the buffer): byte by byte */
+    uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+    for (int i = 0; i < 16; i++) {
+        int64_t p = g + i;
+        if (p >= (int64_t)sv.lead && p < (int64_t)sv.n_total) {
+            uint32_t c = sv.base[p];
+            w[i >> 2] = (w[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | (c << (8 * (i & 3)));
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+/* The 48-base window of one lane: its own 16 bases and the 32 before them. */
+struct Window {
+    uint32_t w0, w1, w2;     /* forward: own, lane-1, lane-2 (w2 oldest)         */
+    uint32_t r0, r1, r2;     /* reverse-complement image: r0 oldest 16 bases     */
+    uint64_t bad;            /* 48 flags, oldest base in bit 47                  */
+    uint32_t emit;           /* 16 bits, base 0 in bit 15: this position may emit */
+    uint32_t n_bases;        /* sequence characters among the own 16 that count  */
+};
+
+/* Window of the lane whose own 16 bytes start at byte g (relative to sv.base),
+ * given its packed bytes p and those of the two lanes before it (p1 = lane-1,
+ * p2 = lane-2).  Pure function: runs on the host too (tests/emul). */
+template <bool K30>
+__host__ __device__ __forceinline__ Window assemble_window(const SeqView &sv, int64_t g, bool halo_lane,
+                                                           Packed p, Packed p1, Packed p2, uint32_t k)
+{
+    Window W;
+    W.w0 = p.fwd;
+    W.w1 = p1.fwd;
+    W.w2 = p2.fwd;
+    W.bad = ((uint64_t)p2.bad << 32) | ((uint64_t)p1.bad << 16) | p.bad;
+    W.r0 = rc_word(W.w2);
+    W.r1 = rc_word(W.w1);
+    W.r2 = rc_word(W.w0);
+    /* positions of this lane that lie in [emit_from, n_total) */
+    uint32_t in_range = 0;
+    {
+        int64_t lo = (int64_t)sv.emit_from - g, hi = (int64_t)sv.n_total - g; /* j in [lo, hi) */
+        lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+        hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+        if (hi > lo) in_range = ((0xFFFFu >> lo) & ~(0xFFFFu >> hi)) & 0xFFFFu;
+    }
+    if (halo_lane) in_range = 0;                   /* halo lanes never emit      */
+    W.n_bases = __builtin_popcount(in_range & ~p.nl);
+    /* emission: the last k characters hold no reset (run >= k, :418) */
+    uint32_t emit = 0;
+    const uint64_t kbits = (1ull << (K30 ? 30 : k)) - 1;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (((W.bad >> (15 - j)) & kbits) == 0) emit |= 0x8000u >> j;
+    emit &= in_range;
+    /* the reference's run counter is a uint16 (:402): in an N-free run the
+     * windows ending at run positions 65536*m .. 65536*m + k-1 are dropped.
+     * The host (or the caller) lists the byte position of each run position
+     * 65536*m; windows ending in [s, s+k-1] are suppressed. */
+    if (sv.n_suppress) {
+        /* list entries are relative to payload byte 0 (= base + lead) */
+        const int64_t hi_pos = g + 15 - (int64_t)sv.lead;
+        if (hi_pos >= 0) {
+            uint64_t a = 0, b = sv.n_suppress;           /* first entry > hi_pos */
+            while (a < b) {
+                uint64_t m = (a + b) >> 1;
+                if (sv.suppress[m] <= (uint64_t)hi_pos) a = m + 1; else b = m;
+            }
+            if (a > 0) {
+                const int64_t s = (int64_t)sv.suppress[a - 1] + (int64_t)sv.lead;
+                const int kk = K30 ? 30 : (int)k;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int64_t pos = g + j;
+                    if (pos >= s && pos < s + kk) emit &= ~(0x8000u >> j);
+                }
+            }
+        }
+    }
+    W.emit = emit;
+    return W;
+}
+
+/* Byte offset (from sv.base) of the 16 bytes lane `lane` owns in the tile that
+ * starts at byte tile0. */
+__host__ __device__ __forceinline__ int64_t lane_offset(uint64_t tile0, int lane)
+{
+    return (int64_t)tile0 - kHaloLanes * kBytesPerLane + (int64_t)lane * kBytesPerLane;
+}
+
+/* Build the window for `lane` of a wave whose tile starts at byte tile0.
+ * All 64 lanes must call (wave shuffles inside). */
+template <bool K30>
+__device__ __forceinline__ Window make_window(const SeqView &sv, uint64_t tile0, int lane, uint32_t k)
+{
+    const int64_t g = lane_offset(tile0, lane);
+    const Packed p = pack16(load16(sv, g));
+    Packed p1, p2;
+    p1.fwd = __shfl_up(p.fwd, 1); p1.bad = __shfl_up(p.bad, 1); p1.nl = 0;
+    p2.fwd = __shfl_up(p.fwd, 2); p2.bad = __shfl_up(p.bad, 2); p2.nl = 0;
+    return assemble_window<K30>(sv, g, lane < kHaloLanes, p, p1, p2, k);
+}
+
+/* Canonical k-mer of own position j (compile-time j), rules of :412-420. */
+template <bool K30, int J>
+__host__ __device__ __forceinline__ uint64_t kmer_at(const Window &W, uint32_t k)
+{
+    constexpr int s = 2 * (15 - J);
+    uint32_t flo = funnel_r(W.w0, W.w1, s);
+    uint32_t fhi = funnel_r(W.w1, W.w2, s);
+    uint64_t fwd = ((uint64_t)fhi << 32) | flo;
+    constexpr int t = 2 * (3 + J);
+    uint32_t rlo, rhi;
+    if constexpr (t < 32) {
+        rlo = funnel_r(W.r0, W.r1, t);
+        rhi = funnel_r(W.r1, W.r2, t);
+    } else {
+        rlo = funnel_r(W.r1, W.r2, t - 32);
+        rhi = W.r2 >> (t - 32);
+    }
+    uint64_t rc = (((uint64_t)rhi << 32) | rlo) & kMask60;
+    if (K30) {
+        fwd &= kMask60;
+    } else {
+        fwd &= (1ull << (2 * k)) - 1;                   /* :419 */
+        /* rc holds only the bases since the last reset (:404-407 zero it):
+         * keep the top 2*m bits, m = min(run, 30) */
+        uint64_t b = (W.bad >> (15 - J)) | (1ull << 30);
+        int m = __builtin_ctzll(b);              /* trailing clean bases */
+        if (m < 30) rc &= ~((1ull << (2 * (30 - m))) - 1);
+    }
+    return fwd < rc ? fwd : rc;                          /* :420 */
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+}  // namespace qm2

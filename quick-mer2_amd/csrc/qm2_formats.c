@@ -1,0 +1,155 @@
+/*
+ * qm2_formats.c — .qm reader and .bin / .txt writers of `quicKmer2 count`.
+ * Formats per SURVEY Appendix A; behaviour per QuicKmer.c:334-366 and :483-545.
+ */
+#define _GNU_SOURCE
+#include <stdlib.h>
+#include <string.h>
+
+#include "qm2_host.h"
+
+#define QM2_FLUSH_ENTRIES (1u << 20)    /* the reference flushes .bin every 2^20 entries (:11, :511) */
+
+int qm2_dict_open(const char *ref_prefix, qm2_dict_file *d)
+{
+    memset(d, 0, sizeof *d);
+    size_t len = strlen(ref_prefix);
+    char *path = malloc(len + 8);
+    if (!path) { puts("Memory allocation failed"); return 1; }
+    memcpy(path, ref_prefix, len);
+    memcpy(path + len, ".qm", 4);
+    d->fp = fopen(path, "rb");                               /* :337 */
+    if (!d->fp) {
+        /* the reference does not check this fopen and crashes; say why instead */
+        printf("Cannot open dictionary %s\n", path);
+        free(path);
+        return 1;
+    }
+    free(path);
+    unsigned char hdr[24];
+    if (fread(hdr, 1, sizeof hdr, d->fp) != sizeof hdr) {
+        puts("Dictionary file is too short");
+        qm2_dict_close(d);
+        return 1;
+    }
+    d->k = hdr[4];                                           /* :345-347 */
+    memcpy(&d->hash_size, hdr + 8, 8);                       /* :348-349 */
+    memcpy(&d->first_idx, hdr + 16, 8);                      /* :350-351 */
+    printf("Hash Size: 0x%lX\nFirst location: 0x%lX\n",      /* :352 */
+           (unsigned long)d->hash_size, (unsigned long)d->first_idx);
+    const uint64_t H = d->hash_size;
+    if (H < 2 || (H & (H - 1)) || H > ((uint64_t)1 << 32)) {
+        puts("Dictionary header holds an impossible hash size");
+        qm2_dict_close(d);
+        return 1;
+    }
+    d->keys = malloc(H * sizeof(uint64_t));                  /* :353 */
+    if (!d->keys) {
+        puts("Memory allocation failed");                    /* :355 */
+        qm2_dict_close(d);
+        return 1;
+    }
+    d->keys_read = fread(d->keys, sizeof(uint64_t), H, d->fp);
+    printf("Read 0x%lX hash\n", (unsigned long)d->keys_read);/* :359 */
+    if (d->keys_read != H) {
+        puts("Dictionary file is truncated");
+        qm2_dict_close(d);
+        return 1;
+    }
+    return 0;
+}
+
+void qm2_dict_close(qm2_dict_file *d)
+{
+    if (d->fp) fclose(d->fp);
+    free(d->keys);
+    d->fp = NULL;
+    d->keys = NULL;
+}
+
+int qm2_write_outputs(qm2_dict_file *d, const uint16_t *depth, const char *ref_prefix,
+                      const char *out_prefix)
+{
+    const uint64_t H = d->hash_size;
+    /* the key buffer is dead now: the chain is read over it (:483, :490) */
+    uint32_t *chain = (uint32_t *)d->keys;
+    size_t got = fread(chain, sizeof(uint32_t), H, d->fp);
+    printf("Pileup finish\nRead chain file %lu entries\n", (unsigned long)got);   /* :483 */
+    if (got != H) { puts("Dictionary chain is truncated"); return 1; }
+
+    size_t plen = strlen(ref_prefix), olen = strlen(out_prefix);
+    char *path = malloc((plen > olen ? plen : olen) + 8);
+    if (!path) { puts("Memory allocation failed"); return 1; }
+
+    memcpy(path, ref_prefix, plen);
+    memcpy(path + plen, ".qgc", 5);                          /* :484-486 */
+    FILE *qgc = fopen(path, "rb");
+    if (!qgc) printf("GC control file %s absent. Continue without GC correction!\n", path); /* :488 */
+
+    memcpy(path, out_prefix, olen);
+    memcpy(path + olen, ".bin", 5);                          /* :342-344 */
+    FILE *bin = fopen(path, "wb");
+    if (!bin) {
+        printf("Cannot create %s\n", path);
+        if (qgc) fclose(qgc);
+        free(path);
+        return 1;
+    }
+
+    uint16_t *out = malloc(QM2_FLUSH_ENTRIES * sizeof(uint16_t));
+    uint16_t *gc = malloc(QM2_FLUSH_ENTRIES * sizeof(uint16_t));
+    if (!out || !gc) { puts("Memory allocation failed"); free(out); free(gc); free(path); return 1; }
+    double sum[401], sumsq[401];
+    uint32_t cnt[401];
+    memset(sum, 0, sizeof sum); memset(sumsq, 0, sizeof sumsq); memset(cnt, 0, sizeof cnt);
+
+    const uint32_t first = (uint32_t)d->first_idx;           /* :494 */
+    uint32_t at = first, fill = 0;
+    do {                                                     /* :498-516 */
+        const uint16_t v = depth[at];
+        out[fill] = v;
+        at = chain[at];
+        if (qgc) {
+            if (fill == 0 && fread(gc, sizeof(uint16_t), QM2_FLUSH_ENTRIES, qgc) == 0) gc[0] = 0;
+            const uint16_t g = gc[fill];
+            if (g & 0x8000) {                                /* control-region k-mer (:504) */
+                const uint32_t b = g & 0x1FF;
+                if (b < 401) {
+                    sum[b] += v;
+                    cnt[b]++;
+                    sumsq[b] += (int)v * (int)v;
+                }
+            }
+        }
+        if (++fill == QM2_FLUSH_ENTRIES) {
+            fwrite(out, sizeof(uint16_t), fill, bin);
+            fill = 0;
+        }
+    } while (at != first);
+    fwrite(out, sizeof(uint16_t), fill, bin);                /* :517 */
+    fclose(bin);
+    free(out); free(gc);
+
+    if (qgc) {                                               /* :522-542 */
+        fclose(qgc);
+        memcpy(path + olen, ".txt", 5);
+        FILE *txt = fopen(path, "w");
+        if (!txt) { printf("Cannot create %s\n", path); free(path); return 1; }
+        double all_sum = 0;
+        uint64_t all_cnt = 0;
+        for (int i = 0; i < 401; i++) {
+            all_cnt += cnt[i];
+            all_sum += sum[i];
+            double mean = sum[i], var = sumsq[i];
+            if (cnt[i]) {
+                mean = sum[i] / cnt[i];
+                var = sumsq[i] / cnt[i] - mean * mean;
+            }
+            fprintf(txt, "%.2f\t%f\t%i\t%f\n", i / 4.0, mean, (int)cnt[i], var);   /* :536 */
+        }
+        fclose(txt);
+        printf("Mean sequencing depth: %.2f\n", all_sum / (double)all_cnt);        /* :540 */
+    }
+    free(path);
+    return 0;
+}

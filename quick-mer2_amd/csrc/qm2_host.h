@@ -1,0 +1,46 @@
+/*
+ * qm2_host.h — host-side (plain C) pieces of `quicKmer2 count` around the
+ * C-ABI of include/qm2.h: on-disk formats, the input line discipline and the
+ * command itself.  Mirrors the reference's main_count (QuicKmer.c:304-545)
+ * region by region; nothing here touches the GPU directly.
+ */
+#ifndef QM2_HOST_H
+#define QM2_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/qm2.h"
+
+/* ---- .qm dictionary ---------------------------------- */
+typedef struct {
+    FILE     *fp;          /* left open: the chain is read later (:483)          */
+    uint32_t  k;           /* byte @4  (:345-347)                                */
+    uint64_t  hash_size;   /* u64 @8   (:348-349)                                */
+    uint64_t  first_idx;   /* u64 @16  (:350-351)                                */
+    uint64_t *keys;        /* H x u64 from @24 (:353-359); later reused for the
+                              H x u32 chain exactly as the reference does (:490) */
+    uint64_t  keys_read;
+} qm2_dict_file;
+
+int  qm2_dict_open(const char *ref_prefix, qm2_dict_file *d);
+void qm2_dict_close(qm2_dict_file *d);
+
+/* Epilogue (:483-542): chain walk -> <out>.bin, optional .qgc stats -> <out>.txt.
+ * Prints the reference's stdout lines. */
+int qm2_write_outputs(qm2_dict_file *d, const uint16_t *depth, const char *ref_prefix,
+                      const char *out_prefix);
+
+/* ---- input line discipline (:393-398, :451-455) ---------------------------- */
+typedef int (*qm2_lines_sink)(void *user, const char *lines, size_t n);
+
+/* Streams `path` (file, pipe or /dev/fd/N), strips it to sequence lines and
+ * hands batches of whole '\n'-terminated lines (<= batch_bytes unless a single
+ * line is longer) to `sink`.  Returns 0, or non-zero after printing a message. */
+int qm2_stream_reads(const char *path, size_t batch_bytes, qm2_lines_sink sink, void *user);
+
+/* ---- the command ----------------------------------------------------------- */
+int qm2_main_count(int argc, char **argv);
+
+#endif

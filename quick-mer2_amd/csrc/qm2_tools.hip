@@ -1,0 +1,368 @@
+/*
+ * qm2_tools.hip — device-side synthetic workload generators and the
+ * random-access microbenchmarks (include/qm2_tools.h).  Bench/test tooling;
+ * not on the `count` path.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/qm2_tools.h"
+#include "qm2_device.hip.h"
+
+using namespace qm2;
+
+#define T_OK(call)                                                                \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            printf("qm2 tools: %s failed: %s\n", #call, hipGetErrorString(e_));   \
+            fflush(stdout);                                                       \
+            return 1;                                                             \
+        }                                                                         \
+    } while (0)
+
+namespace {
+
+__host__ __device__ inline uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline uint64_t rnd(uint64_t seed, uint64_t stream, uint64_t i)
+{
+    return mix64(mix64(seed ^ (stream * 0xD6E8FEB86659FD93ull)) + i);
+}
+__host__ __device__ inline float u01(uint64_t r) { return (float)(r >> 40) * (1.0f / 16777216.0f); }
+
+struct GenomeParams {
+    uint64_t n, seed;
+    float gc_lo, gc_hi;
+    const qm2t_range *n_blocks;
+    uint32_t n_n_blocks;
+    const qm2t_dup *dups;
+    uint32_t n_dups;
+};
+
+__device__ inline uint8_t genome_base(const GenomeParams &g, uint64_t p)
+{
+    /* inside an N block? (sorted by start) */
+    {
+        uint32_t a = 0, b = g.n_n_blocks;
+        while (a < b) { uint32_t m = (a + b) >> 1; if (g.n_blocks[m].start <= p) a = m + 1; else b = m; }
+        if (a > 0 && p < g.n_blocks[a - 1].start + g.n_blocks[a - 1].len) return 'N';
+    }
+    /* inside a duplicated segment? (sorted by dst) */
+    {
+        uint32_t a = 0, b = g.n_dups;
+        while (a < b) { uint32_t m = (a + b) >> 1; if (g.dups[m].dst <= p) a = m + 1; else b = m; }
+        if (a > 0 && p < g.dups[a - 1].dst + g.dups[a - 1].len) p = g.dups[a - 1].src + (p - g.dups[a - 1].dst);
+    }
+    const float gc = g.gc_lo + (g.gc_hi - g.gc_lo) * u01(rnd(g.seed, 1, p / 10000));
+    const uint64_t r = rnd(g.seed, 2, p);
+    const bool strong = u01(r) < gc;
+    const bool second = (r & 1) != 0;
+    return strong ? (second ? 'G' : 'C') : (second ? 'T' : 'A');
+}
+
+__global__ void genome_kernel(uint8_t *out, GenomeParams g)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < g.n; i += stride) out[i] = genome_base(g, i);
+}
+
+/* ---- dictionary ------------------------------------------------------------ */
+
+constexpr uint64_t kDupFlag = 1ull << 63;
+
+__device__ inline void table_insert(uint64_t *T, uint32_t hmask, uint32_t hhalf, uint64_t km, bool flag_dups)
+{
+    uint32_t i = djb32(km) & hmask;
+    const uint32_t step = (i & hhalf) ? 0xFFFFFFFFu : 1u;
+    for (;;) {
+        unsigned long long old = atomicCAS((unsigned long long *)&T[i], 0ull, (unsigned long long)km);
+        if (old == 0) return;
+        if ((old & ~kDupFlag) == km) {
+            if (flag_dups && !(old & kDupFlag)) atomicOr((unsigned long long *)&T[i], (unsigned long long)kDupFlag);
+            return;
+        }
+        i += step;
+    }
+}
+
+template <bool K30>
+__global__ __launch_bounds__(kBlock) void dict_insert_kernel(SeqView sv, uint32_t k, uint64_t n_tiles,
+                                                            uint64_t *T, uint32_t hmask, uint32_t hhalf)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) / kWave;
+    for (uint64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const Window W = make_window<K30>(sv, tile * kTileBytes, lane, k);
+#define QM2_INS(J)                                                                \
+        if (W.emit & (0x8000u >> J)) {                                            \
+            const uint64_t km = kmer_at<K30, J>(W, k);                            \
+            if (km) table_insert(T, hmask, hhalf, km, true);   /* :864: k-mer 0 is never stored */ \
+        }
+        QM2_INS(0) QM2_INS(1) QM2_INS(2) QM2_INS(3) QM2_INS(4) QM2_INS(5) QM2_INS(6) QM2_INS(7)
+        QM2_INS(8) QM2_INS(9) QM2_INS(10) QM2_INS(11) QM2_INS(12) QM2_INS(13) QM2_INS(14) QM2_INS(15)
+#undef QM2_INS
+    }
+}
+
+__global__ void dict_rebuild_kernel(const uint64_t *A, uint64_t H, uint64_t *T, uint32_t hmask, uint32_t hhalf,
+                                    unsigned long long *n_distinct, unsigned long long *n_unique)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long d = 0, u = 0;
+    for (; i < H; i += stride) {
+        const uint64_t v = A[i];
+        if (v == 0) continue;
+        d++;
+        if (v & kDupFlag) continue;                            /* :1222: occurs more than once */
+        u++;
+        table_insert(T, hmask, hhalf, v, false);
+    }
+    d = wave_sum(d); u = wave_sum(u);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(n_distinct, d); atomicAdd(n_unique, u); }
+}
+
+/* ---- reads ----------------------------------------------------------------- */
+
+struct ReadParams {
+    const uint8_t *genome;
+    uint64_t n;
+    uint8_t *out;
+    const uint64_t *offsets;
+    uint64_t n_reads, first_read;
+    uint32_t len_lo, len_hi;
+    uint64_t seed;
+    float sub_rate, n_read_frac;
+};
+
+__host__ __device__ inline uint32_t read_len(uint64_t seed, uint64_t R, uint32_t lo, uint32_t hi)
+{
+    return lo == hi ? lo : lo + (uint32_t)(rnd(seed, 3, R) % (uint64_t)(hi - lo + 1));
+}
+
+__device__ inline uint8_t read_byte(const ReadParams &p, uint64_t R, uint32_t len, uint32_t i)
+{
+    if (i == len) return '\n';
+    const uint64_t pos = rnd(p.seed, 4, R) % (p.n - len + 1);
+    const bool rc = (rnd(p.seed, 5, R) & 1) != 0;
+    uint8_t c = p.genome[rc ? pos + (len - 1 - i) : pos + i];
+    if (rc) c = (c == 'A') ? 'T' : (c == 'T') ? 'A' : (c == 'C') ? 'G' : (c == 'G') ? 'C' : c;
+    const uint64_t e = rnd(p.seed, 8, (R << 20) + i);
+    if (u01(e) < p.sub_rate) c = "ACGT"[e & 3];
+    if (u01(rnd(p.seed, 6, R)) < p.n_read_frac && (uint32_t)(rnd(p.seed, 7, R) % len) == i) c = 'N';
+    return c;
+}
+
+/* fixed-length reads: one thread per output byte */
+__global__ void reads_fixed_kernel(ReadParams p)
+{
+    const uint64_t line = (uint64_t)p.len_lo + 1;
+    const uint64_t total = p.n_reads * line;
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; t < total; t += stride) {
+        const uint64_t r = t / line;
+        p.out[t] = read_byte(p, p.first_read + r, p.len_lo, (uint32_t)(t - r * line));
+    }
+}
+
+/* variable-length (long) reads: one block per read */
+__global__ void reads_var_kernel(ReadParams p)
+{
+    for (uint64_t r = blockIdx.x; r < p.n_reads; r += gridDim.x) {
+        const uint64_t R = p.first_read + r;
+        const uint32_t len = read_len(p.seed, R, p.len_lo, p.len_hi);
+        uint8_t *dst = p.out + p.offsets[r];
+        for (uint32_t i = threadIdx.x; i <= len; i += blockDim.x) dst[i] = read_byte(p, R, len, i);
+    }
+}
+
+/* ---- microbenchmarks ------------------------------------------------------- */
+
+template <int MODE>
+__global__ __launch_bounds__(256) void micro_kernel(const uint64_t *keys, uint32_t *cnt, uint64_t mask,
+                                                    uint64_t n_ops, uint64_t seed, unsigned long long *sink)
+{
+    const uint64_t t0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16;
+    unsigned long long acc = 0;
+    for (uint64_t t = t0; t < n_ops; t += stride) {
+        uint64_t idx[16];
+        uint64_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) idx[j] = mix64(seed + t + j) & mask;
+        if (MODE == 0 || MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = keys[idx[j]];
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) atomicAdd(&cnt[idx[j]], 1u);
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (v[j] != 0x1234567ull) atomicAdd(&cnt[idx[j]], 1u);
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc += v[j];
+        }
+    }
+    if (MODE == 0 && acc == 0x7FFFFFFFFFFFull) *sink = acc;   /* keep the loads alive */
+}
+
+}  // namespace
+
+extern "C" int qm2t_genome_generate(void *d_genome, uint64_t n, uint64_t seed, float gc_lo, float gc_hi,
+                                    const qm2t_range *n_blocks, uint32_t n_n_blocks,
+                                    const qm2t_dup *dups, uint32_t n_dups, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<qm2t_range> nb(n_blocks, n_blocks + n_n_blocks);
+    std::vector<qm2t_dup> dp(dups, dups + n_dups);
+    std::sort(nb.begin(), nb.end(), [](const qm2t_range &a, const qm2t_range &b) { return a.start < b.start; });
+    std::sort(dp.begin(), dp.end(), [](const qm2t_dup &a, const qm2t_dup &b) { return a.dst < b.dst; });
+    qm2t_range *d_nb = nullptr;
+    qm2t_dup *d_dp = nullptr;
+    if (n_n_blocks) {
+        T_OK(hipMalloc((void **)&d_nb, n_n_blocks * sizeof(qm2t_range)));
+        T_OK(hipMemcpy(d_nb, nb.data(), n_n_blocks * sizeof(qm2t_range), hipMemcpyHostToDevice));
+    }
+    if (n_dups) {
+        T_OK(hipMalloc((void **)&d_dp, n_dups * sizeof(qm2t_dup)));
+        T_OK(hipMemcpy(d_dp, dp.data(), n_dups * sizeof(qm2t_dup), hipMemcpyHostToDevice));
+    }
+    GenomeParams g = {n, seed, gc_lo, gc_hi, d_nb, n_n_blocks, d_dp, n_dups};
+    hipLaunchKernelGGL(genome_kernel, dim3(4096), dim3(256), 0, s, (uint8_t *)d_genome, g);
+    T_OK(hipGetLastError());
+    T_OK(hipStreamSynchronize(s));
+    if (d_nb) T_OK(hipFree(d_nb));
+    if (d_dp) T_OK(hipFree(d_dp));
+    return 0;
+}
+
+extern "C" int qm2t_dict_build(const void *d_genome, uint64_t n, uint32_t k, uint64_t *d_keys, uint64_t H,
+                               uint64_t *d_scratch, uint64_t *n_distinct, uint64_t *n_unique, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (k < 1 || k > 31 || H < 2 || (H & (H - 1)) || H > (1ull << 32)) {
+        puts("qm2 tools: bad k or H");
+        return 1;
+    }
+    const uint32_t hmask = (uint32_t)(H - 1), hhalf = (uint32_t)(H >> 1);
+    T_OK(hipMemsetAsync(d_scratch, 0, H * sizeof(uint64_t), s));
+    T_OK(hipMemsetAsync(d_keys, 0, H * sizeof(uint64_t), s));
+    SeqView sv;
+    const uintptr_t p = (uintptr_t)d_genome;
+    sv.lead = p & 15u;
+    sv.base = (const uint8_t *)(p - sv.lead);
+    sv.emit_from = sv.lead;
+    sv.n_total = sv.lead + n;
+    sv.suppress = nullptr;
+    sv.n_suppress = 0;
+    const uint64_t n_tiles = (sv.n_total + kTileBytes - 1) / kTileBytes;
+    const int grid = (int)std::min<uint64_t>((n_tiles + 3) / 4, 2048);
+    if (k == 30)
+        hipLaunchKernelGGL(dict_insert_kernel<true>, dim3(grid), dim3(kBlock), 0, s, sv, k, n_tiles, d_scratch, hmask, hhalf);
+    else
+        hipLaunchKernelGGL(dict_insert_kernel<false>, dim3(grid), dim3(kBlock), 0, s, sv, k, n_tiles, d_scratch, hmask, hhalf);
+    T_OK(hipGetLastError());
+    unsigned long long *d_cnt = nullptr;
+    T_OK(hipMalloc((void **)&d_cnt, 2 * sizeof(unsigned long long)));
+    T_OK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(dict_rebuild_kernel, dim3(2048), dim3(256), 0, s, d_scratch, H, d_keys, hmask, hhalf,
+                       d_cnt, d_cnt + 1);
+    T_OK(hipGetLastError());
+    unsigned long long h_cnt[2];
+    T_OK(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, s));
+    T_OK(hipStreamSynchronize(s));
+    T_OK(hipFree(d_cnt));
+    if (n_distinct) *n_distinct = h_cnt[0];
+    if (n_unique) *n_unique = h_cnt[1];
+    return 0;
+}
+
+extern "C" void qm2t_read_offsets(uint64_t *offsets, uint64_t n_reads, uint64_t first_read,
+                                  uint32_t len_lo, uint32_t len_hi, uint64_t seed)
+{
+    uint64_t at = 0;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        offsets[r] = at;
+        at += (uint64_t)read_len(seed, first_read + r, len_lo, len_hi) + 1;
+    }
+    offsets[n_reads] = at;
+}
+
+extern "C" int qm2t_reads_generate(const void *d_genome, uint64_t n, void *d_out, const uint64_t *d_offsets,
+                                   uint64_t n_reads, uint64_t first_read, uint32_t len_lo, uint32_t len_hi,
+                                   uint64_t seed, float sub_rate, float n_read_frac, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (len_lo == 0 || len_hi < len_lo || (uint64_t)len_hi > n || len_hi >= (1u << 20)) {
+        puts("qm2 tools: bad read length range");
+        return 1;
+    }
+    ReadParams p = {(const uint8_t *)d_genome, n, (uint8_t *)d_out, d_offsets, n_reads, first_read,
+                    len_lo, len_hi, seed, sub_rate, n_read_frac};
+    if (len_lo == len_hi)
+        hipLaunchKernelGGL(reads_fixed_kernel, dim3(8192), dim3(256), 0, s, p);
+    else {
+        if (!d_offsets) { puts("qm2 tools: variable-length reads need offsets"); return 1; }
+        hipLaunchKernelGGL(reads_var_kernel, dim3((unsigned)std::min<uint64_t>(n_reads, 65536)), dim3(256), 0, s, p);
+    }
+    T_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int qm2t_microbench(uint64_t slots, uint64_t n_ops, int mode, int repeats, double *ms_out)
+{
+    if (slots < 2 || (slots & (slots - 1)) || mode < 0 || mode > 2 || repeats < 1) {
+        puts("qm2 tools: bad microbench arguments");
+        return 1;
+    }
+    uint64_t *keys = nullptr;
+    uint32_t *cnt = nullptr;
+    unsigned long long *sink = nullptr;
+    T_OK(hipMalloc((void **)&keys, slots * sizeof(uint64_t)));
+    T_OK(hipMalloc((void **)&cnt, slots * sizeof(uint32_t)));
+    T_OK(hipMalloc((void **)&sink, sizeof(unsigned long long)));
+    T_OK(hipMemset(keys, 0x5A, slots * sizeof(uint64_t)));
+    T_OK(hipMemset(cnt, 0, slots * sizeof(uint32_t)));
+    hipEvent_t a, b;
+    T_OK(hipEventCreate(&a));
+    T_OK(hipEventCreate(&b));
+    double best = 1e30;
+    for (int r = 0; r < repeats + 1; r++) {
+        T_OK(hipEventRecord(a, 0));
+        const uint64_t seed = 0x1234 + (uint64_t)r * 0x9E3779B97F4A7C15ull;
+        if (mode == 0) hipLaunchKernelGGL(micro_kernel<0>, dim3(2048), dim3(256), 0, 0, keys, cnt, slots - 1, n_ops, seed, sink);
+        if (mode == 1) hipLaunchKernelGGL(micro_kernel<1>, dim3(2048), dim3(256), 0, 0, keys, cnt, slots - 1, n_ops, seed, sink);
+        if (mode == 2) hipLaunchKernelGGL(micro_kernel<2>, dim3(2048), dim3(256), 0, 0, keys, cnt, slots - 1, n_ops, seed, sink);
+        T_OK(hipGetLastError());
+        T_OK(hipEventRecord(b, 0));
+        T_OK(hipEventSynchronize(b));
+        float ms = 0.f;
+        T_OK(hipEventElapsedTime(&ms, a, b));
+        if (r > 0 && ms < best) best = ms;     /* first pass is a warm-up */
+    }
+    T_OK(hipEventDestroy(a));
+    T_OK(hipEventDestroy(b));
+    T_OK(hipFree(keys));
+    T_OK(hipFree(cnt));
+    T_OK(hipFree(sink));
+    if (ms_out) *ms_out = best;
+    return 0;
+}

@@ -1,0 +1,247 @@
+"""ctypes binding of the C-ABI in include/qm2.h (libqm2_hip.so).
+
+This is the reference-side stub a Python caller would use (INTEGRATION.md shows
+the C one).  It holds no algorithm: every call goes straight to the HIP
+library.  There is no CPU fallback — if the library is missing or no GPU is
+usable the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libqm2_hip.so")
+
+FLAG_TIMING = 0x1
+FLAG_NO_STATS = 0x2
+
+
+class Opts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("n_staging", C.c_uint32), ("staging_bytes", C.c_uint64),
+                ("ext_keys", C.c_void_p), ("ext_counters", C.c_void_p), ("stream", C.c_void_p),
+                ("span_lo", C.c_uint64), ("span_hi", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_bases", C.c_uint64), ("n_kmers", C.c_uint64),
+                ("n_probes", C.c_uint64), ("n_hits", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class Profile(C.Structure):
+    _fields_ = [("n_launches", C.c_uint64), ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double)]
+
+
+class Range(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("len", C.c_uint64)]
+
+
+class Dup(C.Structure):
+    _fields_ = [("dst", C.c_uint64), ("src", C.c_uint64), ("len", C.c_uint64)]
+
+
+# every symbol include/qm2.h and include/qm2_tools.h declare
+ABI_SYMBOLS = ["qm2_open", "qm2_submit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
+               "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
+               "qm2_encode_device", "qm2_probe_device", "qm2_shard_span", "qm2_last_error",
+               "qm2_abi_version"]
+TOOL_SYMBOLS = ["qm2t_genome_generate", "qm2t_dict_build", "qm2t_reads_generate",
+                "qm2t_read_offsets", "qm2t_microbench"]
+
+_LIB = None
+
+
+def lib():
+    """Load libqm2_hip.so; raises (never falls back) when it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libqm2_hip.so is not built (run `make -C quick-mer2_amd` or "
+                           "__graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.qm2_open.restype = C.c_int
+    L.qm2_open.argtypes = [C.POINTER(vp), vp, u64, u32, C.POINTER(Opts)]
+    L.qm2_submit.restype = C.c_int
+    L.qm2_submit.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.qm2_submit_device.restype = C.c_int
+    L.qm2_submit_device.argtypes = [vp, vp, C.c_size_t, vp, u64]
+    L.qm2_sync.restype = C.c_int
+    L.qm2_sync.argtypes = [vp]
+    L.qm2_finish.restype = C.c_int
+    L.qm2_finish.argtypes = [vp, vp, C.POINTER(Stats)]
+    L.qm2_reset.restype = C.c_int
+    L.qm2_reset.argtypes = [vp]
+    L.qm2_close.restype = None
+    L.qm2_close.argtypes = [vp]
+    L.qm2_counters_device.restype = vp
+    L.qm2_counters_device.argtypes = [vp]
+    L.qm2_keys_device.restype = vp
+    L.qm2_keys_device.argtypes = [vp]
+    L.qm2_get_profile.restype = C.c_int
+    L.qm2_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    L.qm2_encode_device.restype = C.c_int
+    L.qm2_encode_device.argtypes = [vp, vp, C.c_size_t, vp, u64, vp, u64, u32, vp]
+    L.qm2_probe_device.restype = C.c_int
+    L.qm2_probe_device.argtypes = [vp, vp, u64, vp]
+    L.qm2_shard_span.restype = C.c_int
+    L.qm2_shard_span.argtypes = [vp, u64, u32, u32] + [C.POINTER(u64)] * 4
+    L.qm2_last_error.restype = C.c_char_p
+    L.qm2_abi_version.restype = u32
+    L.qm2t_genome_generate.restype = C.c_int
+    L.qm2t_genome_generate.argtypes = [vp, u64, u64, C.c_float, C.c_float, C.POINTER(Range), u32,
+                                       C.POINTER(Dup), u32, vp]
+    L.qm2t_dict_build.restype = C.c_int
+    L.qm2t_dict_build.argtypes = [vp, u64, u32, vp, u64, vp, C.POINTER(u64), C.POINTER(u64), vp]
+    L.qm2t_reads_generate.restype = C.c_int
+    L.qm2t_reads_generate.argtypes = [vp, u64, vp, vp, u64, u64, u32, u32, u64, C.c_float, C.c_float, vp]
+    L.qm2t_read_offsets.restype = None
+    L.qm2t_read_offsets.argtypes = [vp, u64, u64, u32, u32, u64]
+    L.qm2t_microbench.restype = C.c_int
+    L.qm2t_microbench.argtypes = [u64, u64, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    _LIB = L
+    return L
+
+
+class Qm2Error(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise Qm2Error("%s failed: %s" % (what, lib().qm2_last_error().decode(errors="replace")))
+
+
+class Counter:
+    """One counting context (qm2_ctx).  keys: host uint64[H] (or None with ext_keys)."""
+
+    def __init__(self, keys, hash_size=None, k=30, device=-1, flags=0, n_staging=0, staging_bytes=0,
+                 ext_keys=None, ext_counters=None, stream=None, span=None):
+        L = lib()
+        self._h = C.c_void_p()
+        o = Opts()
+        o.struct_size = C.sizeof(Opts)
+        o.device = device
+        o.flags = flags
+        o.n_staging = n_staging
+        o.staging_bytes = staging_bytes
+        o.ext_keys = ext_keys
+        o.ext_counters = ext_counters
+        o.stream = stream
+        if span is not None:
+            o.span_lo, o.span_hi = int(span[0]), int(span[1])
+        kp = None
+        if keys is not None:
+            keys = np.ascontiguousarray(keys, dtype=np.uint64)
+            kp = keys.ctypes.data
+            if hash_size is None:
+                hash_size = len(keys)
+        self.H = int(hash_size)
+        self.n_slots = (int(span[1]) - int(span[0])) if span is not None else self.H
+        self.k = k
+        _check(L.qm2_open(C.byref(self._h), kp, self.H, k, C.byref(o)), "qm2_open")
+
+    def submit(self, lines: bytes):
+        _check(lib().qm2_submit(self._h, lines, len(lines)), "qm2_submit")
+
+    def submit_device(self, ptr, n, suppress_ptr=None, n_suppress=0):
+        _check(lib().qm2_submit_device(self._h, ptr, n, suppress_ptr, n_suppress), "qm2_submit_device")
+
+    def encode_device(self, ptr, n, out_ptr, bucket_cap, n_buckets, counts_ptr, suppress_ptr=None, n_suppress=0):
+        _check(lib().qm2_encode_device(self._h, ptr, n, suppress_ptr, n_suppress, out_ptr, bucket_cap,
+                                       n_buckets, counts_ptr), "qm2_encode_device")
+
+    def probe_device(self, kmers_ptr, n, n_ptr=None):
+        _check(lib().qm2_probe_device(self._h, kmers_ptr, n, n_ptr), "qm2_probe_device")
+
+    def sync(self):
+        _check(lib().qm2_sync(self._h), "qm2_sync")
+
+    def finish(self, want_depth=True):
+        st = Stats()
+        depth = np.empty(self.n_slots, dtype=np.uint16) if want_depth else None
+        _check(lib().qm2_finish(self._h, depth.ctypes.data if want_depth else None, C.byref(st)), "qm2_finish")
+        return depth, st.as_dict()
+
+    def reset(self):
+        _check(lib().qm2_reset(self._h), "qm2_reset")
+
+    def profile(self):
+        p = Profile()
+        _check(lib().qm2_get_profile(self._h, C.byref(p)), "qm2_get_profile")
+        return {"n_launches": int(p.n_launches), "kernel_ms": float(p.kernel_ms),
+                "last_kernel_ms": float(p.last_kernel_ms)}
+
+    @property
+    def counters_ptr(self):
+        return lib().qm2_counters_device(self._h)
+
+    @property
+    def keys_ptr(self):
+        return lib().qm2_keys_device(self._h)
+
+    def close(self):
+        if self._h:
+            lib().qm2_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_span(keys, n_shards, g):
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    v = [C.c_uint64() for _ in range(4)]
+    _check(lib().qm2_shard_span(keys.ctypes.data, len(keys), n_shards, g, *[C.byref(x) for x in v]),
+           "qm2_shard_span")
+    return tuple(int(x.value) for x in v)   # own_lo, own_hi, span_lo, span_hi
+
+
+class tools:
+    """Synthetic workload tooling (include/qm2_tools.h).  Device pointers are ints."""
+
+    @staticmethod
+    def genome_generate(d_ptr, n, seed, gc_lo=0.32, gc_hi=0.62, n_blocks=(), dups=(), stream=None):
+        nb = (Range * max(1, len(n_blocks)))(*[Range(int(a), int(b)) for a, b in n_blocks])
+        dp = (Dup * max(1, len(dups)))(*[Dup(int(a), int(b), int(c)) for a, b, c in dups])
+        _check(lib().qm2t_genome_generate(d_ptr, n, seed, gc_lo, gc_hi, nb, len(n_blocks), dp, len(dups),
+                                          stream), "qm2t_genome_generate")
+
+    @staticmethod
+    def dict_build(d_genome, n, k, d_keys, H, d_scratch, stream=None):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().qm2t_dict_build(d_genome, n, k, d_keys, H, d_scratch, C.byref(a), C.byref(b), stream),
+               "qm2t_dict_build")
+        return int(a.value), int(b.value)
+
+    @staticmethod
+    def read_offsets(n_reads, first_read, len_lo, len_hi, seed):
+        off = np.empty(n_reads + 1, dtype=np.uint64)
+        lib().qm2t_read_offsets(off.ctypes.data, n_reads, first_read, len_lo, len_hi, seed)
+        return off
+
+    @staticmethod
+    def reads_generate(d_genome, n, d_out, d_offsets, n_reads, first_read, len_lo, len_hi, seed,
+                       sub_rate=0.005, n_read_frac=0.01, stream=None):
+        _check(lib().qm2t_reads_generate(d_genome, n, d_out, d_offsets, n_reads, first_read, len_lo, len_hi,
+                                         seed, sub_rate, n_read_frac, stream), "qm2t_reads_generate")
+
+    @staticmethod
+    def microbench(slots, n_ops, mode, repeats=3):
+        ms = C.c_double(0)
+        _check(lib().qm2t_microbench(slots, n_ops, mode, repeats, C.byref(ms)), "qm2t_microbench")
+        return float(ms.value)

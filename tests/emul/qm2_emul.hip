@@ -1,0 +1,77 @@
+/*
+ * qm2_emul.cpp — TEST INFRASTRUCTURE: runs the product's device-side encoder
+ * (quick-mer2_amd/csrc/qm2_device.hip.h: SWAR pack, window assembly, funnel-
+ * shift k-mer extraction, DJB) and its host-side staging planner
+ * (qm2_plan.h) on the CPU, lane by lane, so that the arithmetic of the HIP
+ * kernels is checked against the oracle in the CPU-only test suite.  Compiled
+ * by hipcc for the host (same headers, same code; only the three wave shuffles
+ * of make_window are replaced by array look-ups).
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../quick-mer2_amd/csrc/qm2_device.hip.h"
+#include "../../quick-mer2_amd/csrc/qm2_plan.h"
+
+using namespace qm2;
+
+template <bool K30>
+static void emul_part(const SeqView &sv, uint32_t k, std::vector<uint64_t> &out, uint64_t *n_bases)
+{
+    const uint64_t n_tiles = (sv.n_total + kTileBytes - 1) / kTileBytes;
+    for (uint64_t tile = 0; tile < n_tiles; tile++) {
+        Packed p[kWave];
+        for (int lane = 0; lane < kWave; lane++) p[lane] = pack16(load16(sv, lane_offset(tile * kTileBytes, lane)));
+        for (int lane = 0; lane < kWave; lane++) {
+            /* __shfl_up(x, d): lanes < d keep their own value */
+            const Packed p1 = p[lane >= 1 ? lane - 1 : lane], p2 = p[lane >= 2 ? lane - 2 : lane];
+            const Window W = assemble_window<K30>(sv, lane_offset(tile * kTileBytes, lane), lane < kHaloLanes,
+                                                  p[lane], p1, p2, k);
+            *n_bases += W.n_bases;
+#define E(J) if (W.emit & (0x8000u >> J)) out.push_back(kmer_at<K30, J>(W, k));
+            E(0) E(1) E(2) E(3) E(4) E(5) E(6) E(7) E(8) E(9) E(10) E(11) E(12) E(13) E(14) E(15)
+#undef E
+        }
+    }
+}
+
+extern "C" {
+
+/* Emulates qm2_submit(buf, n) with the given staging capacity and device-buffer
+ * misalignment; returns the emitted canonical k-mers in stream order. */
+uint64_t qm2e_extract(const char *buf, size_t n, uint32_t k, size_t staging_bytes, unsigned misalign,
+                      uint64_t *out, uint64_t cap, uint64_t *n_bases, uint64_t *n_parts)
+{
+    std::vector<Part> parts;
+    plan_parts(buf, n, staging_bytes, parts);
+    std::vector<uint64_t> km;
+    uint64_t bases = 0;
+    for (const Part &pt : parts) {
+        const size_t staged = pt.carry + pt.take;
+        /* a 16-byte aligned "device" buffer with `misalign` leading bytes and a poisoned tail */
+        std::vector<uint8_t> dev(staged + 64 + 32, 0xEE);
+        uint8_t *aligned = (uint8_t *)(((uintptr_t)dev.data() + 15) & ~(uintptr_t)15);
+        uint8_t *data = aligned + (misalign & 15);
+        memcpy(data, buf + pt.off - pt.carry, staged);
+        SeqView sv;
+        sv.lead = (uintptr_t)data & 15u;
+        sv.base = data - sv.lead;
+        sv.emit_from = sv.lead + pt.carry;
+        sv.n_total = sv.lead + staged;
+        sv.suppress = pt.wraps.empty() ? nullptr : pt.wraps.data();
+        sv.n_suppress = pt.wraps.size();
+        if (k == 30) emul_part<true>(sv, k, km, &bases);
+        else emul_part<false>(sv, k, km, &bases);
+    }
+    for (uint64_t i = 0; i < km.size() && i < cap; i++) out[i] = km[i];
+    if (n_bases) *n_bases = bases;
+    if (n_parts) *n_parts = parts.size();
+    return km.size();
+}
+
+uint32_t qm2e_djb32(uint64_t kmer) { return djb32(kmer); }
+
+}

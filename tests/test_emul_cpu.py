@@ -1,0 +1,134 @@
+"""CPU-only check of the kernels' arithmetic: the product's device header
+(SWAR pack, window assembly, funnel-shift k-mer extraction, uint16-wrap
+suppression) and its staging planner are compiled for the host
+(tests/emul/qm2_emul.hip) and run lane by lane; the k-mer stream must equal the
+oracle's, for every k, staging size and buffer alignment."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMUL_DIR = os.path.join(HERE, "emul")
+_L = None
+
+
+def emul():
+    global _L
+    if _L is not None:
+        return _L
+    so = os.path.join(EMUL_DIR, "libqm2_emul.so")
+    srcs = [os.path.join(EMUL_DIR, "qm2_emul.hip"),
+            os.path.join(ol.ROOT, "quick-mer2_amd", "csrc", "qm2_device.hip.h"),
+            os.path.join(ol.ROOT, "quick-mer2_amd", "csrc", "qm2_plan.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-fPIC",
+                        "-shared", "-o", so, srcs[0]], check=True)
+    L = C.CDLL(so)
+    L.qm2e_extract.restype = C.c_uint64
+    L.qm2e_extract.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint, C.c_void_p,
+                               C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.qm2e_djb32.restype = C.c_uint32
+    L.qm2e_djb32.argtypes = [C.c_uint64]
+    _L = L
+    return L
+
+
+def emul_extract(blob, k, staging=1 << 20, misalign=0):
+    L = emul()
+    nb, npart = C.c_uint64(0), C.c_uint64(0)
+    cap = len(blob) + 16
+    out = np.empty(cap, dtype=np.uint64)
+    n = L.qm2e_extract(blob, len(blob), k, staging, misalign, out.ctypes.data, cap, C.byref(nb), C.byref(npart))
+    return out[:n], int(nb.value), int(npart.value)
+
+
+def fuzz_blob(seed, n_lines=300, maxlen=400):
+    rng = np.random.default_rng(seed)
+    ref = synth.kat_reference().tobytes()
+    parts = []
+    for _ in range(n_lines):
+        L = int(rng.integers(0, maxlen))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            s = rng.integers(0, 256, L, dtype=np.uint8).tobytes().replace(b"\n", b"A")
+        elif kind == 1:
+            p = int(rng.integers(0, len(ref) - maxlen))
+            s = bytearray(ref[p:p + L])
+            for _ in range(int(rng.integers(0, 4))):
+                if L:
+                    s[int(rng.integers(0, L))] = int(rng.choice(list(b"NnXacgt\r\x00\xff")))
+            s = bytes(s)
+        elif kind == 2:
+            s = bytes([int(rng.choice(list(b"ACGTN")))]) * L
+        else:
+            p = int(rng.integers(0, len(ref) - maxlen))
+            s = ref[p:p + L].lower()
+        parts.append(s + b"\n")
+    return b"".join(parts)
+
+
+def test_djb32_is_low_half_of_djb():
+    L, O = emul(), ol.lib()
+    rng = np.random.default_rng(1)
+    for x in [0, 1, 0xFF, (1 << 60) - 1, (1 << 64) - 1] + [int(v) for v in rng.integers(0, 1 << 62, 2000)]:
+        assert L.qm2e_djb32(x) == (O.qm2o_djb(x) & 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("k", [30, 1, 3, 12, 16, 25, 29, 31])
+def test_fuzz_stream_equals_oracle(k):
+    for seed in range(3):
+        blob = fuzz_blob(100 * k + seed)
+        exp, exp_nb = ol.extract(blob, k)
+        for staging, mis in ((1 << 20, 0), (4096, 5), (700, 15), (97, 9)):
+            got, nb, nparts = emul_extract(blob, k, staging, mis)
+            assert nb == exp_nb, (k, seed, staging)
+            assert np.array_equal(got, exp), (k, seed, staging, mis)
+
+
+@pytest.mark.parametrize("k", [30, 25, 31, 12])
+def test_long_lines_uint16_wrap(k):
+    """Lines >= 65536 bases: the reference's uint16 run counter drops k windows per wrap."""
+    tile = synth.kat_reference().tobytes()
+    for L in (65535, 65536, 65537, 65566, 70000, 131072, 131100, 200000):
+        s = (tile * (L // len(tile) + 1))[:L]
+        blob = b"ACGT\n" + s + b"\n" + tile[:100] + b"\n"
+        exp, exp_nb = ol.extract(blob, k)
+        for staging, mis in ((1 << 22, 0), (65536, 3), (50000, 0), (9973, 11)):
+            got, nb, _ = emul_extract(blob, k, staging, mis)
+            assert nb == exp_nb and np.array_equal(got, exp), (k, L, staging)
+    s = bytearray((tile * 60)[:250000])
+    for p in (1234, 70000, 70001, 135535, 200000):
+        s[p] = ord("N")
+    blob = bytes(s) + b"\n" + bytes(s[:66000]) + b"\n"
+    exp, exp_nb = ol.extract(blob, k)
+    for staging in (1 << 22, 40000):
+        got, nb, _ = emul_extract(blob, k, staging, 0)
+        assert nb == exp_nb and np.array_equal(got, exp)
+
+
+def test_edges():
+    for blob in (b"\n", b"\n\n\n", b"A\n", b"ACGT\n" * 3, b"N" * 100 + b"\n",
+                 synth.kat_reference().tobytes()[:30] + b"\n",
+                 synth.kat_reference().tobytes()[:29] + b"\n" + synth.kat_reference().tobytes()[:31] + b"\n"):
+        for k in (30, 25, 31):
+            exp, exp_nb = ol.extract(blob, k)
+            for mis in (0, 1, 15):
+                got, nb, _ = emul_extract(blob, k, 1 << 20, mis)
+                assert nb == exp_nb and np.array_equal(got, exp)
+
+
+def test_kat_case_streams():
+    cases = synth.kat_cases(synth.kat_reference())
+    for name in ("polyA", "junk_bytes", "crlf", "n_lower", "n_upper", "split_lines", "short_reads", "long_with_N"):
+        data = cases[name][1]
+        blob = b"".join(l + b"\n" for l in data.split(b"\n") if l and not l.startswith(b">"))
+        for k in (30, 25):
+            exp, exp_nb = ol.extract(blob, k)
+            got, nb, _ = emul_extract(blob, k, 5000, 7)
+            assert nb == exp_nb and np.array_equal(got, exp), name

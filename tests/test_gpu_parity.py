@@ -1,0 +1,413 @@
+"""GPU parity tests: the HIP path (through the C-ABI, libqm2_hip.so) against the
+CPU oracle on the same inputs and against the vectors the real reference
+produced.  Bit-exact everywhere (integer / byte work).  Run with `-m gpu`."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(HERE, "golden")
+MAN = json.load(open(os.path.join(GOLD, "manifest.json")))
+CLI = os.path.join(ROOT, "quick-mer2_amd", "quicKmer2")
+
+
+@pytest.fixture(scope="module")
+def qm2():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "quick-mer2_amd"))
+    import pyqm2
+    pyqm2.lib()
+    return pyqm2
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def md5_file(p):
+    return hashlib.md5(open(p, "rb").read()).hexdigest()
+
+
+def kat_qm(setname="kat"):
+    return ol.load_qm(os.path.join(GOLD, setname, "ref.fa.qm"))
+
+
+def check_against_oracle(qm2, keys, k, lines, **kw):
+    exp_depth, exp_st = ol.count_lines(keys, k, lines)
+    with qm2.Counter(keys, k=k, **kw) as c:
+        c.submit(lines)
+        depth, st = c.finish()
+    assert st == exp_st
+    assert np.array_equal(depth, exp_depth)
+    return st
+
+
+# ---- 1. the reference's own vectors, end to end through the CLI ---------------
+
+def _cases():
+    return [(s, n) for s, e in MAN["sets"].items() for n in e.get("cases", {})]
+
+
+_REGEN = {}
+
+
+def _reads_path(setname, name, tmp):
+    c = MAN["sets"][setname]["cases"][name]
+    p = os.path.join(GOLD, setname, c["reads"])
+    if os.path.exists(p):
+        return p
+    if not _REGEN:
+        _REGEN.update(synth.kat_cases(synth.kat_reference()))
+    p = os.path.join(tmp, c["reads"])
+    open(p, "wb").write(_REGEN[name][1])
+    assert md5_file(p) == c["reads_md5"]
+    return p
+
+
+@pytest.mark.parametrize("setname,name", _cases())
+def test_cli_matches_reference_vectors(setname, name, tmp_path):
+    c = MAN["sets"][setname]["cases"][name]
+    rp = _reads_path(setname, name, str(tmp_path))
+    out = str(tmp_path / "o")
+    r = subprocess.run([CLI, "count", "-t", "2", os.path.join(GOLD, setname, "ref.fa"), rp, out],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    txt = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, txt
+    assert "total %d kmers" % c["n_kmers"] in txt          # QuicKmer.c:481
+    assert open(out + ".bin", "rb").read() == open(os.path.join(GOLD, setname, name + ".bin"), "rb").read()
+    assert md5_file(out + ".txt") == c["txt_md5"]
+    if c["mean_depth"] is not None:
+        assert "Mean sequencing depth: %s" % c["mean_depth"] in txt
+    assert txt.rstrip().endswith("Exit quicK-mer2 count")
+
+
+def test_cli_mini_fasta_fastq_and_pipe(tmp_path):
+    m = MAN["sets"]["mini"]
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    ref_prefix = os.path.join(GOLD, "mini", "ref.fa")
+    for tag, reads in (("fa", rfa), ("fq", rfq)):
+        out = str(tmp_path / tag)
+        r = subprocess.run([CLI, "count", ref_prefix, reads, out], stdout=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0
+        assert md5_file(out + ".bin") == m["bin_md5"] and md5_file(out + ".txt") == m["txt_md5"]
+        assert ("total %d kmers" % m["n_kmers"]).encode() in r.stdout
+    # stdin pipe, the README's usage (samtools ... | quicKmer2 count ref /dev/fd/0 out)
+    out = str(tmp_path / "pipe")
+    with open(rfq, "rb") as f:
+        r = subprocess.run([CLI, "count", "-t", "4", ref_prefix, "/dev/fd/0", out], stdin=f,
+                           stdout=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and md5_file(out + ".bin") == m["bin_md5"]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ol.ORACLE_DIR, "_ref", "quicKmer2")),
+                    reason="real reference binary not shipped")
+def test_cli_c1_against_live_reference(tmp_path):
+    """Config C1: dictionary by the real `search`, counts by the real `count`, vs the GPU CLI."""
+    c1 = json.load(open(os.path.join(GOLD, "c1_manifest.json")))
+    ref = os.path.join(ol.ORACLE_DIR, "_ref", "quicKmer2")
+    fa, ctrl, rfa, rfq = synth.c1_inputs(str(tmp_path))
+    subprocess.run([ref, "search", "-k", "30", "-s", "2M", "-e", "0", "-w", "1000", "-c", ctrl, fa],
+                   check=True, stdout=subprocess.DEVNULL)
+    assert md5_file(fa + ".qm") == c1["qm_md5"]
+    subprocess.run([ref, "count", "-t", "4", fa, rfq, str(tmp_path / "ref")], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([CLI, "count", fa, rfq, str(tmp_path / "gpu")], stdout=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0
+    assert open(str(tmp_path / "gpu.bin"), "rb").read() == open(str(tmp_path / "ref.bin"), "rb").read()
+    assert md5_file(str(tmp_path / "gpu.bin")) == c1["bin_md5"]
+    assert md5_file(str(tmp_path / "gpu.txt")) == c1["txt_md5"]
+    assert ("total %d kmers" % c1["n_kmers"]).encode() in r.stdout
+
+
+# ---- 2. C-ABI vs oracle: whole counter array and statistics --------------------
+
+def test_api_mini_full_depth_and_stats(qm2, tmp_path):
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    lines = ol.strip_reads(rfq)
+    st = check_against_oracle(qm2, qm["keys"], 30, lines)
+    assert st["n_kmers"] == MAN["sets"]["mini"]["n_kmers"]
+
+
+@pytest.mark.parametrize("staging", [4096, 5000, 65536, 1 << 20])
+def test_batch_boundaries_do_not_matter(qm2, staging, tmp_path):
+    """Result independent of staging size / split points, including mid-line splits."""
+    qm = kat_qm()
+    ref = synth.kat_reference()
+    cases = synth.kat_cases(ref)
+    blob = b""
+    for name in ("reads_fa", "long70000", "long_with_N", "polyA", "long99998", "junk_bytes"):
+        p = tmp_path / (name + ".fa")
+        p.write_bytes(cases[name][1])
+        blob += ol.strip_reads(str(p))
+    exp_depth, exp_st = ol.count_lines(qm["keys"], 30, blob)
+    with qm2.Counter(qm["keys"], k=30, staging_bytes=staging, n_staging=2) as c:
+        # feed in pieces cut at line boundaries
+        rng = np.random.default_rng(staging)
+        nl = np.flatnonzero(np.frombuffer(blob, dtype=np.uint8) == 10) + 1
+        cuts = sorted(set([0, len(blob)] + list(rng.choice(nl, size=7, replace=False))))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            c.submit(blob[a:b])
+        depth, st = c.finish()
+    assert st == exp_st and np.array_equal(depth, exp_depth)
+
+
+@pytest.mark.parametrize("setname,k", [("kat_k12", 12), ("kat_k25", 25), ("kat_k31", 31)])
+def test_other_k(qm2, setname, k, tmp_path):
+    qm = kat_qm(setname)
+    assert qm["k"] == k
+    cases = synth.kat_cases(synth.kat_reference())
+    for name in ("reads_fa", "long70000", "polyA", "short_reads", "long_with_N"):
+        p = tmp_path / (name + ".fa")
+        p.write_bytes(cases[name][1])
+        check_against_oracle(qm2, qm["keys"], k, ol.strip_reads(str(p)), staging_bytes=30000)
+
+
+def test_fuzz_arbitrary_bytes(qm2):
+    """Any byte is a base (QuicKmer.c:411); 'N' and newline are the only resets."""
+    qm = kat_qm()
+    rng = np.random.default_rng(5)
+    ref = synth.kat_reference().tobytes()
+    parts = []
+    for i in range(400):
+        L = int(rng.integers(0, 400))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            s = rng.integers(0, 256, L, dtype=np.uint8).tobytes().replace(b"\n", b"A")
+        elif kind == 1:
+            p = int(rng.integers(0, len(ref) - 400))
+            s = bytearray(ref[p:p + L])
+            for _ in range(int(rng.integers(0, 4))):
+                if L:
+                    s[int(rng.integers(0, L))] = int(rng.choice(list(b"NnXacgt\r\x00\xff")))
+            s = bytes(s)
+        elif kind == 2:
+            s = bytes([int(rng.choice(list(b"ACGT")))]) * L
+        else:
+            p = int(rng.integers(0, len(ref) - 400))
+            s = ref[p:p + L].lower()
+        parts.append(s + b"\n")
+    blob = b"".join(parts)
+    for k, setname in ((30, "kat"), (25, "kat_k25")):
+        check_against_oracle(qm2, kat_qm(setname)["keys"], k, blob, staging_bytes=8192)
+
+
+def test_empty_and_degenerate_inputs(qm2):
+    qm = kat_qm()
+    with qm2.Counter(qm["keys"], k=30) as c:
+        c.submit(b"")
+        c.submit(b"\n")
+        c.submit(b"\n\n\n")
+        c.submit(b"ACGT\n")
+        depth, st = c.finish()
+        assert st == {"n_bases": 4, "n_kmers": 0, "n_probes": 0, "n_hits": 0}
+        assert not depth.any()
+        with pytest.raises(qm2.Qm2Error):
+            c.submit(b"ACGT")          # not newline-terminated
+    with pytest.raises(qm2.Qm2Error):
+        qm2.Counter(qm["keys"][:1000], k=30)       # not a power of two
+    with pytest.raises(qm2.Qm2Error):
+        qm2.Counter(qm["keys"], k=32)
+
+
+def test_wrap_mod_65536_and_reset(qm2):
+    qm = kat_qm()
+    one = synth.kat_reference()[1000:1030].tobytes()
+    with qm2.Counter(qm["keys"], k=30) as c:
+        c.submit((one + b"\n") * 70000)
+        depth, st = c.finish()
+        assert st["n_hits"] == 70000 and int(depth.max()) == 4464 and int((depth != 0).sum()) == 1
+        c.reset()
+        depth, st = c.finish()
+        assert st["n_kmers"] == 0 and not depth.any()
+
+
+# ---- 3. device-resident input, any alignment -----------------------------------
+
+def test_submit_device_unaligned(qm2, torch_cuda, tmp_path):
+    torch = torch_cuda
+    qm = kat_qm()
+    cases = synth.kat_cases(synth.kat_reference())
+    p = tmp_path / "r.fa"
+    p.write_bytes(cases["reads_fa"][1])
+    blob = ol.strip_reads(str(p))[:200000]
+    blob = blob[:blob.rfind(b"\n") + 1]
+    exp_depth, exp_st = ol.count_lines(qm["keys"], 30, blob)
+    for mis in (0, 1, 7, 15, 16, 33):
+        buf = torch.zeros(len(blob) + 64, dtype=torch.uint8, device="cuda")
+        buf[mis:mis + len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+        with qm2.Counter(qm["keys"], k=30) as c:
+            c.submit_device(buf.data_ptr() + mis, len(blob))
+            depth, st = c.finish()
+        assert st == exp_st and np.array_equal(depth, exp_depth), mis
+
+
+# ---- 4. split path: encode + probe, sharded spans -------------------------------
+
+def test_encode_then_probe_equals_fused(qm2, torch_cuda, tmp_path):
+    torch = torch_cuda
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    keys = qm["keys"]
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    blob = ol.strip_reads(rfa)
+    exp_kmers, nb = ol.extract(blob, 30)
+    exp_depth, exp_st = ol.count_lines(keys, 30, blob)
+    dbuf = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+    for n_shards in (1, 2, 4):
+        cap = len(exp_kmers) + 16
+        out = torch.zeros(n_shards * cap, dtype=torch.int64, device="cuda")
+        counts = torch.zeros(n_shards, dtype=torch.int64, device="cuda")
+        with qm2.Counter(keys, k=30) as enc:
+            enc.encode_device(dbuf.data_ptr(), len(blob), out.data_ptr(), cap, n_shards, counts.data_ptr())
+            enc.sync()
+            _, st = enc.finish(want_depth=False)
+        assert st["n_kmers"] == len(exp_kmers) and st["n_bases"] == nb
+        cnt = counts.cpu().numpy()
+        assert int(cnt.sum()) == len(exp_kmers)
+        got = np.concatenate([out[g * cap:g * cap + int(cnt[g])].cpu().numpy().view(np.uint64) for g in range(n_shards)])
+        assert np.array_equal(np.sort(got), np.sort(exp_kmers))
+        # every k-mer sits in the bucket of its home slot's owner
+        lgH = int(np.log2(len(keys)))
+        for g in range(n_shards):
+            km = out[g * cap:g * cap + int(cnt[g])].cpu().numpy().view(np.uint64)
+            L = ol.lib()
+            homes = np.array([L.qm2o_djb(int(x)) & (len(keys) - 1) for x in km[:2000]], dtype=np.uint64)
+            assert np.all((homes >> (lgH - int(np.log2(n_shards)))) == g) if n_shards > 1 else True
+        # probe each bucket on a context that holds only that shard's span
+        total = np.zeros(len(keys), dtype=np.uint64)
+        hits = probes = 0
+        for g in range(n_shards):
+            own_lo, own_hi, lo, hi = qm2.shard_span(keys, n_shards, g)
+            assert lo <= own_lo and hi >= own_hi
+            with qm2.Counter(keys[lo:hi], hash_size=len(keys), k=30, span=(lo, hi)) as pc:
+                pc.probe_device(out.data_ptr() + 8 * g * cap, int(cnt[g]))
+                d, s = pc.finish()
+            total[lo:hi] += d
+            hits += s["n_hits"]
+            probes += s["n_probes"]
+        assert hits == exp_st["n_hits"] and probes == exp_st["n_probes"]
+        assert np.array_equal(total.astype(np.uint16), exp_depth)
+
+
+# ---- 5. device tooling ----------------------------------------------------------
+
+def test_tools_dictionary_is_valid_and_unique(qm2, torch_cuda):
+    torch = torch_cuda
+    n, H, k = 200_000, 1 << 19, 30
+    genome = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    qm2.tools.genome_generate(genome.data_ptr(), n, seed=11, n_blocks=[(50_000, 700)],
+                              dups=[(120_000, 20_000, 3000)])
+    g = genome.cpu().numpy().tobytes()
+    assert set(g) <= set(b"ACGTN") and g[50_000:50_700] == b"N" * 700 and g[120_000:123_000] == g[20_000:23_000]
+    keys = torch.zeros(H, dtype=torch.int64, device="cuda")
+    scratch = torch.zeros(H, dtype=torch.int64, device="cuda")
+    n_distinct, n_unique = qm2.tools.dict_build(genome.data_ptr(), n, k, keys.data_ptr(), H, scratch.data_ptr())
+    hk = keys.cpu().numpy().view(np.uint64)
+    # CPU truth: canonical k-mers of the genome as one line, unique ones only, k-mer 0 excluded
+    km, _ = ol.extract(g + b"\n", k)
+    vals, cnts = np.unique(km[km != 0], return_counts=True)
+    assert n_distinct == len(vals) and n_unique == int((cnts == 1).sum())
+    assert np.array_equal(np.sort(hk[hk != 0]), vals[cnts == 1])
+    # table obeys the probe rule: every stored key is found by the oracle's Find_hash
+    L = ol.lib()
+    import ctypes as C
+    idx = C.c_uint64()
+    for s in np.flatnonzero(hk)[::97]:
+        assert L.qm2o_find(hk.ctypes.data, H, int(hk[s]), C.byref(idx), None) == 1 and idx.value == s
+    # reads from it: deterministic, hit the dictionary, GPU count == oracle count
+    n_reads, rl = 20_000, 150
+    off = qm2.tools.read_offsets(n_reads, 0, rl, rl, 5)
+    reads = torch.zeros(int(off[-1]), dtype=torch.uint8, device="cuda")
+    qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, n_reads, 0, rl, rl, 5)
+    torch.cuda.synchronize()
+    blob = reads.cpu().numpy().tobytes()
+    assert blob.count(b"\n") == n_reads and len(blob) == n_reads * (rl + 1)
+    exp_depth, exp_st = ol.count_lines(hk, k, blob)
+    assert exp_st["n_hits"] > 0.7 * exp_st["n_kmers"]
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr()) as c:
+        c.submit_device(reads.data_ptr(), len(blob))
+        depth, st = c.finish()
+    assert st == exp_st and np.array_equal(depth, exp_depth)
+    # variable-length (HiFi-like) reads
+    off = qm2.tools.read_offsets(300, 7, 5000, 9000, 9)
+    d_off = torch.from_numpy(off.view(np.int64)).cuda()
+    reads = torch.zeros(int(off[-1]), dtype=torch.uint8, device="cuda")
+    qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), d_off.data_ptr(), 300, 7, 5000, 9000, 9,
+                             sub_rate=0.001)
+    torch.cuda.synchronize()
+    blob = reads.cpu().numpy().tobytes()
+    assert blob.count(b"\n") == 300
+    exp_depth, exp_st = ol.count_lines(hk, k, blob)
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr()) as c:
+        c.submit_device(reads.data_ptr(), len(blob))
+        depth, st = c.finish()
+    assert st == exp_st and np.array_equal(depth, exp_depth)
+
+
+# ---- 6. full-size, size-independent properties (config C2 shape) -----------------
+
+def test_c2_scale_properties(qm2, torch_cuda):
+    """H=2^28 dictionary of a 50.8 Mb chr22-like genome, 2M x 150 bp reads:
+    linearity, hit conservation, strand symmetry, batch independence, and an
+    exact oracle comparison on a sample of the stream."""
+    torch = torch_cuda
+    n, H, k = 50_818_468, 1 << 28, 30
+    genome = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    qm2.tools.genome_generate(genome.data_ptr(), n, seed=22,
+                              n_blocks=[(0, 10_500_000), (30_000_000, 600_000), (50_300_000, 518_468)],
+                              dups=[(40_000_000 + i * 100_000, 12_000_000 + i * 37_000, 1000 + 190 * i) for i in range(100)])
+    keys = torch.zeros(H, dtype=torch.int64, device="cuda")
+    scratch = torch.zeros(H, dtype=torch.int64, device="cuda")
+    n_distinct, n_unique = qm2.tools.dict_build(genome.data_ptr(), n, k, keys.data_ptr(), H, scratch.data_ptr())
+    del scratch
+    assert 35_000_000 < n_unique <= n_distinct < 40_000_000
+    n_reads, rl = 2_000_000, 150
+    reads = torch.zeros(n_reads * (rl + 1), dtype=torch.uint8, device="cuda")
+    qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, n_reads, 0, rl, rl, 22)
+    torch.cuda.synchronize()
+    nbytes = reads.numel()
+    counters = torch.zeros(H, dtype=torch.int32, device="cuda")
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr()) as c:
+        c.submit_device(reads.data_ptr(), nbytes)
+        d1, s1 = c.finish()
+        assert s1["n_bases"] == n_reads * rl
+        assert int(counters.sum(dtype=torch.int64)) == s1["n_hits"]           # every hit is one increment
+        assert s1["n_kmers"] <= n_reads * (rl - k + 1) and s1["n_probes"] >= s1["n_kmers"]
+        # linearity: the same stream again doubles every counter
+        c.submit_device(reads.data_ptr(), nbytes)
+        d2, s2 = c.finish()
+        assert s2 == {a: 2 * b for a, b in s1.items()}
+        assert np.array_equal(d2, (2 * d1.astype(np.uint32)).astype(np.uint16))
+        # counts only land on occupied slots (or on the one empty slot k-mer 0 resolves to)
+        occ = (keys != 0)
+        stray = torch.count_nonzero(counters[~occ])
+        assert int(stray) <= 1
+        # batch independence: two halves cut at a line boundary, through the host pipeline
+        c.reset()
+        half = (n_reads // 2) * (rl + 1)
+        host = reads.cpu().numpy().tobytes()
+        c.submit(host[:half])
+        c.submit(host[half:])
+        d3, s3 = c.finish()
+        assert s3 == s1 and np.array_equal(d3, d1)
+    # exact oracle comparison on the first 100k reads
+    hk = keys.cpu().numpy().view(np.uint64)
+    sample = host[:100_000 * (rl + 1)]
+    exp_depth, exp_st = ol.count_lines(hk, k, sample, threads=8)
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr()) as c:
+        c.submit(sample)
+        depth, st = c.finish()
+    assert st["n_kmers"] == exp_st["n_kmers"] and st["n_bases"] == exp_st["n_bases"]
+    assert np.array_equal(depth, exp_depth)
