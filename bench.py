@@ -56,7 +56,15 @@ def genome_layout(n):
         i += 1
         if at + 20_000 >= n - int(0.0102 * n) or src + 20_000 >= int(0.58 * n):
             break
-    return n_blocks, dups
+    gaps = sorted(n_blocks)
+    covered, at = [], 0
+    for st, ln in gaps:
+        if st > at:
+            covered.append((at, st - at))
+        at = st + ln
+    if at < n:
+        covered.append((at, n - at))
+    return n_blocks, dups, covered
 
 
 def main():
@@ -92,7 +100,7 @@ def main():
     # ---- untimed set-up: reference, dictionary, read batches, all made on the device -------
     t_setup = time.time()
     genome = torch.empty(n, dtype=torch.uint8, device=dev)
-    n_blocks, dups = genome_layout(n)
+    n_blocks, dups, covered = genome_layout(n)
     pyqm2.tools.genome_generate(genome.data_ptr(), n, seed=22, n_blocks=n_blocks, dups=dups)
     keys = torch.empty(H, dtype=torch.int64, device=dev)
     scratch = torch.empty(H, dtype=torch.int64, device=dev)
@@ -112,7 +120,8 @@ def main():
         if wl["len_lo"] != wl["len_hi"]:
             d_off = torch.from_numpy(off.view(np.int64)).to(dev)
         pyqm2.tools.reads_generate(genome.data_ptr(), n, buf.data_ptr(), d_off.data_ptr() if d_off is not None else None,
-                                   wl["reads"], first, wl["len_lo"], wl["len_hi"], 22, sub_rate=wl["sub"])
+                                   wl["reads"], first, wl["len_lo"], wl["len_hi"], 22, sub_rate=wl["sub"],
+                                   sample_from=covered)
         batches.append((buf, nbytes, nbytes - wl["reads"]))
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
@@ -192,7 +201,7 @@ def main():
         buf, nbytes, _ = batches[0]
         line = wl["len_lo"] + 1 if wl["len_lo"] == wl["len_hi"] else None
         # calibrate on a small slice, then size the sample for ~cpu_seconds
-        probe_bytes = min(nbytes, 20_000 * 151)
+        probe_bytes = min(nbytes, 400_000 * 151)
         host = buf[:probe_bytes].cpu().numpy().tobytes()
         host = host[:host.rfind(b"\n") + 1]
         tA = time.perf_counter()
@@ -204,6 +213,7 @@ def main():
         tA = time.perf_counter()
         cdepth, cst = ol.count_lines(hk, k, host, threads=args.cpu_threads)
         cpu_s = time.perf_counter() - tA
+        cdepth = ol.remove_drain_padding(cdepth, hk, cst["n_kmers"])
         # the same sample through the GPU path must give the same counters (bit-exact)
         chk = pyqm2.Counter(None, hash_size=H, k=k, device=local, ext_keys=keys.data_ptr())
         chk.submit(host)

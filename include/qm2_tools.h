@@ -41,11 +41,13 @@ int qm2t_dict_build(const void *d_genome, uint64_t n, uint32_t k, uint64_t *d_ke
 /* Write n_reads sequence lines into d_out: read r (global index first_read + r)
  * starts at a uniform genome position, has length U[len_lo, len_hi], is reverse-
  * complemented with p = 0.5, gets substitutions at sub_rate per base and, with
- * probability n_read_frac, one 'N'.  d_offsets: device array of n_reads+1 u64
+ * probability n_read_frac, one 'N'.  from[] (host array, may be empty) restricts the start
+ * positions to those regions (real reads do not come out of assembly gaps).  d_offsets: device array of n_reads+1 u64
  * byte offsets (from qm2t_read_offsets).  Each line is '\n'-terminated. */
 int qm2t_reads_generate(const void *d_genome, uint64_t n, void *d_out, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t first_read, uint32_t len_lo, uint32_t len_hi,
-                        uint64_t seed, float sub_rate, float n_read_frac, void *stream);
+                        uint64_t seed, float sub_rate, float n_read_frac,
+                        const qm2t_range *from, uint32_t n_from, void *stream);
 
 /* Host helper: offsets[0..n_reads] for the same (seed, first_read, lens). */
 void qm2t_read_offsets(uint64_t *offsets, uint64_t n_reads, uint64_t first_read,

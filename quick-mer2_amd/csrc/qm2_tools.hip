@@ -145,6 +145,9 @@ struct ReadParams {
     uint32_t len_lo, len_hi;
     uint64_t seed;
     float sub_rate, n_read_frac;
+    const qm2t_range *ranges;    /* regions reads are drawn from (device), or null = whole genome */
+    uint32_t n_ranges;
+    uint64_t ranges_total;
 };
 
 __host__ __device__ inline uint32_t read_len(uint64_t seed, uint64_t R, uint32_t lo, uint32_t hi)
@@ -155,7 +158,14 @@ __host__ __device__ inline uint32_t read_len(uint64_t seed, uint64_t R, uint32_t
 __device__ inline uint8_t read_byte(const ReadParams &p, uint64_t R, uint32_t len, uint32_t i)
 {
     if (i == len) return '\n';
-    const uint64_t pos = rnd(p.seed, 4, R) % (p.n - len + 1);
+    uint64_t pos;
+    if (p.n_ranges == 0) pos = rnd(p.seed, 4, R) % (p.n - len + 1);
+    else {
+        uint64_t x = rnd(p.seed, 4, R) % p.ranges_total;
+        uint32_t r = 0;
+        while (r + 1 < p.n_ranges && x >= p.ranges[r].len) { x -= p.ranges[r].len; r++; }
+        pos = p.ranges[r].start + rnd(p.seed, 9, R) % (p.ranges[r].len - len + 1);
+    }
     const bool rc = (rnd(p.seed, 5, R) & 1) != 0;
     uint8_t c = p.genome[rc ? pos + (len - 1 - i) : pos + i];
     if (rc) c = (c == 'A') ? 'T' : (c == 'T') ? 'A' : (c == 'C') ? 'G' : (c == 'G') ? 'C' : c;
@@ -308,7 +318,8 @@ extern "C" void qm2t_read_offsets(uint64_t *offsets, uint64_t n_reads, uint64_t 
 
 extern "C" int qm2t_reads_generate(const void *d_genome, uint64_t n, void *d_out, const uint64_t *d_offsets,
                                    uint64_t n_reads, uint64_t first_read, uint32_t len_lo, uint32_t len_hi,
-                                   uint64_t seed, float sub_rate, float n_read_frac, void *stream)
+                                   uint64_t seed, float sub_rate, float n_read_frac,
+                                   const qm2t_range *from, uint32_t n_from, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (len_lo == 0 || len_hi < len_lo || (uint64_t)len_hi > n || len_hi >= (1u << 20)) {
@@ -316,7 +327,21 @@ extern "C" int qm2t_reads_generate(const void *d_genome, uint64_t n, void *d_out
         return 1;
     }
     ReadParams p = {(const uint8_t *)d_genome, n, (uint8_t *)d_out, d_offsets, n_reads, first_read,
-                    len_lo, len_hi, seed, sub_rate, n_read_frac};
+                    len_lo, len_hi, seed, sub_rate, n_read_frac, nullptr, 0, 0};
+    qm2t_range *d_from = nullptr;
+    if (n_from) {
+        for (uint32_t i = 0; i < n_from; i++) {
+            if (from[i].len < len_hi || from[i].start + from[i].len > n) {
+                puts("qm2 tools: a sampling range is shorter than a read or outside the genome");
+                return 1;
+            }
+            p.ranges_total += from[i].len;
+        }
+        T_OK(hipMalloc((void **)&d_from, n_from * sizeof(qm2t_range)));
+        T_OK(hipMemcpy(d_from, from, n_from * sizeof(qm2t_range), hipMemcpyHostToDevice));
+        p.ranges = d_from;
+        p.n_ranges = n_from;
+    }
     if (len_lo == len_hi)
         hipLaunchKernelGGL(reads_fixed_kernel, dim3(8192), dim3(256), 0, s, p);
     else {
@@ -324,6 +349,10 @@ extern "C" int qm2t_reads_generate(const void *d_genome, uint64_t n, void *d_out
         hipLaunchKernelGGL(reads_var_kernel, dim3((unsigned)std::min<uint64_t>(n_reads, 65536)), dim3(256), 0, s, p);
     }
     T_OK(hipGetLastError());
+    if (d_from) {
+        T_OK(hipStreamSynchronize(s));
+        T_OK(hipFree(d_from));
+    }
     return 0;
 }
 

@@ -63,6 +63,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libqm2_hip.so is not built (run `make -C quick-mer2_amd` or "
                            "__graft_entry__.build()); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  Importing
+    # torch first makes libqm2_hip.so's NEEDED libamdhip64.so.7 resolve to that already-loaded
+    # copy, so device pointers and streams are interchangeable between torch and this library
+    # (loading ours first would leave torch unable to see the GPU).  Without torch installed the
+    # library binds to /opt/rocm's runtime, as the C CLI does.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
     L.qm2_open.restype = C.c_int
@@ -99,7 +108,8 @@ def lib():
     L.qm2t_dict_build.restype = C.c_int
     L.qm2t_dict_build.argtypes = [vp, u64, u32, vp, u64, vp, C.POINTER(u64), C.POINTER(u64), vp]
     L.qm2t_reads_generate.restype = C.c_int
-    L.qm2t_reads_generate.argtypes = [vp, u64, vp, vp, u64, u64, u32, u32, u64, C.c_float, C.c_float, vp]
+    L.qm2t_reads_generate.argtypes = [vp, u64, vp, vp, u64, u64, u32, u32, u64, C.c_float, C.c_float,
+                                      C.POINTER(Range), u32, vp]
     L.qm2t_read_offsets.restype = None
     L.qm2t_read_offsets.argtypes = [vp, u64, u64, u32, u32, u64]
     L.qm2t_microbench.restype = C.c_int
@@ -236,9 +246,11 @@ class tools:
 
     @staticmethod
     def reads_generate(d_genome, n, d_out, d_offsets, n_reads, first_read, len_lo, len_hi, seed,
-                       sub_rate=0.005, n_read_frac=0.01, stream=None):
+                       sub_rate=0.005, n_read_frac=0.01, sample_from=(), stream=None):
+        fr = (Range * max(1, len(sample_from)))(*[Range(int(a), int(b)) for a, b in sample_from])
         _check(lib().qm2t_reads_generate(d_genome, n, d_out, d_offsets, n_reads, first_read, len_lo, len_hi,
-                                         seed, sub_rate, n_read_frac, stream), "qm2t_reads_generate")
+                                         seed, sub_rate, n_read_frac, fr, len(sample_from), stream),
+               "qm2t_reads_generate")
 
     @staticmethod
     def microbench(slots, n_ops, mode, repeats=3):

@@ -103,6 +103,27 @@ def count_lines(keys: np.ndarray, k: int, lines: bytes, threads=0, depth=None):
     return depth, st.as_dict()
 
 
+def zero_slot(keys: np.ndarray) -> int:
+    """The empty slot k-mer 0 resolves to (Find_hash of 0 stops on the first empty slot and
+    reports a match, QuicKmer.c:96-98)."""
+    L = lib()
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    idx = C.c_uint64(0)
+    assert L.qm2o_find(keys.ctypes.data, len(keys), 0, C.byref(idx), None) == 1
+    return int(idx.value)
+
+
+def remove_drain_padding(depth: np.ndarray, keys: np.ndarray, n_kmers: int) -> np.ndarray:
+    """The threaded reference pads its last batch with zeros (QuicKmer.c:460-466); each padding
+    zero bumps the counter of zero_slot(keys), which is never on the chain.  Undo that so a
+    threaded-oracle counter array can be compared slot for slot with a serial / GPU one."""
+    pad = 4096 - (n_kmers % 4096)
+    out = depth.copy()
+    z = zero_slot(keys)
+    out[z] = np.uint16((int(out[z]) - pad) & 0xFFFF)
+    return out
+
+
 def strip_reads(path, seekable=True) -> bytes:
     L = lib()
     n = C.c_size_t(0)

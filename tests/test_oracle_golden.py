@@ -143,3 +143,17 @@ def test_c1_full_against_live_reference(tmp_path):
         assert rc == 0 and st["n_kmers"] == c1["n_kmers"]
         assert md5_file(out + ".bin") == c1["bin_md5"]
         assert md5_file(out + ".txt") == c1["txt_md5"]
+
+
+def test_threaded_drain_padding_lands_on_zero_slot():
+    """The threaded model differs from the serial one only by the zero padding of the last
+    batch, which bumps the (off-chain) empty slot k-mer 0 resolves to (QuicKmer.c:460-466)."""
+    qm = ol.load_qm(os.path.join(GOLD, "kat", "ref.fa.qm"))
+    ref = synth.kat_reference().tobytes()
+    lines = (ref[100:300] + b"\n") * 37
+    d0, s0 = ol.count_lines(qm["keys"], 30, lines, threads=0)
+    d3, s3 = ol.count_lines(qm["keys"], 30, lines, threads=3)
+    assert s0["n_kmers"] == s3["n_kmers"]
+    assert not np.array_equal(d0, d3)
+    assert np.array_equal(ol.remove_drain_padding(d3, qm["keys"], s3["n_kmers"]), d0)
+    assert qm["keys"][ol.zero_slot(qm["keys"])] == 0
