@@ -1,0 +1,126 @@
+"""CPU-only checks of the product boundary: libqm2_hip.so loads, exports every
+symbol include/qm2.h and include/qm2_tools.h declare, and fails LOUDLY (no CPU
+fallback) when no GPU is usable.  No compute calls are made here."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, "quick-mer2_amd", "libqm2_hip.so")):
+        ge.build()
+    return ge.load_package()
+
+
+def declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(qm2t?_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    L = pkg.lib()
+    names = declared("qm2.h") + declared("qm2_tools.h")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(pkg.pyqm2.ABI_SYMBOLS) == declared("qm2.h")
+    assert sorted(pkg.pyqm2.TOOL_SYMBOLS) == declared("qm2_tools.h")
+    assert L.qm2_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "quick-mer2_amd", "libqm2_hip.so")],
+                         stdout=subprocess.PIPE, check=True).stdout.decode()
+    exported = set(re.findall(r" T (qm2t?_[a-z_0-9]+)", out))
+    assert set(names) <= exported
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the loud-failure path cannot be shown")
+    with pytest.raises(pkg.pyqm2.Qm2Error) as e:
+        pkg.Counter(np.zeros(1 << 10, dtype=np.uint64), k=30)
+    assert "no usable HIP device" in str(e.value) and "no CPU fallback" in str(e.value)
+
+
+def test_cli_fails_loudly_without_gpu(pkg, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    cli = os.path.join(ROOT, "quick-mer2_amd", "quicKmer2")
+    r = subprocess.run([cli, "count", os.path.join(HERE, "golden", "kat", "ref.fa"),
+                        os.path.join(HERE, "golden", "kat", "upper.fa"), str(tmp_path / "o")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode != 0
+    assert b"no usable HIP device" in r.stdout
+    assert not os.path.exists(str(tmp_path / "o.bin"))
+    # usage / dispatch text (QuicKmer.c:1496-1519 surface, count only)
+    r = subprocess.run([cli], stdout=subprocess.PIPE)
+    assert r.returncode == 1 and b"count" in r.stdout
+    r = subprocess.run([cli, "count", "-h"], stdout=subprocess.PIPE)
+    assert b"quicKmer2 count [Options] ref.fa sample.fast[a/q] Out_prefix" in r.stdout
+
+
+def test_product_never_references_the_oracle():
+    """The product tree must not import, link or call anything under oracle/."""
+    bad = []
+    for dp, dn, fn in os.walk(os.path.join(ROOT, "quick-mer2_amd")):
+        for f in fn:
+            if f.endswith((".so", ".pyc")) or f == "quicKmer2":
+                continue
+            txt = open(os.path.join(dp, f), errors="replace").read()
+            if re.search(r"qm2o_|oracle_lib|libqm2_oracle|oracle/", txt):
+                if f == "multi.py" and not re.search(r"qm2o_|oracle_lib|libqm2_oracle|import oracle", txt):
+                    continue       # multi.py mentions the word in a docstring only
+                bad.append(f)
+    assert not bad, bad
+    out = subprocess.run(["ldd", os.path.join(ROOT, "quick-mer2_amd", "quicKmer2")], stdout=subprocess.PIPE).stdout
+    assert b"oracle" not in out
+
+
+def test_host_reader_matches_reference_line_discipline(tmp_path):
+    """qm2_reader.c vs the oracle's restatement of QuicKmer.c:393-398/:451-455, via a tiny
+    host-only harness (no GPU): the stripped stream must be identical."""
+    src = os.path.join(ROOT, "quick-mer2_amd", "csrc")
+    harness = tmp_path / "h.c"
+    harness.write_text('''
+#include <stdio.h>
+#include "qm2_host.h"
+static int sink(void *u, const char *p, size_t n) { fwrite(p, 1, n, (FILE *)u); return 0; }
+int main(int argc, char **argv) { (void)argc; FILE *o = fopen(argv[2], "wb");
+  int rc = qm2_stream_reads(argv[1], (size_t)atol(argv[3]), sink, o); fclose(o); return rc; }
+''')
+    exe = str(tmp_path / "h")
+    subprocess.run(["gcc", "-O1", "-I", src, "-include", "stdlib.h", "-o", exe, str(harness),
+                    os.path.join(src, "qm2_reader.c")], check=True)
+    import oracle_lib as ol
+    import synth
+    cases = synth.kat_cases(synth.kat_reference())
+    extra = {
+        "no_final_newline": ("fa", b">a\nACGTACGT\nGGGG"),
+        "fq_truncated": ("fq", b"@a\nACGT\n+\nIIII\n@b\nGG"),
+        "gt_in_fastq_seq_pos": ("fq", b"@a\nACGT\n+\nIIII\n>odd\nTTTT\n+\nIIII\n@c\nCCCC\n+\nIIII\n"),
+        "empty_seq_line": ("fq", b"@a\n\n+\n\n@b\nACGT\n+\nIIII\n"),
+    }
+    for name, (kind, data) in list(cases.items()) + list(extra.items()):
+        p = tmp_path / ("%s.%s" % (name, kind))
+        p.write_bytes(data)
+        exp = ol.strip_reads(str(p), seekable=True)
+        for batch in (64, 4096, 1 << 20):
+            outp = str(tmp_path / "out.bin")
+            subprocess.run([exe, str(p), outp, str(batch)], check=True)
+            assert open(outp, "rb").read() == exp, (name, batch)
+        # pipe: first line is lost unless FASTQ (QuicKmer.c:396)
+        outp = str(tmp_path / "out_pipe.bin")
+        with open(str(p), "rb") as f:
+            pr = subprocess.Popen(["cat"], stdin=f, stdout=subprocess.PIPE)
+            subprocess.run([exe, "/dev/fd/0", outp, "4096"], stdin=pr.stdout, check=True)
+            pr.wait()
+        assert open(outp, "rb").read() == ol.strip_reads(str(p), seekable=False), name

@@ -1,0 +1,173 @@
+"""The N>1 host logic (quick-mer2_amd/multi.py) under torch.distributed with the
+gloo backend, world_size 2 and 4, on the CPU.  The compute legs are replaced by
+a stand-in engine built on the oracle (test infrastructure, defined HERE);
+everything else — read partitioning, owner bucketing contract, all-to-all of
+ragged k-mer slabs, overhang folding, counter reduction, final assembly — is the
+product's code.  Results must equal the single-process oracle bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+
+class OracleEngine:
+    """CPU stand-in for HipEngine: same method contract, oracle arithmetic."""
+
+    def __init__(self):
+        import oracle_lib as ol
+        self.ol = ol
+
+    class Ctx:
+        pass
+
+    def open(self, keys_span, hash_size, k, span, counters):
+        c = self.Ctx()
+        c.keys = np.ascontiguousarray(keys_span, dtype=np.uint64)
+        c.H, c.k = hash_size, k
+        c.lo = 0 if span is None else span[0]
+        c.counters = counters
+        c.close = lambda: None
+        return c
+
+    def new_counters(self, n):
+        return torch.zeros(n, dtype=torch.int32)
+
+    def to_device(self, lines):
+        return torch.frombuffer(bytearray(lines), dtype=torch.uint8)
+
+    def _probe_np(self, c, kmers):
+        import ctypes as C
+        L = self.ol.lib()
+        cnt = c.counters.numpy()
+        idx = C.c_uint64()
+        mask, half = c.H - 1, c.H >> 1
+        for km in kmers:
+            km = int(km)
+            i = L.qm2o_djb(km) & mask
+            step = -1 if (i & half) else 1
+            while True:
+                v = int(c.keys[i - c.lo])        # IndexError here = a walk left the span
+                if v == km:
+                    cnt[i - c.lo] += 1
+                    break
+                if v == 0:
+                    break
+                i += step
+
+    def count(self, c, d_lines):
+        kmers, _ = self.ol.extract(d_lines.numpy().tobytes(), c.k)
+        self._probe_np(c, kmers)
+
+    def encode(self, c, d_lines, n_buckets):
+        kmers, _ = self.ol.extract(d_lines.numpy().tobytes(), c.k)
+        L = self.ol.lib()
+        lgH = int(np.log2(c.H))
+        shift = lgH - int(np.log2(n_buckets))
+        owner = np.array([(L.qm2o_djb(int(x)) & (c.H - 1)) >> shift for x in kmers], dtype=np.int64) \
+            if n_buckets > 1 else np.zeros(len(kmers), dtype=np.int64)
+        cap = max(16, d_lines.numel())
+        out = torch.zeros(n_buckets * cap, dtype=torch.int64)
+        fills = torch.zeros(n_buckets, dtype=torch.int64)
+        for g in range(n_buckets):
+            sel = kmers[owner == g].view(np.int64)
+            out[g * cap:g * cap + len(sel)] = torch.from_numpy(sel.copy())
+            fills[g] = len(sel)
+        return out, fills, cap
+
+    def probe(self, c, d_kmers):
+        self._probe_np(c, d_kmers.numpy().view(np.uint64))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, qm_path, lines, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from quick_mer2_amd import multi
+    import oracle_lib as ol
+    qm = ol.load_qm(qm_path)
+    eng = OracleEngine()
+    if mode == "replica":
+        job = multi.ReplicaJob(dist, eng, qm["keys"], qm["k"])
+    else:
+        job = multi.ShardedJob(dist, eng, qm["keys"], qm["k"], torch)
+    half = lines.rfind(b"\n", 0, len(lines) // 2) + 1
+    job.count(lines[:half])              # two "batches"
+    job.count(lines[half:])
+    depth = job.finish()
+    np.save(os.path.join(out_dir, "depth_%s_%d.npy" % (mode, rank)), depth)
+    job.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,world", [("replica", 2), ("sharded", 2), ("sharded", 4)])
+def test_multi_rank_counts_equal_single_process(mode, world, tmp_path):
+    import oracle_lib as ol
+    import synth
+    qm_path = os.path.join(HERE, "golden", "kat", "ref.fa.qm")
+    qm = ol.load_qm(qm_path)
+    cases = synth.kat_cases(synth.kat_reference())
+    p = tmp_path / "r.fa"
+    p.write_bytes(cases["reads_fa"][1][:120_000] + b"\n" + cases["polyA"][1])
+    lines = ol.strip_reads(str(p))
+    exp, _ = ol.count_lines(qm["keys"], qm["k"], lines)
+    mp.spawn(_worker, args=(world, _free_port(), mode, qm_path, lines, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(str(tmp_path / ("depth_%s_%d.npy" % (mode, r))))
+        assert np.array_equal(got, exp), (mode, world, r)
+
+
+def test_rank_slices_partition_the_stream():
+    import __graft_entry__ as ge
+    ge.load_package()
+    from quick_mer2_amd import multi
+    rng = np.random.default_rng(3)
+    blob = b"".join(bytes(rng.integers(65, 70, int(rng.integers(0, 90)), dtype=np.uint8)) + b"\n" for _ in range(500))
+    for world in (1, 2, 3, 8):
+        cuts = [multi.rank_slice(blob, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(blob)
+        for (a, b), (c, d) in zip(cuts[:-1], cuts[1:]):
+            assert b == c
+        for a, b in cuts:
+            assert a == b or (blob[b - 1:b] == b"\n" and (a == 0 or blob[a - 1:a] == b"\n"))
+
+
+def test_shard_spans_contain_every_walk():
+    """qm2_shard_span (pure host C): a probe walk that starts in the owned range never leaves the span."""
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    import oracle_lib as ol
+    for name in ("kat", "mini"):
+        keys = ol.load_qm(os.path.join(HERE, "golden", name, "ref.fa.qm"))["keys"]
+        H = len(keys)
+        for G in (1, 2, 4, 8, 64):
+            prev_hi = 0
+            for g in range(G):
+                own_lo, own_hi, lo, hi = pkg.pyqm2.shard_span(keys, G, g)
+                assert own_lo == prev_hi and own_hi - own_lo == H // G and lo <= own_lo and hi >= own_hi
+                prev_hi = own_hi
+                if G > 1:
+                    if own_lo < H // 2:
+                        assert lo == own_lo and keys[hi - 1] == 0 or hi == own_hi
+                        assert np.all(keys[own_hi - 1:hi - 1] != 0) if hi > own_hi else True
+                    else:
+                        assert hi == own_hi and (keys[lo] == 0 or lo == own_lo)
