@@ -54,6 +54,11 @@ typedef struct qm2_ctx qm2_ctx;
 #define QM2_FLAG_TIMING      0x1u  /* bracket every kernel launch with HIP events
                                       on its own stream (qm2_get_profile)       */
 #define QM2_FLAG_NO_STATS    0x2u  /* do not collect n_probes / n_hits          */
+#define QM2_FLAG_DIRECT      0x4u  /* always use the direct kernel (random probes +
+                                      global atomics), never the partitioned pipeline */
+#define QM2_FLAG_PARTITION   0x8u  /* always use the partitioned pipeline (radix-
+                                      partition by home slot, probe + count in LDS);
+                                      default: chosen per batch from its size vs. H   */
 
 typedef struct {
     uint32_t struct_size;     /* = sizeof(qm2_opts); 0-filled fields = defaults  */
@@ -62,6 +67,8 @@ typedef struct {
     uint32_t n_staging;       /* pinned host staging buffers for qm2_submit
                                  (default 3; each has its own stream)            */
     uint64_t staging_bytes;   /* size of each staging buffer (default 64 MiB)    */
+    uint64_t batch_bytes;     /* device batch that qm2_submit accumulates before it
+                                 launches (default 1 GiB; two are kept)          */
     void    *ext_keys;        /* optional: device pointer to H x u64 keys that are
                                  ALREADY resident (then `keys` may be NULL)      */
     void    *ext_counters;    /* optional: device pointer to H x u32 counters
@@ -86,10 +93,24 @@ typedef struct {
     uint64_t n_hits;    /* counter increments (:291 / :443)                       */
 } qm2_stats;
 
+/* kernel classes timed separately under QM2_FLAG_TIMING */
+enum {
+    QM2_K_COUNT_DIRECT = 0,   /* count_kernel: fused encode + probe + atomics     */
+    QM2_K_SPLIT_TEXT   = 1,   /* split_text_kernel: encode + level-1 partition    */
+    QM2_K_SPLIT_KMER   = 2,   /* split_kmer_kernel: deeper partition levels       */
+    QM2_K_BUCKET_COUNT = 3,   /* bucket_count_kernel: probe + count in LDS        */
+    QM2_K_PROBE        = 4,   /* probe_kernel: spill list / qm2_probe_device      */
+    QM2_K_ENCODE       = 5,   /* encode_kernel (qm2_encode_device)                */
+    QM2_K_CLASSES      = 8
+};
+
 typedef struct {
-    uint64_t n_launches;      /* count-kernel launches timed                      */
-    double   kernel_ms;       /* sum of their HIP-event durations                 */
-    double   last_kernel_ms;  /* duration of the most recent one                  */
+    uint64_t n_launches;      /* batches (qm2_submit_device calls / staged batches) timed */
+    double   kernel_ms;       /* sum of all HIP-event kernel durations            */
+    double   last_kernel_ms;  /* kernel time of the most recent batch             */
+    uint64_t class_launches[QM2_K_CLASSES];
+    double   class_ms[QM2_K_CLASSES];
+    uint64_t partitioned_batches, direct_batches;
 } qm2_profile;
 
 /* Create a counting context for a dictionary of `hash_size` slots (power of

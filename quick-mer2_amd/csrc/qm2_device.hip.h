@@ -54,7 +54,12 @@ struct SeqView {
 
 /* stats block in device memory */
 struct DevStats {
-    unsigned long long n_bases, n_kmers, n_probes, n_hits, overflow;
+    unsigned long long n_bases, n_kmers, n_probes, n_hits;
+    unsigned long long overflow;    /* qm2_encode_device: k-mers that did not fit a bucket (error) */
+    unsigned long long part_lost;   /* partitioned pipeline, current batch: k-mers that fit neither
+                                       their bucket nor the spill list => the batch is recounted by
+                                       the direct kernel instead (exact either way)              */
+    unsigned long long fallbacks;   /* batches that took that fallback                            */
 };
 
 /* ---- SWAR helpers ---------------------------------------------------------- */

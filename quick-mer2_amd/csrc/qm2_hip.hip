@@ -2,9 +2,11 @@
  * qm2_hip.hip — the HIP implementation of include/qm2.h (libqm2_hip.so).
  *
  * Host side of the counting phase: device residency of the dictionary
- * (QuicKmer.c:353-366), a pinned multi-buffer H2D pipeline that replaces the
- * reference's producer/worker FIFOs (:368-384, :421-439), and the drain
- * (:458-479).  The kernels live in qm2_kernels.hip.h.
+ * (QuicKmer.c:353-366), a pinned staging -> device-batch pipeline that replaces
+ * the reference's producer/worker FIFOs (:368-384, :421-439), the choice between
+ * the direct kernel and the partitioned pipeline per batch, and the drain
+ * (:458-479).  Kernels: qm2_kernels.hip.h (direct, split path) and
+ * qm2_partition.hip.h (partitioned pipeline).
  *
  * There is deliberately no CPU implementation behind this ABI: without a
  * usable HIP device every call fails loudly.
@@ -12,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +23,7 @@
 
 #include "../../include/qm2.h"
 #include "qm2_kernels.hip.h"
+#include "qm2_partition.hip.h"
 #include "qm2_plan.h"
 
 using namespace qm2;
@@ -54,19 +58,48 @@ extern "C" uint32_t qm2_abi_version(void) { return QM2_ABI_VERSION; }
 namespace {
 
 constexpr size_t kDevPad = 64;
+constexpr int    kLgS = 12;                /* finest bucket = 4096 table slots (48 KiB + halo of LDS) */
+constexpr int    kMaxLevels = 3;
 
-struct Slot {
-    char       *host = nullptr;            /* pinned */
+struct Slot {                               /* one pinned staging buffer */
+    char       *host = nullptr;
+    hipEvent_t  done = nullptr;             /* its H2D copy has finished */
+    bool        busy = false;
+};
+
+struct Batch {                              /* one device batch being filled by qm2_submit */
     uint8_t    *dev = nullptr;
-    uint64_t   *dev_sup = nullptr;         /* suppress list for this slot */
-    size_t      sup_cap = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t  done = nullptr;
+    size_t      fill = 0;
+    size_t      carry = 0;                  /* leading bytes that only serve as look-back */
+    std::vector<uint64_t> wraps;            /* uint16-wrap positions, relative to dev[0]  */
+    uint64_t   *dev_wraps = nullptr;
+    size_t      wraps_cap = 0;
+    hipEvent_t  done = nullptr;             /* its kernels have finished */
     bool        busy = false;
 };
 
 struct TimedLaunch {
     hipEvent_t a, b;
+    int cls;
+    bool batch_end;
+};
+
+struct PartPlan {                           /* how a batch is radix-partitioned for this table */
+    int      levels = 0;
+    uint32_t bits[kMaxLevels] = {0, 0, 0};
+    uint32_t shift[kMaxLevels] = {0, 0, 0}; /* child id at level l = (home >> shift[l]) & (fan-1) */
+    uint64_t buckets[kMaxLevels] = {0, 0, 0};
+    /* sized for `reserved` payload bytes */
+    uint64_t reserved = 0;
+    uint32_t cap[kMaxLevels] = {0, 0, 0};
+    uint64_t *buf[2] = {nullptr, nullptr};
+    uint64_t  buf_slots[2] = {0, 0};
+    uint32_t *cursors = nullptr;            /* all levels, contiguous */
+    uint64_t  cursor_off[kMaxLevels] = {0, 0, 0};
+    uint64_t  n_cursors = 0;
+    uint64_t *spill = nullptr;
+    uint64_t  spill_cap = 0;
+    unsigned long long *spill_count = nullptr;
 };
 
 }  // namespace
@@ -75,24 +108,29 @@ struct qm2_ctx {
     int         device = 0;
     uint32_t    k = 30;
     uint64_t    H = 0;
+    uint32_t    lgH = 0;
     uint64_t    span_lo = 0, span_hi = 0;
     uint32_t    flags = 0;
     uint64_t   *keys = nullptr;
     bool        own_keys = false;
     uint32_t   *counters = nullptr;
     bool        own_counters = false;
-    uint16_t   *narrow = nullptr;          /* H x u16 scratch for qm2_finish */
+    uint16_t   *narrow = nullptr;           /* H x u16 scratch for qm2_finish */
     DevStats   *stats = nullptr;
-    hipStream_t stream = nullptr;          /* device-resident submissions */
+    hipStream_t stream = nullptr;           /* every kernel of this context runs here, in order */
     bool        own_stream = false;
+    hipStream_t copy_stream = nullptr;      /* H2D staging copies */
     std::vector<Slot> slots;
     size_t      staging_bytes = 0;
     uint32_t    next_slot = 0;
+    Batch       batch[2];
+    size_t      batch_bytes = 0;
+    int         cur = 0;
     int         n_cu = 256;
-    std::vector<TimedLaunch> timed;        /* recorded, not yet read */
-    std::vector<TimedLaunch> pool;         /* free event pairs */
-    qm2_profile prof = {0, 0.0, 0.0};
-    uint64_t    host_bases_hint = 0;
+    std::vector<TimedLaunch> timed;
+    std::vector<TimedLaunch> pool;
+    qm2_profile prof;
+    PartPlan    part;
 };
 
 static int use_device(qm2_ctx *c)
@@ -122,7 +160,9 @@ static int grid_for(const qm2_ctx *c, uint64_t n_wave_items)
     return (int)blocks;
 }
 
-static int time_begin(qm2_ctx *c, hipStream_t s, TimedLaunch *t)
+/* ---- per-kernel timing (QM2_FLAG_TIMING) ----------------------------------- */
+
+static int time_begin(qm2_ctx *c, TimedLaunch *t, int cls)
 {
     if (!(c->flags & QM2_FLAG_TIMING)) return 0;
     if (!c->pool.empty()) {
@@ -132,39 +172,121 @@ static int time_begin(qm2_ctx *c, hipStream_t s, TimedLaunch *t)
         HIP_OK(hipEventCreate(&t->a));
         HIP_OK(hipEventCreate(&t->b));
     }
-    HIP_OK(hipEventRecord(t->a, s));
+    t->cls = cls;
+    t->batch_end = false;
+    HIP_OK(hipEventRecord(t->a, c->stream));
     return 0;
 }
 
-static int time_end(qm2_ctx *c, hipStream_t s, TimedLaunch *t)
+static int time_end(qm2_ctx *c, TimedLaunch *t, bool batch_end = false)
 {
     if (!(c->flags & QM2_FLAG_TIMING)) return 0;
-    HIP_OK(hipEventRecord(t->b, s));
+    HIP_OK(hipEventRecord(t->b, c->stream));
+    t->batch_end = batch_end;
     c->timed.push_back(*t);
     return 0;
 }
 
 static int harvest_timing(qm2_ctx *c)
 {
+    double batch_ms = 0;
     for (auto &t : c->timed) {
         float ms = 0.f;
         HIP_OK(hipEventSynchronize(t.b));
         HIP_OK(hipEventElapsedTime(&ms, t.a, t.b));
-        c->prof.n_launches++;
         c->prof.kernel_ms += ms;
-        c->prof.last_kernel_ms = ms;
+        c->prof.class_ms[t.cls] += ms;
+        c->prof.class_launches[t.cls]++;
+        batch_ms += ms;
+        if (t.batch_end) {
+            c->prof.n_launches++;
+            c->prof.last_kernel_ms = batch_ms;
+            batch_ms = 0;
+        }
         c->pool.push_back(t);
     }
     c->timed.clear();
     return 0;
 }
 
-/* Launch the fused kernel over a device buffer. `data` points at payload byte
- * 0; `carry` bytes before emit start belong to the previous part of a line. */
-static int launch_count(qm2_ctx *c, hipStream_t s, const uint8_t *data, size_t n, size_t carry,
-                        const uint64_t *d_sup, uint64_t n_sup)
+/* ---- partition plan --------------------------------------------------------- */
+
+static void part_init(qm2_ctx *c)
 {
-    if (n == 0) return 0;
+    PartPlan &p = c->part;
+    const int nb = (int)c->lgH > kLgS ? (int)c->lgH - kLgS : 0;     /* bits of the finest bucket id */
+    p.levels = nb <= 8 ? 1 : (nb + 7) / 8;
+    if (p.levels > kMaxLevels) { p.levels = 0; return; }             /* cannot happen for H <= 2^32 */
+    int left = nb, cum = 0;
+    for (int l = 0; l < p.levels; l++) {
+        const int b = (left + (p.levels - l) - 1) / (p.levels - l);
+        p.bits[l] = (uint32_t)b;
+        cum += b;
+        left -= b;
+        p.shift[l] = c->lgH - (uint32_t)cum;                          /* >= kLgS */
+        p.buckets[l] = 1ull << cum;
+    }
+}
+
+static void part_free(PartPlan &p)
+{
+    for (int i = 0; i < 2; i++) { if (p.buf[i]) (void)hipFree(p.buf[i]); p.buf[i] = nullptr; p.buf_slots[i] = 0; }
+    if (p.cursors) (void)hipFree(p.cursors);
+    if (p.spill) (void)hipFree(p.spill);
+    if (p.spill_count) (void)hipFree(p.spill_count);
+    p.cursors = nullptr; p.spill = nullptr; p.spill_count = nullptr;
+    p.reserved = 0;
+}
+
+/* Make sure the partition buffers can take a batch of n payload bytes (an upper
+ * bound on its k-mers).  Returns 1 with g_err set when memory does not allow:
+ * the caller then uses the direct kernel. */
+static int part_reserve(qm2_ctx *c, uint64_t n)
+{
+    PartPlan &p = c->part;
+    if (p.levels == 0) return 1;
+    if (n <= p.reserved) return 0;
+    HIP_OK(hipStreamSynchronize(c->stream));                          /* buffers may be in use */
+    const uint64_t want = std::max<uint64_t>(n + n / 16, 1u << 20);   /* grow with some slack */
+    part_free(p);
+    double mean = (double)want;
+    uint64_t slots[kMaxLevels] = {0, 0, 0};
+    for (int l = 0; l < p.levels; l++) {
+        mean /= (double)(1u << p.bits[l]);
+        /* expected fill + a margin that covers the Poisson spread of uniform hashing;
+         * skew beyond it goes to the spill list */
+        const double capd = mean * (l == 0 ? 1.10 : 1.20) + 8.0 * std::sqrt(mean + 1.0) + 64.0;
+        if (capd > 4.0e9) return fail("qm2: batch too large for the partition plan");
+        p.cap[l] = (uint32_t)capd;
+        slots[l] = p.buckets[l] * (uint64_t)p.cap[l];
+        mean = (double)p.cap[l];
+    }
+    p.buf_slots[0] = std::max(slots[0], slots[2]);
+    p.buf_slots[1] = slots[1];
+    p.n_cursors = 0;
+    for (int l = 0; l < p.levels; l++) { p.cursor_off[l] = p.n_cursors; p.n_cursors += p.buckets[l]; }
+    p.spill_cap = want / 2 + 4096;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; i++)
+        if (p.buf_slots[i]) e = hipMalloc((void **)&p.buf[i], p.buf_slots[i] * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&p.cursors, p.n_cursors * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&p.spill, p.spill_cap * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&p.spill_count, sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        part_free(p);
+        snprintf(g_err, sizeof g_err, "qm2: partition buffers for %llu bytes do not fit (%s)",
+                 (unsigned long long)n, hipGetErrorString(e));
+        return 1;
+    }
+    p.reserved = want;
+    return 0;
+}
+
+/* ---- launching one batch ----------------------------------------------------- */
+
+static SeqView seq_view(const uint8_t *data, size_t n, size_t carry, const uint64_t *d_sup, uint64_t n_sup)
+{
     SeqView sv;
     const uintptr_t p = (uintptr_t)data;
     sv.lead = p & 15u;
@@ -173,17 +295,109 @@ static int launch_count(qm2_ctx *c, hipStream_t s, const uint8_t *data, size_t n
     sv.n_total = sv.lead + n;
     sv.suppress = d_sup;
     sv.n_suppress = n_sup;
+    return sv;
+}
+
+static int launch_direct(qm2_ctx *c, const SeqView &sv, const unsigned long long *only_if, bool seq_stats,
+                         bool batch_end)
+{
     const uint64_t n_tiles = (sv.n_total + kTileBytes - 1) / kTileBytes;
     const int grid = grid_for(c, n_tiles);
-    DevStats *st = c->stats;
     TimedLaunch t;
-    if (time_begin(c, s, &t)) return 1;
+    if (time_begin(c, &t, QM2_K_COUNT_DIRECT)) return 1;
     if (c->k == 30)
-        hipLaunchKernelGGL(count_kernel<true>, dim3(grid), dim3(kBlock), 0, s, sv, table_view(c), c->k, n_tiles, st);
+        hipLaunchKernelGGL(count_kernel<true>, dim3(grid), dim3(kBlock), 0, c->stream, sv, table_view(c), c->k,
+                           n_tiles, c->stats, only_if, seq_stats);
     else
-        hipLaunchKernelGGL(count_kernel<false>, dim3(grid), dim3(kBlock), 0, s, sv, table_view(c), c->k, n_tiles, st);
+        hipLaunchKernelGGL(count_kernel<false>, dim3(grid), dim3(kBlock), 0, c->stream, sv, table_view(c), c->k,
+                           n_tiles, c->stats, only_if, seq_stats);
     HIP_OK(hipGetLastError());
-    return time_end(c, s, &t);
+    return time_end(c, &t, batch_end);
+}
+
+static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
+{
+    PartPlan &p = c->part;
+    hipStream_t s = c->stream;
+    const uint32_t hmask = (uint32_t)(c->H - 1);
+    HIP_OK(hipMemsetAsync(p.cursors, 0, p.n_cursors * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(part_begin_kernel, dim3(1), dim3(64), 0, s, c->stats, p.spill_count);
+    HIP_OK(hipGetLastError());
+
+    TimedLaunch t;
+    /* level 1: text -> buckets[0] */
+    {
+        SplitDst d = {p.buf[0], p.cursors + p.cursor_off[0], p.cap[0], p.spill, p.spill_count, p.spill_cap};
+        const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
+        const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu);
+        if (time_begin(c, &t, QM2_K_SPLIT_TEXT)) return 1;
+        if (c->k == 30)
+            hipLaunchKernelGGL(split_text_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k, hmask,
+                               p.shift[0], 1u << p.bits[0], n_chunks, d, c->stats);
+        else
+            hipLaunchKernelGGL(split_text_kernel<false>, dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k, hmask,
+                               p.shift[0], 1u << p.bits[0], n_chunks, d, c->stats);
+        HIP_OK(hipGetLastError());
+        if (time_end(c, &t)) return 1;
+    }
+    /* deeper levels: buckets[l-1] -> buckets[l], ping-pong between the two buffers */
+    for (int l = 1; l < p.levels; l++) {
+        SplitDst d = {p.buf[l & 1], p.cursors + p.cursor_off[l], p.cap[l], p.spill, p.spill_count, p.spill_cap};
+        const uint32_t chunks = (p.cap[l - 1] + kSplitSlots - 1) / kSplitSlots;
+        if (time_begin(c, &t, QM2_K_SPLIT_KMER)) return 1;
+        hipLaunchKernelGGL(split_kmer_kernel, dim3(chunks, (uint32_t)p.buckets[l - 1]), dim3(kSplitThreads), 0, s,
+                           p.buf[(l - 1) & 1], p.cursors + p.cursor_off[l - 1], p.cap[l - 1], hmask, p.shift[l],
+                           1u << p.bits[l], d, c->stats);
+        HIP_OK(hipGetLastError());
+        if (time_end(c, &t)) return 1;
+    }
+    /* finest buckets + table slices -> counters (skipped on device if the batch lost k-mers) */
+    {
+        const int L = p.levels - 1;
+        const uint32_t n_buckets = (uint32_t)p.buckets[L];
+        const int grid = (int)std::min<uint64_t>(n_buckets, (uint64_t)c->n_cu * 3 * 8);
+        if (time_begin(c, &t, QM2_K_BUCKET_COUNT)) return 1;
+        hipLaunchKernelGGL(bucket_count_kernel<kLgS>, dim3(grid), dim3(kCountThreads), 0, s, p.buf[L & 1],
+                           p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, c->stats);
+        HIP_OK(hipGetLastError());
+        if (time_end(c, &t)) return 1;
+    }
+    /* spill list (skew): the reference's batch loop on the direct path */
+    {
+        const uint64_t groups = (p.spill_cap + (uint64_t)kWave * kNJ - 1) / ((uint64_t)kWave * kNJ);
+        const int grid = grid_for(c, std::min<uint64_t>(groups, 1u << 16));
+        if (time_begin(c, &t, QM2_K_PROBE)) return 1;
+        hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(kBlock), 0, s, p.spill, p.spill_cap, p.spill_count,
+                           table_view(c), c->stats, &c->stats->part_lost);
+        HIP_OK(hipGetLastError());
+        if (time_end(c, &t)) return 1;
+    }
+    /* exact fallback, decided on the device: only if even the spill list overflowed */
+    if (launch_direct(c, sv, &c->stats->part_lost, false, true)) return 1;
+    hipLaunchKernelGGL(part_end_kernel, dim3(1), dim3(64), 0, s, c->stats);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+/* Count the sequence lines at `data` (device).  `carry` bytes at the start are
+ * look-back only.  Chooses the pipeline: the partitioned one streams the whole
+ * table once per batch (~16 B per slot), the direct one pays ~60 ps per k-mer in
+ * sector gathers and memory-side atomics; break-even is near n = H / 13. */
+static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry, const uint64_t *d_sup,
+                        uint64_t n_sup)
+{
+    if (n == 0) return 0;
+    const SeqView sv = seq_view(data, n, carry, d_sup, n_sup);
+    bool part = (c->flags & QM2_FLAG_PARTITION) != 0 || ((uint64_t)n >= c->H / 8 && n >= (1u << 20));
+    if (c->flags & QM2_FLAG_DIRECT) part = false;
+    if (c->span_lo != 0 || c->span_hi != c->H) part = false;         /* shard spans: direct only */
+    if (part && part_reserve(c, n)) part = false;                    /* no memory: direct */
+    if (part) {
+        c->prof.partitioned_batches++;
+        return launch_partitioned(c, sv);
+    }
+    c->prof.direct_batches++;
+    return launch_direct(c, sv, nullptr, true, true);
 }
 
 /* ---- open / close ---------------------------------------------------------- */
@@ -206,6 +420,8 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
     if (k < 1 || k > 31)
         return fail("qm2_open: k-mer size %u unsupported (1..31; k=32 is undefined in the reference)", k);
     if (!keys && !o.ext_keys) return fail("qm2_open: no keys given");
+    if ((o.flags & QM2_FLAG_DIRECT) && (o.flags & QM2_FLAG_PARTITION))
+        return fail("qm2_open: QM2_FLAG_DIRECT and QM2_FLAG_PARTITION exclude each other");
 
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
@@ -214,6 +430,7 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
 
     qm2_ctx *c = new qm2_ctx();
+    memset(&c->prof, 0, sizeof c->prof);
     if (o.device >= 0) c->device = o.device;
     else if (hipGetDevice(&c->device) != hipSuccess) c->device = 0;
     if (c->device >= n_dev) {
@@ -222,6 +439,7 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
     }
     c->k = k;
     c->H = hash_size;
+    while ((1ull << c->lgH) < hash_size) c->lgH++;
     c->flags = o.flags;
     c->span_lo = o.span_lo;
     c->span_hi = o.span_hi ? o.span_hi : hash_size;
@@ -252,6 +470,7 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
         OPEN_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
+    OPEN_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (o.ext_keys) c->keys = (uint64_t *)o.ext_keys;
     else {
         OPEN_OK(hipMalloc((void **)&c->keys, n_slots * sizeof(uint64_t)));
@@ -268,9 +487,11 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
     OPEN_OK(hipMemset(c->stats, 0, sizeof(DevStats)));
 
     c->staging_bytes = o.staging_bytes ? (size_t)o.staging_bytes : ((size_t)64 << 20);
-    if (c->staging_bytes < 4096) c->staging_bytes = 4096;
-    const uint32_t n_staging = o.n_staging ? o.n_staging : 3;
-    c->slots.resize(n_staging);          /* buffers are allocated lazily by qm2_submit */
+    if (c->staging_bytes < 64) c->staging_bytes = 64;
+    c->batch_bytes = o.batch_bytes ? (size_t)o.batch_bytes : ((size_t)1 << 30);
+    if (c->batch_bytes < 64) c->batch_bytes = 64;
+    c->slots.resize(o.n_staging ? o.n_staging : 3);      /* buffers are allocated lazily by qm2_submit */
+    part_init(c);
 #undef OPEN_OK
     *out = c;
     return 0;
@@ -283,17 +504,21 @@ extern "C" void qm2_close(qm2_ctx *c)
     (void)hipDeviceSynchronize();
     for (auto &s : c->slots) {
         if (s.host) (void)hipHostFree(s.host);
-        if (s.dev) (void)hipFree(s.dev);
-        if (s.dev_sup) (void)hipFree(s.dev_sup);
         if (s.done) (void)hipEventDestroy(s.done);
-        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    for (auto &b : c->batch) {
+        if (b.dev) (void)hipFree(b.dev);
+        if (b.dev_wraps) (void)hipFree(b.dev_wraps);
+        if (b.done) (void)hipEventDestroy(b.done);
     }
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto &t : c->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    part_free(c->part);
     if (c->own_keys && c->keys) (void)hipFree(c->keys);
     if (c->own_counters && c->counters) (void)hipFree(c->counters);
     if (c->narrow) (void)hipFree(c->narrow);
     if (c->stats) (void)hipFree(c->stats);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -301,23 +526,75 @@ extern "C" void qm2_close(qm2_ctx *c)
 extern "C" void *qm2_counters_device(qm2_ctx *c) { return c ? c->counters : nullptr; }
 extern "C" void *qm2_keys_device(qm2_ctx *c) { return c ? c->keys : nullptr; }
 
-/* ---- host-buffer pipeline -------------------------------------------------- */
+/* ---- host-buffer pipeline: pinned staging -> device batch -> kernels --------- */
 
-static int slot_acquire(qm2_ctx *c, Slot **out)
+static int batch_ready(qm2_ctx *c, Batch &b)
 {
-    Slot &s = c->slots[c->next_slot];
-    c->next_slot = (c->next_slot + 1) % (uint32_t)c->slots.size();
-    if (!s.host) {
-        HIP_OK(hipHostMalloc((void **)&s.host, c->staging_bytes + kCarry, hipHostMallocDefault));
-        HIP_OK(hipMalloc((void **)&s.dev, c->staging_bytes + kCarry + kDevPad));
-        HIP_OK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    if (!b.dev) {
+        HIP_OK(hipMalloc((void **)&b.dev, c->batch_bytes + kCarry + kDevPad));
+        HIP_OK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
     }
-    if (s.busy) {
-        HIP_OK(hipEventSynchronize(s.done));
-        s.busy = false;
+    if (b.busy) {
+        HIP_OK(hipEventSynchronize(b.done));
+        b.busy = false;
     }
-    *out = &s;
+    return 0;
+}
+
+/* Launch the kernels for the batch being filled and switch to the other one. */
+static int batch_flush(qm2_ctx *c)
+{
+    Batch &b = c->batch[c->cur];
+    if (b.fill <= b.carry) { b.fill = b.carry = 0; b.wraps.clear(); return 0; }
+    /* the kernels must see every staged copy of this batch */
+    hipEvent_t copied;
+    HIP_OK(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(copied, c->copy_stream));
+    HIP_OK(hipStreamWaitEvent(c->stream, copied, 0));
+    HIP_OK(hipEventDestroy(copied));
+    uint64_t *d_sup = nullptr;
+    const uint64_t n_sup = b.wraps.size();
+    if (n_sup) {                              /* long lines are rare: a small blocking copy is fine */
+        if (b.wraps_cap < n_sup) {
+            if (b.dev_wraps) HIP_OK(hipFree(b.dev_wraps));
+            b.wraps_cap = std::max<size_t>(n_sup, 1024);
+            HIP_OK(hipMalloc((void **)&b.dev_wraps, b.wraps_cap * sizeof(uint64_t)));
+        }
+        HIP_OK(hipMemcpy(b.dev_wraps, b.wraps.data(), n_sup * sizeof(uint64_t), hipMemcpyHostToDevice));
+        d_sup = b.dev_wraps;
+    }
+    if (launch_batch(c, b.dev, b.fill, b.carry, d_sup, n_sup)) return 1;
+    HIP_OK(hipEventRecord(b.done, c->stream));
+    b.busy = true;
+    b.fill = b.carry = 0;
+    b.wraps.clear();
+    c->cur ^= 1;
+    return 0;
+}
+
+/* Stage [src, src+n) behind the current batch's fill through the pinned slots. */
+static int stage_bytes(qm2_ctx *c, Batch &b, const char *src, size_t n)
+{
+    size_t done = 0;
+    while (done < n) {
+        Slot &s = c->slots[c->next_slot];
+        c->next_slot = (c->next_slot + 1) % (uint32_t)c->slots.size();
+        if (!s.host) {
+            HIP_OK(hipHostMalloc((void **)&s.host, c->staging_bytes, hipHostMallocDefault));
+            HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        }
+        if (s.busy) {
+            HIP_OK(hipEventSynchronize(s.done));
+            s.busy = false;
+        }
+        const size_t take = std::min(c->staging_bytes, n - done);
+        memcpy(s.host, src + done, take);
+        HIP_OK(hipMemcpyAsync(b.dev + b.fill, s.host, take, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_OK(hipEventRecord(s.done, c->copy_stream));
+        s.busy = true;
+        b.fill += take;
+        done += take;
+    }
     return 0;
 }
 
@@ -331,27 +608,26 @@ extern "C" int qm2_submit(qm2_ctx *c, const char *buf, size_t n)
     if (use_device(c)) return 1;
 
     std::vector<Part> parts;
-    plan_parts(buf, n, c->staging_bytes, parts);
-    for (const Part &pt : parts) {
-        Slot *s;
-        if (slot_acquire(c, &s)) return 1;
-        const size_t staged = pt.carry + pt.take;
-        memcpy(s->host, buf + pt.off - pt.carry, staged);
-        uint64_t *d_sup = nullptr;
-        const uint64_t n_sup = pt.wraps.size();
-        if (n_sup) {                       /* long lines are rare: a small blocking copy is fine */
-            if (s->sup_cap < n_sup) {
-                if (s->dev_sup) HIP_OK(hipFree(s->dev_sup));
-                s->sup_cap = std::max<size_t>(n_sup, 1024);
-                HIP_OK(hipMalloc((void **)&s->dev_sup, s->sup_cap * sizeof(uint64_t)));
-            }
-            HIP_OK(hipMemcpy(s->dev_sup, pt.wraps.data(), n_sup * sizeof(uint64_t), hipMemcpyHostToDevice));
-            d_sup = s->dev_sup;
+    {
+        const Batch &b0 = c->batch[c->cur];
+        const size_t pending = b0.fill - b0.carry;
+        plan_parts(buf, n, pending < c->batch_bytes ? c->batch_bytes - pending : 0, c->batch_bytes, parts);
+    }
+    for (size_t i = 0; i < parts.size(); i++) {
+        const Part &pt = parts[i];
+        if (pt.take == 0) {                   /* no line end fits behind the pending bytes */
+            if (batch_flush(c)) return 1;
+            continue;
         }
-        HIP_OK(hipMemcpyAsync(s->dev, s->host, staged, hipMemcpyHostToDevice, s->stream));
-        if (launch_count(c, s->stream, s->dev, staged, pt.carry, d_sup, n_sup)) return 1;
-        HIP_OK(hipEventRecord(s->done, s->stream));
-        s->busy = true;
+        Batch &b = c->batch[c->cur];
+        if (batch_ready(c, b)) return 1;
+        const size_t at = b.fill;             /* first staged byte of this part lands at dev[at] */
+        if (pt.carry) b.carry = pt.carry;     /* (only ever the first bytes of an empty batch) */
+        if (stage_bytes(c, b, buf + pt.off - pt.carry, pt.carry + pt.take)) return 1;
+        for (uint64_t w : pt.wraps) b.wraps.push_back(w + at);
+        /* every part but the last fills its batch; the last one may */
+        if (i + 1 < parts.size() || b.fill - b.carry >= c->batch_bytes)
+            if (batch_flush(c)) return 1;
     }
     return 0;
 }
@@ -363,19 +639,18 @@ extern "C" int qm2_submit_device(qm2_ctx *c, const void *d_seq, size_t n, const 
     if (n == 0) return 0;
     if (!d_seq) return fail("qm2_submit_device: null buffer");
     if (use_device(c)) return 1;
-    return launch_count(c, c->stream, (const uint8_t *)d_seq, n, 0, d_sup, n_sup);
+    return launch_batch(c, (const uint8_t *)d_seq, n, 0, d_sup, n_sup);
 }
 
 extern "C" int qm2_sync(qm2_ctx *c)
 {
     if (!c) return fail("qm2_sync: null context");
     if (use_device(c)) return 1;
-    for (auto &s : c->slots)
-        if (s.busy) {
-            HIP_OK(hipEventSynchronize(s.done));
-            s.busy = false;
-        }
+    if (batch_flush(c)) return 1;
+    HIP_OK(hipStreamSynchronize(c->copy_stream));
     HIP_OK(hipStreamSynchronize(c->stream));
+    for (auto &s : c->slots) s.busy = false;
+    for (auto &b : c->batch) b.busy = false;
     if (harvest_timing(c)) return 1;
     DevStats st;
     HIP_OK(hipMemcpy(&st, c->stats, sizeof st, hipMemcpyDeviceToHost));
@@ -413,7 +688,7 @@ extern "C" int qm2_reset(qm2_ctx *c)
     const uint64_t n_slots = c->span_hi - c->span_lo;
     HIP_OK(hipMemset(c->counters, 0, n_slots * sizeof(uint32_t)));
     HIP_OK(hipMemset(c->stats, 0, sizeof(DevStats)));
-    c->prof = {0, 0.0, 0.0};
+    memset(&c->prof, 0, sizeof c->prof);
     return 0;
 }
 
@@ -436,22 +711,14 @@ extern "C" int qm2_encode_device(qm2_ctx *c, const void *d_seq, size_t n, const 
     if (n_buckets == 0 || (n_buckets & (n_buckets - 1)) || n_buckets > c->H)
         return fail("qm2_encode_device: bucket count %u is not a power of two <= H", n_buckets);
     if (use_device(c)) return 1;
-    SeqView sv;
-    const uintptr_t p = (uintptr_t)d_seq;
-    sv.lead = p & 15u;
-    sv.base = (const uint8_t *)(p - sv.lead);
-    sv.emit_from = sv.lead;
-    sv.n_total = sv.lead + n;
-    sv.suppress = d_sup;
-    sv.n_suppress = n_sup;
+    const SeqView sv = seq_view((const uint8_t *)d_seq, n, 0, d_sup, n_sup);
     const uint64_t n_tiles = (sv.n_total + kTileBytes - 1) / kTileBytes;
-    uint32_t lgH = 0, lgB = 0;
-    while ((1ull << lgH) < c->H) lgH++;
+    uint32_t lgB = 0;
     while ((1u << lgB) < n_buckets) lgB++;
-    const uint32_t owner_shift = lgH - lgB;
+    const uint32_t owner_shift = c->lgH - lgB;
     const int grid = grid_for(c, n_tiles);
     TimedLaunch t;
-    if (time_begin(c, c->stream, &t)) return 1;
+    if (time_begin(c, &t, QM2_K_ENCODE)) return 1;
     if (c->k == 30)
         hipLaunchKernelGGL(encode_kernel<true>, dim3(grid), dim3(kBlock), 0, c->stream, sv, c->k,
                            (uint32_t)(c->H - 1), n_tiles, d_out, bucket_cap, n_buckets, owner_shift,
@@ -461,7 +728,7 @@ extern "C" int qm2_encode_device(qm2_ctx *c, const void *d_seq, size_t n, const 
                            (uint32_t)(c->H - 1), n_tiles, d_out, bucket_cap, n_buckets, owner_shift,
                            (unsigned long long *)d_counts, c->stats);
     HIP_OK(hipGetLastError());
-    return time_end(c, c->stream, &t);
+    return time_end(c, &t, true);
 }
 
 extern "C" int qm2_probe_device(qm2_ctx *c, const uint64_t *d_kmers, uint64_t n, const uint64_t *d_n)
@@ -473,11 +740,12 @@ extern "C" int qm2_probe_device(qm2_ctx *c, const uint64_t *d_kmers, uint64_t n,
     const uint64_t groups = (n + (uint64_t)kWave * kNJ - 1) / ((uint64_t)kWave * kNJ);
     const int grid = grid_for(c, groups);
     TimedLaunch t;
-    if (time_begin(c, c->stream, &t)) return 1;
+    if (time_begin(c, &t, QM2_K_PROBE)) return 1;
     hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(kBlock), 0, c->stream, d_kmers, n,
-                       (const unsigned long long *)d_n, table_view(c), c->stats);
+                       (const unsigned long long *)d_n, table_view(c), c->stats,
+                       (const unsigned long long *)nullptr);
     HIP_OK(hipGetLastError());
-    return time_end(c, c->stream, &t);
+    return time_end(c, &t, true);
 }
 
 /* ---- pure host helper ------------------------------------------------------ */
@@ -493,14 +761,10 @@ extern "C" int qm2_shard_span(const uint64_t *keys, uint64_t H, uint32_t n_shard
     const uint64_t lo = (uint64_t)g * per, hi = lo + per;
     uint64_t slo = lo, shi = hi;
     if (n_shards > 1) {
-        if (lo < (H >> 1)) {
-            /* lower half: walks go up (:94-95) and may leave through `hi` */
-            while (shi < H && keys[shi - 1] != 0) shi++;
-            /* the walk stops ON the first empty slot: include it */
-            if (shi < H && keys[shi - 1] != 0) shi++;
-        } else {
-            while (slo > 0 && keys[slo] != 0) slo--;
-        }
+        /* walks go towards the middle (:94-95) and stop ON the first empty slot: extend the
+         * span over the occupied run past the middle-facing edge, empty slot included */
+        if (lo < (H >> 1)) while (shi < H && keys[shi - 1] != 0) shi++;
+        else               while (slo > 0 && keys[slo] != 0) slo--;
     }
     if (own_lo) *own_lo = lo;
     if (own_hi) *own_hi = hi;

@@ -42,8 +42,11 @@ constexpr int kNJ    = 16;             /* k-mers per lane per tile              
 
 template <bool K30>
 __global__ __launch_bounds__(kBlock) void count_kernel(SeqView sv, TableView tv, uint32_t k,
-                                                       uint64_t n_tiles, DevStats *stats)
+                                                       uint64_t n_tiles, DevStats *stats,
+                                                       const unsigned long long *only_if, bool seq_stats)
 {
+    /* as the partitioned pipeline's fallback this launch runs only if the batch lost k-mers */
+    if (only_if && *only_if == 0) return;
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t wave_id = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) / kWave;
     const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) / kWave;
@@ -88,8 +91,10 @@ __global__ __launch_bounds__(kBlock) void count_kernel(SeqView sv, TableView tv,
         n_bases = wave_sum(n_bases);  n_kmers = wave_sum(n_kmers);
         n_probes = wave_sum(n_probes); n_hits = wave_sum(n_hits);
         if (lane == 0) {
-            atomicAdd(&stats->n_bases, n_bases);
-            atomicAdd(&stats->n_kmers, n_kmers);
+            if (seq_stats) {
+                atomicAdd(&stats->n_bases, n_bases);
+                atomicAdd(&stats->n_kmers, n_kmers);
+            }
             atomicAdd(&stats->n_probes, n_probes);
             atomicAdd(&stats->n_hits, n_hits);
         }
@@ -155,9 +160,11 @@ __global__ __launch_bounds__(kBlock) void encode_kernel(SeqView sv, uint32_t k, 
  * strided by the wave so that the k-mer loads are coalesced. */
 __global__ __launch_bounds__(kBlock) void probe_kernel(const uint64_t *kmers, uint64_t n,
                                                        const unsigned long long *d_n,
-                                                       TableView tv, DevStats *stats)
+                                                       TableView tv, DevStats *stats,
+                                                       const unsigned long long *skip_if)
 {
-    if (d_n) n = *d_n;
+    if (skip_if && *skip_if != 0) return;
+    if (d_n) n = *d_n < n ? *d_n : n;
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t wave_id = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) / kWave;
     const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) / kWave;

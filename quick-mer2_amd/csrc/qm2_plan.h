@@ -45,26 +45,31 @@ inline void find_wraps(const char *buf, size_t n, std::vector<uint64_t> &out)
 
 struct Part {
     size_t off;       /* first payload byte of this part in the caller's buffer    */
-    size_t take;      /* payload bytes                                             */
+    size_t take;      /* payload bytes; 0 = "launch what is pending, then go on"   */
     size_t carry;     /* bytes before `off` staged again as look-back (0 or kCarry) */
     std::vector<uint64_t> wraps;   /* wrap positions relative to the first STAGED byte */
 };
 
-/* Cut [0, n) into parts of at most `capacity` payload bytes, at line boundaries
- * where possible; a line longer than the capacity is cut mid-way and the next
- * part re-stages the last kCarry bytes. */
-inline void plan_parts(const char *buf, size_t n, size_t capacity, std::vector<Part> &parts)
+/* Cut [0, n) into parts: the first may hold at most `first_room` payload bytes
+ * (what is left in the batch being filled), the others `capacity`.  Cuts fall on
+ * line boundaries where possible; every part but the last fills its batch.  A
+ * line longer than a whole batch is cut mid-way and the next part re-stages its
+ * last kCarry bytes as look-back. */
+inline void plan_parts(const char *buf, size_t n, size_t first_room, size_t capacity, std::vector<Part> &parts)
 {
     std::vector<uint64_t> wraps;
     find_wraps(buf, n, wraps);
     size_t wi = 0, off = 0, carry = 0;
+    bool first = true;
     while (off < n) {
-        size_t take = capacity < n - off ? capacity : n - off;
+        const size_t cap = first ? first_room : capacity;
+        size_t take = cap < n - off ? cap : n - off;
         size_t next_carry = 0;
         if (off + take < n) {
-            const char *nl = (const char *)memrchr(buf + off, '\n', take);
+            const char *nl = take ? (const char *)memrchr(buf + off, '\n', take) : nullptr;
             if (nl) take = (size_t)(nl - (buf + off)) + 1;
-            else next_carry = kCarry;
+            else if (first && first_room < capacity) take = 0;   /* nothing fits behind the pending bytes */
+            else next_carry = kCarry;                            /* one line longer than a batch */
         }
         Part p;
         p.off = off; p.take = take; p.carry = carry;
@@ -76,6 +81,7 @@ inline void plan_parts(const char *buf, size_t n, size_t capacity, std::vector<P
         parts.push_back(std::move(p));
         off += take;
         carry = next_carry;
+        first = false;
     }
 }
 

@@ -15,11 +15,14 @@ LIB_PATH = os.path.join(HERE, "libqm2_hip.so")
 
 FLAG_TIMING = 0x1
 FLAG_NO_STATS = 0x2
+FLAG_DIRECT = 0x4
+FLAG_PARTITION = 0x8
+KERNEL_CLASSES = ["count_direct", "split_text", "split_kmer", "bucket_count", "probe", "encode", "-", "-"]
 
 
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
-                ("n_staging", C.c_uint32), ("staging_bytes", C.c_uint64),
+                ("n_staging", C.c_uint32), ("staging_bytes", C.c_uint64), ("batch_bytes", C.c_uint64),
                 ("ext_keys", C.c_void_p), ("ext_counters", C.c_void_p), ("stream", C.c_void_p),
                 ("span_lo", C.c_uint64), ("span_hi", C.c_uint64)]
 
@@ -33,7 +36,9 @@ class Stats(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("n_launches", C.c_uint64), ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double)]
+    _fields_ = [("n_launches", C.c_uint64), ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double),
+                ("class_launches", C.c_uint64 * 8), ("class_ms", C.c_double * 8),
+                ("partitioned_batches", C.c_uint64), ("direct_batches", C.c_uint64)]
 
 
 class Range(C.Structure):
@@ -131,7 +136,7 @@ class Counter:
     """One counting context (qm2_ctx).  keys: host uint64[H] (or None with ext_keys)."""
 
     def __init__(self, keys, hash_size=None, k=30, device=-1, flags=0, n_staging=0, staging_bytes=0,
-                 ext_keys=None, ext_counters=None, stream=None, span=None):
+                 batch_bytes=0, ext_keys=None, ext_counters=None, stream=None, span=None):
         L = lib()
         self._h = C.c_void_p()
         o = Opts()
@@ -140,6 +145,7 @@ class Counter:
         o.flags = flags
         o.n_staging = n_staging
         o.staging_bytes = staging_bytes
+        o.batch_bytes = batch_bytes
         o.ext_keys = ext_keys
         o.ext_counters = ext_counters
         o.stream = stream
@@ -185,7 +191,10 @@ class Counter:
         p = Profile()
         _check(lib().qm2_get_profile(self._h, C.byref(p)), "qm2_get_profile")
         return {"n_launches": int(p.n_launches), "kernel_ms": float(p.kernel_ms),
-                "last_kernel_ms": float(p.last_kernel_ms)}
+                "last_kernel_ms": float(p.last_kernel_ms),
+                "class_launches": {KERNEL_CLASSES[i]: int(p.class_launches[i]) for i in range(6)},
+                "class_ms": {KERNEL_CLASSES[i]: float(p.class_ms[i]) for i in range(6)},
+                "partitioned_batches": int(p.partitioned_batches), "direct_batches": int(p.direct_batches)}
 
     @property
     def counters_ptr(self):

@@ -46,7 +46,7 @@ uint64_t qm2e_extract(const char *buf, size_t n, uint32_t k, size_t staging_byte
                       uint64_t *out, uint64_t cap, uint64_t *n_bases, uint64_t *n_parts)
 {
     std::vector<Part> parts;
-    plan_parts(buf, n, staging_bytes, parts);
+    plan_parts(buf, n, staging_bytes, staging_bytes, parts);
     std::vector<uint64_t> km;
     uint64_t bases = 0;
     for (const Part &pt : parts) {

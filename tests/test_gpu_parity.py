@@ -46,12 +46,21 @@ def kat_qm(setname="kat"):
 
 
 def check_against_oracle(qm2, keys, k, lines, **kw):
+    """Both pipelines (direct kernel; partitioned: radix split + LDS probe/count) vs the oracle."""
     exp_depth, exp_st = ol.count_lines(keys, k, lines)
-    with qm2.Counter(keys, k=k, **kw) as c:
-        c.submit(lines)
-        depth, st = c.finish()
-    assert st == exp_st
-    assert np.array_equal(depth, exp_depth)
+    for flags in (qm2.FLAG_DIRECT, qm2.FLAG_PARTITION):
+        with qm2.Counter(keys, k=k, flags=flags | qm2.FLAG_TIMING, **kw) as c:
+            c.submit(lines)
+            depth, st = c.finish()
+            prof = c.profile()
+        assert st == exp_st, flags
+        assert np.array_equal(depth, exp_depth), flags
+        if len(lines) > 64:
+            if flags == qm2.FLAG_PARTITION:
+                assert prof["partitioned_batches"] > 0 and prof["direct_batches"] == 0
+                assert prof["class_launches"]["bucket_count"] > 0
+            else:
+                assert prof["partitioned_batches"] == 0 and prof["class_launches"]["count_direct"] > 0
     return st
 
 
@@ -153,15 +162,18 @@ def test_batch_boundaries_do_not_matter(qm2, staging, tmp_path):
         p.write_bytes(cases[name][1])
         blob += ol.strip_reads(str(p))
     exp_depth, exp_st = ol.count_lines(qm["keys"], 30, blob)
-    with qm2.Counter(qm["keys"], k=30, staging_bytes=staging, n_staging=2) as c:
-        # feed in pieces cut at line boundaries
-        rng = np.random.default_rng(staging)
-        nl = np.flatnonzero(np.frombuffer(blob, dtype=np.uint8) == 10) + 1
-        cuts = sorted(set([0, len(blob)] + list(rng.choice(nl, size=7, replace=False))))
-        for a, b in zip(cuts[:-1], cuts[1:]):
-            c.submit(blob[a:b])
-        depth, st = c.finish()
-    assert st == exp_st and np.array_equal(depth, exp_depth)
+    for flags in (qm2.FLAG_DIRECT, qm2.FLAG_PARTITION):
+        for batch in (staging, 3 * staging + 17, 1 << 22):
+            with qm2.Counter(qm["keys"], k=30, staging_bytes=staging, n_staging=2, batch_bytes=batch,
+                             flags=flags) as c:
+                # feed in pieces cut at line boundaries
+                rng = np.random.default_rng(staging)
+                nl = np.flatnonzero(np.frombuffer(blob, dtype=np.uint8) == 10) + 1
+                cuts = sorted(set([0, len(blob)] + list(rng.choice(nl, size=7, replace=False))))
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    c.submit(blob[a:b])
+                depth, st = c.finish()
+            assert st == exp_st and np.array_equal(depth, exp_depth), (flags, batch)
 
 
 @pytest.mark.parametrize("setname,k", [("kat_k12", 12), ("kat_k25", 25), ("kat_k31", 31)])
@@ -234,6 +246,32 @@ def test_wrap_mod_65536_and_reset(qm2):
         assert st["n_kmers"] == 0 and not depth.any()
 
 
+def test_skewed_input_spills_and_falls_back(qm2):
+    """Partitioned pipeline under skew: poly-A floods one bucket.  A mild flood goes through the
+    spill list; a total one overflows even that and the batch is recounted by the direct kernel
+    (decided on the device).  Either way the counts are exact."""
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    keys = qm["keys"]
+    ref = synth.kat_reference().tobytes()
+    rng = np.random.default_rng(8)
+    normal = b"".join(ref[int(p):int(p) + 150] + b"\n" for p in rng.integers(0, 4800, 4000))
+    mild = normal + (b"A" * 150 + b"\n") * 2500 + (b"T" * 150 + b"\n") * 500
+    total = (b"A" * 150 + b"\n") * 12000
+    for name, blob in (("mild", mild), ("total", total)):
+        exp_depth, exp_st = ol.count_lines(keys, 30, blob)
+        with qm2.Counter(keys, k=30, flags=qm2.FLAG_PARTITION | qm2.FLAG_TIMING) as c:
+            c.submit(blob)
+            depth, st = c.finish()
+            c.submit(normal)                       # the context keeps working after a fallback
+            depth2, st2 = c.finish()
+        assert st == exp_st, name
+        assert np.array_equal(depth, exp_depth), name
+        e2, s2 = ol.count_lines(keys, 30, blob + normal)
+        assert st2 == s2 and np.array_equal(depth2, e2), name
+    z = ol.zero_slot(keys)
+    assert exp_depth[z] == (12000 * 121) % 65536       # k-mer 0 lands on the empty slot (QuicKmer.c:96-98)
+
+
 # ---- 3. device-resident input, any alignment -----------------------------------
 
 def test_submit_device_unaligned(qm2, torch_cuda, tmp_path):
@@ -248,10 +286,11 @@ def test_submit_device_unaligned(qm2, torch_cuda, tmp_path):
     for mis in (0, 1, 7, 15, 16, 33):
         buf = torch.zeros(len(blob) + 64, dtype=torch.uint8, device="cuda")
         buf[mis:mis + len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
-        with qm2.Counter(qm["keys"], k=30) as c:
-            c.submit_device(buf.data_ptr() + mis, len(blob))
-            depth, st = c.finish()
-        assert st == exp_st and np.array_equal(depth, exp_depth), mis
+        for flags in (qm2.FLAG_DIRECT, qm2.FLAG_PARTITION):
+            with qm2.Counter(qm["keys"], k=30, flags=flags) as c:
+                c.submit_device(buf.data_ptr() + mis, len(blob))
+                depth, st = c.finish()
+            assert st == exp_st and np.array_equal(depth, exp_depth), (mis, flags)
 
 
 # ---- 4. split path: encode + probe, sharded spans -------------------------------
@@ -382,9 +421,15 @@ def test_c2_scale_properties(qm2, torch_cuda):
     torch.cuda.synchronize()
     nbytes = reads.numel()
     counters = torch.zeros(H, dtype=torch.int32, device="cuda")
-    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr()) as c:
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), flags=qm2.FLAG_DIRECT) as cd:
+        cd.submit_device(reads.data_ptr(), nbytes)
+        d_direct, s_direct = cd.finish()
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr(),
+                     flags=qm2.FLAG_TIMING) as c:
         c.submit_device(reads.data_ptr(), nbytes)
         d1, s1 = c.finish()
+        assert c.profile()["partitioned_batches"] == 1          # this size takes the partitioned pipeline
+        assert s1 == s_direct and np.array_equal(d1, d_direct)   # ... and agrees with the direct kernel
         assert s1["n_bases"] == n_reads * rl
         assert int(counters.sum(dtype=torch.int64)) == s1["n_hits"]           # every hit is one increment
         assert s1["n_kmers"] <= n_reads * (rl - k + 1) and s1["n_probes"] >= s1["n_kmers"]
