@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=6, help="probe workers (reference recommends 6)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "direct", "partition"],
+                    help="count pipeline: auto = chosen per batch from its size vs. H")
     args = ap.parse_args()
 
     import numpy as np
@@ -126,7 +128,8 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
-    ctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=pyqm2.FLAG_TIMING,
+    mode_flag = {"auto": 0, "direct": pyqm2.FLAG_DIRECT, "partition": pyqm2.FLAG_PARTITION}[args.mode]
+    ctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=pyqm2.FLAG_TIMING | mode_flag,
                         ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr())
 
     def barrier():
@@ -172,25 +175,48 @@ def main():
         total_bases = int(tb.item())
     assert bases_rank == sum(batches[(args.warmup + i) % n_batches][2] for i in range(args.steps))
 
-    # ---- roofline of the dominant (only) kernel: algorithmic bytes / HIP-event kernel time ---
-    launches = prof1["n_launches"] - prof0["n_launches"]
+    # ---- roofline: per-kernel HIP-event times (recorded on the stream the kernels run on) -----
+    batches_timed = prof1["n_launches"] - prof0["n_launches"]
     kern_ms = prof1["kernel_ms"] - prof0["kernel_ms"]
-    b_alg = d["n_bases"] + 8 * d["n_probes"] + 4 * d["n_hits"]
-    achieved = b_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    cls_ms = {c: prof1["class_ms"][c] - prof0["class_ms"][c] for c in prof1["class_ms"]}
+    cls_n = {c: prof1["class_launches"][c] - prof0["class_launches"][c] for c in prof1["class_launches"]}
+    part_batches = prof1["partitioned_batches"] - prof0["partitioned_batches"]
+    b_survey = d["n_bases"] + 8 * d["n_probes"] + 4 * d["n_hits"]        # SURVEY 8(d), whole timed region
+    levels_kmer = (cls_n["split_kmer"] // max(1, part_batches)) if part_batches else 0
+    # algorithmic bytes each kernel class must move over the timed region
+    alg = {
+        "count_direct": b_survey if part_batches == 0 else 0,
+        "split_text": d["n_bases"] + 8 * d["n_kmers"],                     # text in, k-mers out
+        "split_kmer": 16 * d["n_kmers"] * levels_kmer,                     # k-mers in + out, per level
+        "bucket_count": (8 * d["n_kmers"] + args.steps * (8 * H + 8 * n_unique)) if part_batches else 0,
+        "probe": 0, "encode": 0,
+    }
+    dom = max(cls_ms, key=lambda c: cls_ms[c])
+    dom_ms = cls_ms[dom]
+    dom_n = max(1, cls_n[dom])
+    achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     traffic = None
     tr_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tr_file):
         try:
-            traffic = json.load(open(tr_file)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tr_file))
+            if tj.get("kernel_class") == dom:
+                traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    pipe_gbs = b_survey / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "qm2::count_kernel<true>", "launches": launches,
-                "avg_launch_ms": round(kern_ms / max(1, launches), 4),
-                "algorithmic_bytes_per_launch": b_alg // max(1, launches),
-                "bytes_per_base": round(b_alg / max(1, d["n_bases"]), 3),
-                "kernel_only_bases_per_s": round(d["n_bases"] / (kern_ms * 1e-3), 1) if kern_ms > 0 else None}
+                "kernel": "qm2::%s_kernel" % dom, "launches": cls_n[dom],
+                "avg_launch_ms": round(dom_ms / dom_n, 4),
+                "algorithmic_bytes_per_launch": alg[dom] // dom_n,
+                "pipeline": {"mode": "partitioned" if part_batches else "direct",
+                             "kernel_ms_per_step": {c: round(cls_ms[c] / args.steps, 4) for c in cls_ms if cls_n[c]},
+                             "sum_kernel_ms_per_step": round(kern_ms / args.steps, 4),
+                             "survey_bytes_per_base": round(b_survey / max(1, d["n_bases"]), 3),
+                             "survey_algorithmic_GBs": round(pipe_gbs, 2),
+                             "survey_frac_of_peak": round(pipe_gbs / HBM_PEAK_GBS, 5),
+                             "kernel_only_bases_per_s": round(d["n_bases"] / (kern_ms * 1e-3), 1) if kern_ms > 0 else None}}
 
     # ---- CPU baseline: the oracle's reference-model threaded counter on a bounded sample ------
     cpu = None

@@ -69,6 +69,9 @@ typedef struct {
     uint64_t staging_bytes;   /* size of each staging buffer (default 64 MiB)    */
     uint64_t batch_bytes;     /* device batch that qm2_submit accumulates before it
                                  launches (default 1 GiB; two are kept)          */
+    uint32_t part_max_bits;   /* partitioned pipeline: radix bits per level, 1..8
+                                 (default 8); smaller values only make sense in tests */
+    uint32_t reserved0;
     void    *ext_keys;        /* optional: device pointer to H x u64 keys that are
                                  ALREADY resident (then `keys` may be NULL)      */
     void    *ext_counters;    /* optional: device pointer to H x u32 counters

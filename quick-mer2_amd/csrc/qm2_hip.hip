@@ -211,11 +211,11 @@ static int harvest_timing(qm2_ctx *c)
 
 /* ---- partition plan --------------------------------------------------------- */
 
-static void part_init(qm2_ctx *c)
+static void part_init(qm2_ctx *c, int max_bits)
 {
     PartPlan &p = c->part;
     const int nb = (int)c->lgH > kLgS ? (int)c->lgH - kLgS : 0;     /* bits of the finest bucket id */
-    p.levels = nb <= 8 ? 1 : (nb + 7) / 8;
+    p.levels = nb <= max_bits ? 1 : (nb + max_bits - 1) / max_bits;
     if (p.levels > kMaxLevels) { p.levels = 0; return; }             /* cannot happen for H <= 2^32 */
     int left = nb, cum = 0;
     for (int l = 0; l < p.levels; l++) {
@@ -481,17 +481,20 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
     else {
         OPEN_OK(hipMalloc((void **)&c->counters, n_slots * sizeof(uint32_t)));
         c->own_counters = true;
-        OPEN_OK(hipMemset(c->counters, 0, n_slots * sizeof(uint32_t)));
+        /* stream-ordered: a plain hipMemset runs on the null stream, which the context's
+         * non-blocking stream does not wait for — kernels could start before it finishes */
+        OPEN_OK(hipMemsetAsync(c->counters, 0, n_slots * sizeof(uint32_t), c->stream));
     }
     OPEN_OK(hipMalloc((void **)&c->stats, sizeof(DevStats)));
-    OPEN_OK(hipMemset(c->stats, 0, sizeof(DevStats)));
+    OPEN_OK(hipMemsetAsync(c->stats, 0, sizeof(DevStats), c->stream));
+    OPEN_OK(hipStreamSynchronize(c->stream));
 
     c->staging_bytes = o.staging_bytes ? (size_t)o.staging_bytes : ((size_t)64 << 20);
     if (c->staging_bytes < 64) c->staging_bytes = 64;
     c->batch_bytes = o.batch_bytes ? (size_t)o.batch_bytes : ((size_t)1 << 30);
     if (c->batch_bytes < 64) c->batch_bytes = 64;
     c->slots.resize(o.n_staging ? o.n_staging : 3);      /* buffers are allocated lazily by qm2_submit */
-    part_init(c);
+    part_init(c, o.part_max_bits >= 1 && o.part_max_bits <= 8 ? (int)o.part_max_bits : 8);
 #undef OPEN_OK
     *out = c;
     return 0;
@@ -686,8 +689,9 @@ extern "C" int qm2_reset(qm2_ctx *c)
 {
     if (qm2_sync(c)) return 1;
     const uint64_t n_slots = c->span_hi - c->span_lo;
-    HIP_OK(hipMemset(c->counters, 0, n_slots * sizeof(uint32_t)));
-    HIP_OK(hipMemset(c->stats, 0, sizeof(DevStats)));
+    HIP_OK(hipMemsetAsync(c->counters, 0, n_slots * sizeof(uint32_t), c->stream));
+    HIP_OK(hipMemsetAsync(c->stats, 0, sizeof(DevStats), c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
     memset(&c->prof, 0, sizeof c->prof);
     return 0;
 }
