@@ -134,27 +134,44 @@ __host__ __device__ __forceinline__ uint32_t djb32(uint64_t kmer)
     return h;
 }
 
-/* Load the 16 bytes of lane-slot `g` (byte offset from sv.base, may be
- * negative or beyond the end): bytes outside [lead, n_total) read as '\n'. */
+/* The 16 bytes of lane-slot `g` (byte offset from sv.base, a multiple of 16; may be negative
+ * or beyond the end), in two steps so that the load can be issued early (software prefetch)
+ * and stay in flight: load16_raw is a single unconditional aligned load from a clamped
+ * address — any 16-byte aligned block that overlaps the payload lies inside its allocation's
+ * pages, so it is always safe to read whole — and fix16, applied where the bytes are consumed,
+ * turns everything outside [lead, n_total) into '\n'. */
+__host__ __device__ __forceinline__ uint4 load16_raw(const SeqView &sv, int64_t g)
+{
+    const int64_t last = (int64_t)((sv.n_total - 1) & ~(uint64_t)15);
+    const int64_t gc = g < 0 ? 0 : (g > last ? last : g);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(sv.base + gc));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__host__ __device__ __forceinline__ uint32_t keep_bytes(uint32_t w, int lo, int hi)
+{
+    /* keep bytes [lo, hi) of the dword (positions 0..3), the others become '\n' */
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > 4 ? 4 : hi;
+    if (lo >= hi) return 0x0A0A0A0Au;
+    const uint32_t m = (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & (0xFFFFFFFFu << (8 * lo));
+    return (w & m) | (0x0A0A0A0Au & ~m);
+}
+
+__host__ __device__ __forceinline__ uint4 fix16(const SeqView &sv, int64_t g, uint4 v)
+{
+    const int64_t lo = (int64_t)sv.lead - g, hi = (int64_t)sv.n_total - g;   /* valid bytes: [lo, hi) */
+    if (lo <= 0 && hi >= 16) return v;                                        /* the common case */
+    if (hi <= 0 || lo >= 16) return make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+    const int l = (int)(lo < 0 ? 0 : lo), h = (int)(hi > 16 ? 16 : hi);
+    return make_uint4(keep_bytes(v.x, l, h), keep_bytes(v.y, l - 4, h - 4),
+                      keep_bytes(v.z, l - 8, h - 8), keep_bytes(v.w, l - 12, h - 12));
+}
+
 __host__ __device__ __forceinline__ uint4 load16(const SeqView &sv, int64_t g)
 {
-    const uint4 nl4 = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
-    if (g + 16 <= (int64_t)sv.lead || g >= (int64_t)sv.n_total) return nl4;
-    if (g >= (int64_t)sv.lead && g + 16 <= (int64_t)sv.n_total) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(sv.base + g));
-        return make_uint4(v.x, v.y, v.z, v.w);
-    }
-    /* ragged edge (first / last 16 bytes of the buffer): byte by byte */
-    uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
-    for (int i = 0; i < 16; i++) {
-        int64_t p = g + i;
-        if (p >= (int64_t)sv.lead && p < (int64_t)sv.n_total) {
-            uint32_t c = sv.base[p];
-            w[i >> 2] = (w[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | (c << (8 * (i & 3)));
-        }
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    return fix16(sv, g, load16_raw(sv, g));
 }
 
 /* The 48-base window of one lane: its own 16 bases and the 32 before them. */
@@ -240,6 +257,18 @@ __device__ __forceinline__ Window make_window(const SeqView &sv, uint64_t tile0,
 {
     const int64_t g = lane_offset(tile0, lane);
     const Packed p = pack16(load16(sv, g));
+    Packed p1, p2;
+    p1.fwd = __shfl_up(p.fwd, 1); p1.bad = __shfl_up(p.bad, 1); p1.nl = 0;
+    p2.fwd = __shfl_up(p.fwd, 2); p2.bad = __shfl_up(p.bad, 2); p2.nl = 0;
+    return assemble_window<K30>(sv, g, lane < kHaloLanes, p, p1, p2, k);
+}
+
+/* Same, with the lane's 16 bytes already fetched by load16_raw (software prefetch). */
+template <bool K30>
+__device__ __forceinline__ Window make_window_from(const SeqView &sv, uint64_t tile0, int lane, uint32_t k, uint4 bytes)
+{
+    const int64_t g = lane_offset(tile0, lane);
+    const Packed p = pack16(fix16(sv, g, bytes));
     Packed p1, p2;
     p1.fwd = __shfl_up(p.fwd, 1); p1.bad = __shfl_up(p.bad, 1); p1.nl = 0;
     p2.fwd = __shfl_up(p.fwd, 2); p2.bad = __shfl_up(p.bad, 2); p2.nl = 0;

@@ -58,7 +58,10 @@ extern "C" uint32_t qm2_abi_version(void) { return QM2_ABI_VERSION; }
 namespace {
 
 constexpr size_t kDevPad = 64;
-constexpr int    kLgS = 12;                /* finest bucket = 4096 table slots (48 KiB + halo of LDS) */
+#ifndef QM2_LG_S
+#define QM2_LG_S 12
+#endif
+constexpr int    kLgS = QM2_LG_S;          /* finest bucket = 2^kLgS table slots: 12 B of LDS per slot */
 constexpr int    kMaxLevels = 3;
 
 struct Slot {                               /* one pinned staging buffer */
@@ -255,9 +258,9 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
         mean /= (double)(1u << p.bits[l]);
         /* expected fill + a margin that covers the Poisson spread of uniform hashing;
          * skew beyond it goes to the spill list */
-        const double capd = mean * (l == 0 ? 1.10 : 1.20) + 8.0 * std::sqrt(mean + 1.0) + 64.0;
+        const double capd = mean * (l == 0 ? 1.12 : 1.22) + 8.0 * std::sqrt(mean + 1.0) + 128.0;
         if (capd > 4.0e9) return fail("qm2: batch too large for the partition plan");
-        p.cap[l] = (uint32_t)capd;
+        p.cap[l] = ((uint32_t)capd + 63u) & ~63u;          /* whole sectors; covers the run padding too */
         slots[l] = p.buckets[l] * (uint64_t)p.cap[l];
         mean = (double)p.cap[l];
     }
@@ -329,7 +332,7 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
     {
         SplitDst d = {p.buf[0], p.cursors + p.cursor_off[0], p.cap[0], p.spill, p.spill_count, p.spill_cap};
         const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
-        const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu);
+        const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * (kSplitThreads >= 1024 ? 1 : 2));
         if (time_begin(c, &t, QM2_K_SPLIT_TEXT)) return 1;
         if (c->k == 30)
             hipLaunchKernelGGL(split_text_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k, hmask,
@@ -343,7 +346,8 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
     /* deeper levels: buckets[l-1] -> buckets[l], ping-pong between the two buffers */
     for (int l = 1; l < p.levels; l++) {
         SplitDst d = {p.buf[l & 1], p.cursors + p.cursor_off[l], p.cap[l], p.spill, p.spill_count, p.spill_cap};
-        const uint32_t chunks = (p.cap[l - 1] + kSplitSlots - 1) / kSplitSlots;
+        /* ~4 chunks per workgroup so that the prefetch has something to hide behind */
+        const uint32_t chunks = std::max<uint32_t>(1u, ((p.cap[l - 1] + kSplitSlots - 1) / kSplitSlots + 3) / 4);
         if (time_begin(c, &t, QM2_K_SPLIT_KMER)) return 1;
         hipLaunchKernelGGL(split_kmer_kernel, dim3(chunks, (uint32_t)p.buckets[l - 1]), dim3(kSplitThreads), 0, s,
                            p.buf[(l - 1) & 1], p.cursors + p.cursor_off[l - 1], p.cap[l - 1], hmask, p.shift[l],

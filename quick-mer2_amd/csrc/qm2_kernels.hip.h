@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const uint64_t *kmers, ui
         for (int j = 0; j < kNJ; j++) {
             const uint64_t at = grp * per_wave + (uint64_t)j * kWave + lane;
             km[j] = 0; idx[j] = 0; slot[j] = 0;
-            if (at < n) {
+            if (at < n && kmers[at] != ~0ull) {          /* ~0 = padding of the partitioned pipeline's spill */
                 km[j] = kmers[at];
                 const uint32_t home = djb32(km[j]) & tv.hmask;
                 pending |= 1u << j;

@@ -26,14 +26,38 @@
 
 namespace qm2 {
 
-constexpr int kSplitThreads  = 1024;                 /* 16 waves, one workgroup per CU          */
+#ifndef QM2_SPLIT_THREADS
+#define QM2_SPLIT_THREADS 1024
+#endif
+#ifndef QM2_COUNT_THREADS
+#define QM2_COUNT_THREADS 512
+#endif
+constexpr int kSplitThreads  = QM2_SPLIT_THREADS;    /* 1024: long runs per child beat occupancy (measured) */
 constexpr int kSplitWaves    = kSplitThreads / kWave;
-constexpr int kSplitSlots    = kSplitThreads * 16;   /* k-mers staged in LDS per chunk (128 KiB) */
+constexpr int kSplitSlots    = kSplitThreads * 16;   /* k-mers staged in LDS per chunk          */
 constexpr int kSplitTextBytes = kSplitWaves * kTileBytes;   /* 15872 sequence bytes per chunk   */
 constexpr int kMaxFan        = 256;                  /* children per split                      */
+#ifndef QM2_RUN_ALIGN
+#define QM2_RUN_ALIGN 1
+#endif
+constexpr int kRunAlign      = QM2_RUN_ALIGN;        /* 8 would pad every run a workgroup appends to a
+                                                        child to whole 64-byte sectors (slack = kPad);
+                                                        measured on MI355X: no gain (18.6 vs 18.8 ms per
+                                                        C2 step), so runs are left unpadded            */
+constexpr uint64_t kPad      = ~0ull;                /* never a k-mer (k <= 31 uses at most 62 bits)   */
 constexpr int kHalo          = 256;                  /* table slots staged past a bucket's
                                                         middle-facing edge                      */
-constexpr int kCountThreads  = 512;
+constexpr int kCountThreads  = QM2_COUNT_THREADS;
+
+/* Workgroup barrier for LDS hand-offs.  hipcc's __syncthreads() also drains every outstanding
+ * global load / store / atomic of the wave (s_waitcnt vmcnt(0)); these kernels keep a prefetch,
+ * a cursor reservation and the previous chunk's copy-out stores in flight ACROSS their
+ * barriers, so only the LDS traffic is waited for here.  (The compiler still inserts the vmcnt
+ * wait in front of the first use of each loaded value.) */
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 struct SplitDst {
     uint64_t           *kmers;      /* child c occupies [c*cap, (c+1)*cap)                      */
@@ -45,9 +69,9 @@ struct SplitDst {
 };
 
 struct SplitLds {
-    uint64_t sorted[kSplitSlots];
+    alignas(16) uint64_t sorted[kSplitSlots + kMaxFan * (kRunAlign - 1)];
     uint32_t hist[kMaxFan];
-    uint32_t off[kMaxFan];          /* exclusive prefix of hist                                  */
+    uint32_t off[kMaxFan];          /* exclusive prefix of the PADDED run lengths                */
     uint32_t gbase[kMaxFan];        /* reserved start in the child's region                      */
     uint32_t fit[kMaxFan];          /* how many of this chunk's k-mers fit the child             */
     unsigned long long sbase[kMaxFan];   /* reserved start in the spill list for the rest        */
@@ -63,11 +87,13 @@ __device__ __forceinline__ void split_commit(SplitLds &L, const uint64_t (&km)[1
                                              unsigned long long &lost)
 {
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    __syncthreads();                                           /* hist complete */
+    lds_barrier();                                           /* hist complete */
     /* exclusive scan of hist[0..fan) by the first fan threads (fan <= 256 = 4 waves) */
     uint32_t mine = 0, incl = 0;
+    static_assert(kSplitThreads >= kMaxFan, "the scan uses one thread per child");
     if (tid < kMaxFan) {
         mine = tid < (int)fan ? L.hist[tid] : 0;
+        mine = (mine + kRunAlign - 1) & ~(uint32_t)(kRunAlign - 1);        /* padded run length */
         incl = mine;
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) {
@@ -76,46 +102,78 @@ __device__ __forceinline__ void split_commit(SplitLds &L, const uint64_t (&km)[1
         }
         if (lane == kWave - 1) L.wsum[wave] = incl;
     }
-    __syncthreads();
+    lds_barrier();
+    uint32_t g = 0;
+    const bool reserve = tid < (int)fan && mine != 0;
     if (tid < kMaxFan) {
         uint32_t before = 0;
         for (int w = 0; w < wave; w++) before += L.wsum[w];
         L.off[tid] = before + incl - mine;
-        if (tid < (int)fan && mine) {
-            const uint64_t child = child0 + (uint64_t)tid;
-            const uint32_t g = atomicAdd(&d.cursors[child], mine);
-            const uint32_t f = g >= d.cap ? 0u : (d.cap - g < mine ? d.cap - g : mine);
-            L.gbase[tid] = g;
-            L.fit[tid] = f;
-            if (f < mine) L.sbase[tid] = atomicAdd(d.spill_count, (unsigned long long)(mine - f));
+        if (reserve) {
+            /* reserve the run in the child's region; the returned offset is only needed for the
+             * copy-out, so the round trip overlaps the LDS scatter below */
+            g = atomicAdd(&d.cursors[child0 + (uint64_t)tid], mine);
+            const uint32_t real = L.hist[tid];                 /* pad the tail of the run (kRunAlign > 1) */
+            for (uint32_t i = real; i < mine; i++) L.sorted[before + incl - mine + i] = kPad;
         }
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int j = 0; j < 16; j++)
         if (tag[j] != 0xFFFFFFFFu) L.sorted[L.off[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = km[j];
-    __syncthreads();
-    /* run copy: wave w takes children w, w+16, ... */
-    for (uint32_t b = wave; b < fan; b += kSplitWaves) {
-        const uint32_t n = L.hist[b];
+    if (reserve) {
+        const uint32_t f = g >= d.cap ? 0u : (d.cap - g < mine ? d.cap - g : mine);
+        L.gbase[tid] = g;
+        L.fit[tid] = f;                                        /* cap is a multiple of kRunAlign, so is f */
+        if (f < mine) L.sbase[tid] = atomicAdd(d.spill_count, (unsigned long long)(mine - f));
+    }
+    lds_barrier();
+    /* run copy: wave w takes children w, w + nwaves, ...  Their run descriptors are fetched
+     * once, one per lane, and broadcast with shuffles, so the loop below has no dependent LDS
+     * look-ups in front of its copies. */
+    static_assert(kMaxFan <= kSplitWaves * kWave, "one descriptor per lane");
+    uint32_t m_n = 0, m_o = 0, m_f = 0, m_g = 0;
+    {
+        const uint32_t mb = wave + lane * kSplitWaves;
+        if (mb < fan) {
+            m_n = L.hist[mb];
+            if (m_n) { m_o = L.off[mb]; m_f = L.fit[mb]; m_g = L.gbase[mb]; }
+            m_n = (m_n + kRunAlign - 1) & ~(uint32_t)(kRunAlign - 1);
+        }
+    }
+    const uint32_t per_wave = (fan + kSplitWaves - 1) / kSplitWaves;
+    for (uint32_t it = 0; it < per_wave; it++) {
+        const uint32_t n = __shfl(m_n, it);
         if (n == 0) continue;
-        const uint32_t o = L.off[b], f = L.fit[b];
-        uint64_t *dst = d.kmers + (child0 + b) * (uint64_t)d.cap + L.gbase[b];
-        for (uint32_t i = lane; i < f; i += kWave) dst[i] = L.sorted[o + i];
-        if (f < n) {
+        const uint32_t b = wave + it * kSplitWaves;
+        const uint32_t o = __shfl(m_o, it), f = __shfl(m_f, it), gb = __shfl(m_g, it);
+        uint64_t *dst = d.kmers + (child0 + b) * (uint64_t)d.cap + gb;
+        if constexpr (kRunAlign >= 2) {   /* f, o and dst are multiples of kRunAlign: 16-byte lanes */
+            for (uint32_t i = 2 * lane; i < f; i += 2 * kWave)
+                *reinterpret_cast<ulonglong2 *>(dst + i) = *reinterpret_cast<const ulonglong2 *>(&L.sorted[o + i]);
+        } else {
+            for (uint32_t i = lane; i < f; i += kWave) dst[i] = L.sorted[o + i];
+        }
+        if (f < n) {                                           /* the child is full: spill the rest */
             const unsigned long long sb = L.sbase[b];
             for (uint32_t i = f + lane; i < n; i += kWave) {
+                const uint64_t v = L.sorted[o + i];
                 const unsigned long long at = sb + (i - f);
-                if (at < d.spill_cap) d.spill[at] = L.sorted[o + i];
-                else lost++;
+                if (at < d.spill_cap) d.spill[at] = v;         /* (pads spill too; consumers skip them) */
+                else if (v != kPad) lost++;
             }
         }
     }
-    __syncthreads();                                           /* LDS reusable */
+    lds_barrier();                                           /* LDS reusable */
 }
 
 /* Level 1: sequence text -> canonical k-mers -> 2^b1 buckets by the top bits of
  * the home slot.  One chunk = 16 tiles (one per wave). */
+#if defined(QM2_ABL) && QM2_ABL >= 2
+#define QM2_RANK(b) (b)
+#else
+#define QM2_RANK(b) atomicAdd(&L.hist[b], 1u)
+#endif
 template <bool K30>
 __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, uint32_t k, uint32_t hmask,
                                                                    uint32_t shift, uint32_t fan,
@@ -124,11 +182,15 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
     __shared__ SplitLds L;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     unsigned long long n_bases = 0, n_kmers = 0, lost = 0;
+    /* the 16 bytes of this lane for the NEXT chunk are fetched while the current one is processed */
+    uint4 bytes = load16_raw(sv, lane_offset(((uint64_t)blockIdx.x * kSplitWaves + wave) * kTileBytes, lane));
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         if (tid < kMaxFan) L.hist[tid] = 0;
-        __syncthreads();
+        lds_barrier();
         const uint64_t tile = chunk * kSplitWaves + wave;
-        const Window W = make_window<K30>(sv, tile * kTileBytes, lane, k);
+        const uint4 cur = bytes;
+        bytes = load16_raw(sv, lane_offset(((chunk + gridDim.x) * kSplitWaves + wave) * kTileBytes, lane));
+        const Window W = make_window_from<K30>(sv, tile * kTileBytes, lane, k, cur);
         n_bases += W.n_bases;
         n_kmers += __builtin_popcount(W.emit);
         uint64_t km[16];
@@ -139,13 +201,22 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
             tag[J] = 0xFFFFFFFFu;                                                  \
             if (W.emit & (0x8000u >> J)) {                                         \
                 const uint32_t b = fan > 1 ? (djb32(km[J]) & hmask) >> shift : 0u; \
-                tag[J] = (b << 16) | atomicAdd(&L.hist[b], 1u);                    \
+                tag[J] = (b << 16) | QM2_RANK(b);                                  \
             }                                                                      \
         }
         QM2_T(0) QM2_T(1) QM2_T(2) QM2_T(3) QM2_T(4) QM2_T(5) QM2_T(6) QM2_T(7)
         QM2_T(8) QM2_T(9) QM2_T(10) QM2_T(11) QM2_T(12) QM2_T(13) QM2_T(14) QM2_T(15)
 #undef QM2_T
+#ifdef QM2_ABL   /* timing ablations only (results are wrong): 1 = no commit, 2 = also no LDS rank atomics */
+        {
+            uint64_t x = 0; uint32_t y = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { x ^= km[j]; y ^= tag[j]; }
+            asm volatile("" :: "v"(x), "v"(y));
+        }
+#else
         split_commit(L, km, tag, 0, fan, d, lost);
+#endif
     }
     n_bases = wave_sum(n_bases); n_kmers = wave_sum(n_kmers); lost = wave_sum(lost);
     if (lane == 0) {
@@ -165,27 +236,39 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
     const uint64_t parent = blockIdx.y;
     uint32_t n = src_cursors[parent];
     if (n > src_cap) n = src_cap;
-    const uint64_t first = (uint64_t)blockIdx.x * kSplitSlots;
-    if (first >= n) return;                                    /* whole workgroup leaves together */
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     unsigned long long lost = 0;
-    if (tid < kMaxFan) L.hist[tid] = 0;
-    __syncthreads();
     const uint64_t *in = src + parent * (uint64_t)src_cap;
-    uint64_t km[16];
-    uint32_t tag[16];
+    /* workgroup x of this parent takes chunks x, x + gridDim.x, ...; the next chunk's k-mers are
+     * loaded while the current one is sorted and copied out */
+    uint64_t nxt[16];
+    {
+        const uint64_t first = (uint64_t)blockIdx.x * kSplitSlots;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint64_t at = first + (uint64_t)j * kSplitThreads + tid;
-        km[j] = 0;
-        tag[j] = 0xFFFFFFFFu;
-        if (at < n) {
-            km[j] = in[at];
-            const uint32_t b = ((djb32(km[j]) & hmask) >> shift) & (fan - 1);
-            tag[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
+        for (int j = 0; j < 16; j++) {
+            const uint64_t at = first + (uint64_t)j * kSplitThreads + tid;
+            nxt[j] = at < n ? in[at] : kPad;
         }
     }
-    split_commit(L, km, tag, parent * fan, fan, d, lost);
+    for (uint64_t first = (uint64_t)blockIdx.x * kSplitSlots; first < n; first += (uint64_t)gridDim.x * kSplitSlots) {
+        if (tid < kMaxFan) L.hist[tid] = 0;
+        lds_barrier();
+        uint64_t km[16];
+        uint32_t tag[16];
+        const uint64_t ahead = first + (uint64_t)gridDim.x * kSplitSlots;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            km[j] = nxt[j];
+            const uint64_t at = ahead + (uint64_t)j * kSplitThreads + tid;
+            nxt[j] = at < n ? in[at] : kPad;
+            tag[j] = 0xFFFFFFFFu;
+            if (km[j] != kPad) {
+                const uint32_t b = ((djb32(km[j]) & hmask) >> shift) & (fan - 1);
+                tag[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
+            }
+        }
+        split_commit(L, km, tag, parent * fan, fan, d, lost);
+    }
     lost = wave_sum(lost);
     if (lane == 0 && lost) atomicAdd(&stats->part_lost, lost);
 }
@@ -203,70 +286,126 @@ __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(const uint6
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     unsigned long long n_probes = 0, n_hits = 0;
 
+    constexpr int kSteps = (S + kHalo + kCountThreads - 1) / kCountThreads;
+    constexpr int kGroup = 8;
+
+    /* geometry of bucket b: own range, staged slice (own + kHalo slots on the side its probe
+     * walks leave through, i.e. towards the middle of the table, :94-95), walk direction */
+    struct Geo { uint64_t own_lo, own_hi, seg_lo; uint32_t seg; bool down; };
+    auto geo = [&](uint32_t b) {
+        Geo g;
+        g.own_lo = (uint64_t)b << LG_S;
+        g.own_hi = g.own_lo + S < H ? g.own_lo + S : H;
+        g.down = (g.own_lo & (H >> 1)) != 0;                    /* upper half walks down */
+        uint64_t lo = g.own_lo, hi = g.own_hi;
+        if (H > (uint64_t)S) {
+            if (g.down) lo = g.own_lo >= (uint64_t)kHalo ? g.own_lo - kHalo : 0;
+            else        hi = g.own_hi + kHalo <= H ? g.own_hi + kHalo : H;
+        }
+        g.seg_lo = lo;
+        g.seg = (uint32_t)(hi - lo);
+        return g;
+    };
+    /* The table slice of the NEXT bucket is fetched into registers while the current one is
+     * probed, and the next group of k-mers while the current group is probed: the workgroup
+     * always has loads in flight. */
+    uint64_t kv[kSteps];
+    auto fetch_keys = [&](uint32_t b) {
+        if (b >= n_buckets) return;
+        const Geo g = geo(b);
+#pragma unroll
+        for (int st = 0; st < kSteps; st++) {
+            const uint32_t i = tid + st * kCountThreads;
+            kv[st] = i < g.seg ? tv.keys[g.seg_lo + i] : 0;
+        }
+    };
+    fetch_keys(blockIdx.x);
+
     for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
         uint32_t n = cursors[b];
         if (n > cap) n = cap;
-        if (n == 0) continue;                                  /* uniform for the workgroup */
-        /* the slice of the table this bucket can touch: its own S slots plus kHalo
-         * slots on the side its probe walks leave through (towards the middle, :94-95) */
-        const uint64_t own_lo = (uint64_t)b << LG_S;
-        uint64_t own_hi = own_lo + S;
-        if (own_hi > H) own_hi = H;
-        const bool down = (own_lo & (H >> 1)) != 0;            /* upper half walks down */
-        uint64_t seg_lo = own_lo, seg_hi = own_hi;
-        if (H > (uint64_t)S) {
-            if (down) seg_lo = own_lo >= (uint64_t)kHalo ? own_lo - kHalo : 0;
-            else      seg_hi = own_hi + kHalo <= H ? own_hi + kHalo : H;
+        const Geo g = geo(b);
+        const uint64_t own_lo = g.own_lo, own_hi = g.own_hi, seg_lo = g.seg_lo;
+        const uint32_t seg = g.seg;
+        const bool down = g.down;
+#pragma unroll
+        for (int st = 0; st < kSteps; st++) {
+            const uint32_t i = tid + st * kCountThreads;
+            if (i < seg) { skey[i] = kv[st]; scnt[i] = 0; }
         }
-        const uint32_t seg = (uint32_t)(seg_hi - seg_lo);
-        for (uint32_t i = tid; i < seg; i += kCountThreads) {
-            skey[i] = tv.keys[seg_lo + i];
-            scnt[i] = 0;
-        }
-        __syncthreads();
+        lds_barrier();
+        fetch_keys(b + gridDim.x);
         const uint64_t *in = kmers + (uint64_t)b * cap;
-        for (uint32_t i = tid; i < n; i += kCountThreads) {
-            const uint64_t km = in[i];
-            const uint32_t home = djb32(km) & tv.hmask;                    /* :92 */
-            /* H <= S: the single bucket holds both halves, direction per k-mer */
-            const bool dn = H > (uint64_t)S ? down : (home & tv.hhalf) != 0;
-            int32_t at = (int32_t)((uint64_t)home - seg_lo);
-            uint32_t seen = 0;
-            for (;;) {
-                if (at < 0 || at >= (int32_t)seg) {
-                    /* the walk left the staged slice (a run of occupied slots longer than
-                     * kHalo): finish it in global memory, like the direct kernel */
-                    uint64_t slot = seg_lo + (int64_t)at;
-                    for (;;) {
-                        const uint64_t g = tv.keys[slot];
-                        seen++;
-                        if (g == km) { atomicAdd(&tv.counters[slot], 1u); n_hits++; break; }
-                        if (g == 0) break;
-                        slot += dn ? (uint64_t)-1 : 1;
-                    }
-                    break;
-                }
-                const uint64_t v = skey[at];
-                seen++;
-                if (v == km) { atomicAdd(&scnt[at], 1u); n_hits++; break; }   /* :98, :291 */
-                if (v == 0) break;
-                at += dn ? -1 : 1;                                         /* :97 */
+        uint64_t nq[kGroup];
+#pragma unroll
+        for (int q = 0; q < kGroup; q++) {
+            const uint32_t i = q * kCountThreads + tid;
+            nq[q] = i < n ? in[i] : kPad;
+        }
+        for (uint32_t base = 0; base < n; base += kGroup * kCountThreads) {
+            uint64_t kq[kGroup];
+#pragma unroll
+            for (int q = 0; q < kGroup; q++) {
+                kq[q] = nq[q];
+                const uint32_t i = base + (kGroup + q) * kCountThreads + tid;
+                nq[q] = i < n ? in[i] : kPad;
             }
-            n_probes += seen;
+#pragma unroll
+            for (int q = 0; q < kGroup; q++) {
+                const uint64_t km = kq[q];
+                if (km == kPad) continue;
+                const uint32_t home = djb32(km) & tv.hmask;                    /* :92 */
+                /* H <= S: the single bucket holds both halves, direction per k-mer */
+                const bool dn = H > (uint64_t)S ? down : (home & tv.hhalf) != 0;
+                int32_t at = (int32_t)((uint64_t)home - seg_lo);
+                uint32_t seen = 0;
+                for (;;) {
+                    if (at < 0 || at >= (int32_t)seg) {
+                        /* the walk left the staged slice (a run of occupied slots longer than
+                         * kHalo): finish it in global memory, like the direct kernel */
+                        uint64_t slot = seg_lo + (int64_t)at;
+                        for (;;) {
+                            const uint64_t gk = tv.keys[slot];
+                            seen++;
+                            if (gk == km) { atomicAdd(&tv.counters[slot], 1u); n_hits++; break; }
+                            if (gk == 0) break;
+                            slot += dn ? (uint64_t)-1 : 1;
+                        }
+                        break;
+                    }
+                    const uint64_t v = skey[at];
+                    seen++;
+                    if (v == km) { atomicAdd(&scnt[at], 1u); n_hits++; break; }   /* :98, :291 */
+                    if (v == 0) break;
+                    at += dn ? -1 : 1;                                         /* :97 */
+                }
+                n_probes += seen;
+            }
         }
-        __syncthreads();
-        /* flush: the interior of the owned range is touched by this workgroup only
-         * (plain add); the kHalo slots at either end of it and the staged halo can
-         * also receive a neighbour's counts (atomic add). */
-        for (uint32_t i = tid; i < seg; i += kCountThreads) {
-            const uint32_t c = scnt[i];
-            if (c == 0) continue;
-            const uint64_t slot = seg_lo + i;
-            const bool interior = slot >= own_lo + kHalo && slot + kHalo < own_hi;
-            uint32_t *p = tv.counters + (slot - tv.span_lo);
-            if (interior) *p += c; else atomicAdd(p, c);
+        lds_barrier();
+        /* flush: the interior of the owned range is touched by this workgroup only (plain
+         * read-modify-write, all reads issued before the writes); the kHalo slots at either
+         * end of it and the staged halo can also receive a neighbour's counts (atomic add). */
+        if (n) {
+            uint32_t cv[kSteps], old[kSteps];
+#pragma unroll
+            for (int st = 0; st < kSteps; st++) {
+                const uint32_t i = tid + st * kCountThreads;
+                cv[st] = i < seg ? scnt[i] : 0;
+                old[st] = 0;
+                if (cv[st]) {
+                    const uint64_t slot = seg_lo + i;
+                    const bool interior = slot >= own_lo + kHalo && slot + kHalo < own_hi;
+                    uint32_t *p = tv.counters + (slot - tv.span_lo);
+                    if (interior) old[st] = *p;
+                    else { atomicAdd(p, cv[st]); cv[st] = 0; }
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < kSteps; st++)
+                if (cv[st]) tv.counters[seg_lo + tid + st * kCountThreads - tv.span_lo] = old[st] + cv[st];
         }
-        __syncthreads();
+        lds_barrier();
     }
     n_probes = wave_sum(n_probes); n_hits = wave_sum(n_hits);
     if (lane == 0) {

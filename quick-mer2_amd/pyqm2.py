@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libqm2_hip.so")
+LIB_PATH = os.environ.get("QM2_LIB", os.path.join(HERE, "libqm2_hip.so"))   # QM2_LIB: tuning variants only
 
 FLAG_TIMING = 0x1
 FLAG_NO_STATS = 0x2

@@ -52,7 +52,7 @@ uint64_t qm2e_extract(const char *buf, size_t n, uint32_t k, size_t staging_byte
     for (const Part &pt : parts) {
         const size_t staged = pt.carry + pt.take;
         /* a 16-byte aligned "device" buffer with `misalign` leading bytes and a poisoned tail */
-        std::vector<uint8_t> dev(staged + 64 + 32, 0xEE);
+        std::vector<uint8_t> dev(staged + 64 + 32, 0x41 /* poison that would count as a base */);
         uint8_t *aligned = (uint8_t *)(((uintptr_t)dev.data() + 15) & ~(uintptr_t)15);
         uint8_t *data = aligned + (misalign & 15);
         memcpy(data, buf + pt.off - pt.carry, staged);
