@@ -68,6 +68,9 @@ def genome_layout(n):
 
 
 def main():
+    # native libraries (RCCL prints a version banner) write to fd 1: keep stdout for the ONE JSON line
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -88,9 +91,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("QM2_FORCE_DIST") == "1"    # (1-rank rehearsal of the N>1 code path)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the count path has no CPU fallback")
@@ -133,7 +140,7 @@ def main():
                         ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr())
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def step(i):
@@ -152,14 +159,14 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     ctx.sync()
-    if world > 1:
+    if use_dist:
         dist.all_reduce(counters)          # the replicas' one exchange: RCCL sum of u32 counters
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
 
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -169,7 +176,7 @@ def main():
     d = {a: st1[a] - st0[a] for a in st1}
     bases_rank = d["n_bases"]
     total_bases = bases_rank
-    if world > 1:
+    if use_dist:
         tb = torch.tensor([bases_rank], dtype=torch.int64, device=dev)
         dist.all_reduce(tb)
         total_bases = int(tb.item())
@@ -200,8 +207,7 @@ def main():
     if os.path.exists(tr_file):
         try:
             tj = json.load(open(tr_file))
-            if tj.get("kernel_class") == dom:
-                traffic = tj.get("hbm_bytes_per_launch")
+            traffic = tj.get("per_kernel", {}).get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     pipe_gbs = b_survey / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -273,9 +279,10 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
