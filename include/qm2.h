@@ -186,6 +186,23 @@ int qm2_encode_device(qm2_ctx *c, const void *d_seq_bytes, size_t n,
 int qm2_probe_device(qm2_ctx *c, const uint64_t *d_kmers, uint64_t n,
                      const uint64_t *d_n);
 
+/* ---- epilogue on the device -------------------------------- *
+ * QuicKmer.c:494-516 walks the genome-order chain (uint32 next[H], cyclic from
+ * first_idx) one dependent load at a time: ~0.45 us per dictionary k-mer, ~15
+ * minutes for hg38, long after the counting itself has become seconds.  Here the
+ * walk is a parallel list ranking: every slot whose index is a multiple of R (and
+ * first_idx) is a splitter; one thread per splitter walks to the next splitter and
+ * records the length; the short list of splitters is ranked on the host; a second
+ * walk writes counters[slot] (truncated to uint16) at its rank.
+ *
+ * qm2_chain_gather uploads `chain` (H entries, the .qm at offset 24 + 8H,
+ * QuicKmer.c:483) and leaves the result on the device; qm2_chain_fetch copies a
+ * window of it out (so a caller can stream <Out_prefix>.bin in pieces).  As in
+ * the reference (:483, :490) the chain overwrites the context's key table when the
+ * context owns it: after qm2_chain_gather the context cannot count any more. */
+int qm2_chain_gather(qm2_ctx *c, const uint32_t *chain, uint64_t first_idx, uint64_t *n_out);
+int qm2_chain_fetch(qm2_ctx *c, uint16_t *out, uint64_t offset, uint64_t count);
+
 /* Pure host helper (no device needed): the slot range shard g of n_shards
  * OWNS, [*own_lo, *own_hi) = [g*H/G, (g+1)*H/G), and the range it must hold,
  * [*span_lo, *span_hi): the owned range extended on its middle-facing side

@@ -56,30 +56,27 @@ int qm2_main_count(int argc, char **argv)
         qm2_dict_close(&d);
         return 1;
     }
-    uint16_t *depth = calloc(d.hash_size, sizeof(uint16_t));  /* :360 */
-    if (!depth) { puts("Memory allocation failed"); qm2_dict_close(&d); return 1; }
-
+    /* (the reference's Kmer_depth, :360, lives on the device: qm2_open allocates and zeroes it) */
     qm2_ctx *ctx = NULL;
     qm2_opts o;
     memset(&o, 0, sizeof o);
     o.struct_size = sizeof o;
     o.device = -1;
-    if (qm2_open(&ctx, d.keys, d.hash_size, d.k, &o)) { free(depth); qm2_dict_close(&d); return 1; }
+    if (qm2_open(&ctx, d.keys, d.hash_size, d.k, &o)) { qm2_dict_close(&d); return 1; }
 
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);                      /* :386-387 */
     int rc = qm2_stream_reads(reads, (size_t)64 << 20, submit_sink, ctx);
     qm2_stats st;
     memset(&st, 0, sizeof st);
-    if (!rc) rc = qm2_finish(ctx, depth, &st);                /* :458-479 */
+    if (!rc) rc = qm2_finish(ctx, NULL, &st);                 /* :458-479; counts stay on the device */
     clock_gettime(CLOCK_MONOTONIC, &t1);
-    qm2_close(ctx);
-    if (rc) { free(depth); qm2_dict_close(&d); return 1; }
+    if (rc) { qm2_close(ctx); qm2_dict_close(&d); return 1; }
     printf("Counting elapse %u sec, total %lu kmers\n",       /* :481 */
            (unsigned)(t1.tv_sec - t0.tv_sec), (unsigned long)st.n_kmers);
 
-    rc = qm2_write_outputs(&d, depth, ref_prefix, out_prefix);
-    free(depth);
+    rc = qm2_write_outputs(&d, ctx, ref_prefix, out_prefix);
+    qm2_close(ctx);
     qm2_dict_close(&d);
     if (rc) return 1;
     puts("Exit quicK-mer2 count");                            /* :543 */

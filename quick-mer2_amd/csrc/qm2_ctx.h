@@ -1,0 +1,105 @@
+/*
+ * qm2_ctx.h — the context structure shared by the translation units of
+ * libqm2_hip.so (qm2_hip.hip: counting; qm2_epilogue.hip: chain gather).
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/qm2.h"
+#include "qm2_device.hip.h"
+
+namespace qm2 {
+
+constexpr int kMaxLevels = 3;
+
+struct Slot {                               /* one pinned staging buffer */
+    char       *host = nullptr;
+    hipEvent_t  done = nullptr;             /* its H2D copy has finished */
+    bool        busy = false;
+};
+
+struct Batch {                              /* one device batch being filled by qm2_submit */
+    uint8_t    *dev = nullptr;
+    size_t      fill = 0;
+    size_t      carry = 0;                  /* leading bytes that only serve as look-back */
+    std::vector<uint64_t> wraps;            /* uint16-wrap positions, relative to dev[0]  */
+    uint64_t   *dev_wraps = nullptr;
+    size_t      wraps_cap = 0;
+    hipEvent_t  done = nullptr;             /* its kernels have finished */
+    bool        busy = false;
+};
+
+struct TimedLaunch {
+    hipEvent_t a, b;
+    int cls;
+    bool batch_end;
+};
+
+struct PartPlan {                           /* how a batch is radix-partitioned for this table */
+    int      levels = 0;
+    uint32_t bits[kMaxLevels] = {0, 0, 0};
+    uint32_t shift[kMaxLevels] = {0, 0, 0}; /* child id at level l = (home >> shift[l]) & (fan-1) */
+    uint64_t buckets[kMaxLevels] = {0, 0, 0};
+    /* sized for `reserved` payload bytes */
+    uint64_t reserved = 0;
+    uint32_t cap[kMaxLevels] = {0, 0, 0};
+    uint64_t *buf[2] = {nullptr, nullptr};
+    uint64_t  buf_slots[2] = {0, 0};
+    uint32_t *cursors = nullptr;            /* all levels, contiguous */
+    uint64_t  cursor_off[kMaxLevels] = {0, 0, 0};
+    uint64_t  n_cursors = 0;
+    uint64_t *spill = nullptr;
+    uint64_t  spill_cap = 0;
+    unsigned long long *spill_count = nullptr;
+};
+
+}  // namespace qm2
+
+struct qm2_ctx {
+    int         device = 0;
+    uint32_t    k = 30;
+    uint64_t    H = 0;
+    uint32_t    lgH = 0;
+    uint64_t    span_lo = 0, span_hi = 0;
+    uint32_t    flags = 0;
+    uint64_t   *keys = nullptr;
+    bool        own_keys = false;
+    bool        keys_consumed = false;      /* the chain was uploaded over the key table */
+    uint32_t   *counters = nullptr;
+    bool        own_counters = false;
+    uint16_t   *narrow = nullptr;           /* H x u16 scratch for qm2_finish */
+    qm2::DevStats *stats = nullptr;
+    hipStream_t stream = nullptr;           /* every kernel of this context runs here, in order */
+    bool        own_stream = false;
+    hipStream_t copy_stream = nullptr;      /* H2D staging copies */
+    std::vector<qm2::Slot> slots;
+    size_t      staging_bytes = 0;
+    uint32_t    next_slot = 0;
+    qm2::Batch  batch[2];
+    size_t      batch_bytes = 0;
+    int         cur = 0;
+    int         n_cu = 256;
+    std::vector<qm2::TimedLaunch> timed;
+    std::vector<qm2::TimedLaunch> pool;
+    qm2_profile prof;
+    qm2::PartPlan part;
+    /* epilogue (qm2_epilogue.hip) */
+    uint32_t   *chain = nullptr;            /* device copy of next[]; aliases keys when owned */
+    bool        own_chain = false;
+    uint16_t   *gathered = nullptr;         /* depth in chain order */
+    uint64_t    n_gathered = 0;
+};
+
+int qm2_fail(const char *fmt, ...);         /* sets qm2_last_error(), prints, returns 1 */
+void qm2_part_free(qm2::PartPlan &p);
+
+#define HIP_OK(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess)                                                     \
+            return qm2_fail("qm2: %s failed: %s", #call, hipGetErrorString(e_));  \
+    } while (0)

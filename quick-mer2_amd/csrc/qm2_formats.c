@@ -67,8 +67,7 @@ void qm2_dict_close(qm2_dict_file *d)
     d->keys = NULL;
 }
 
-int qm2_write_outputs(qm2_dict_file *d, const uint16_t *depth, const char *ref_prefix,
-                      const char *out_prefix)
+int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, const char *out_prefix)
 {
     const uint64_t H = d->hash_size;
     /* the key buffer is dead now: the chain is read over it (:483, :490) */
@@ -85,6 +84,14 @@ int qm2_write_outputs(qm2_dict_file *d, const uint16_t *depth, const char *ref_p
     memcpy(path + plen, ".qgc", 5);                          /* :484-486 */
     FILE *qgc = fopen(path, "rb");
     if (!qgc) printf("GC control file %s absent. Continue without GC correction!\n", path); /* :488 */
+
+    /* the walk of :494-516, as a parallel list ranking on the device */
+    uint64_t n_entries = 0;
+    if (qm2_chain_gather(ctx, chain, d->first_idx, &n_entries)) {
+        if (qgc) fclose(qgc);
+        free(path);
+        return 1;
+    }
 
     memcpy(path, out_prefix, olen);
     memcpy(path + olen, ".bin", 5);                          /* :342-344 */
@@ -103,32 +110,31 @@ int qm2_write_outputs(qm2_dict_file *d, const uint16_t *depth, const char *ref_p
     uint32_t cnt[401];
     memset(sum, 0, sizeof sum); memset(sumsq, 0, sizeof sumsq); memset(cnt, 0, sizeof cnt);
 
-    const uint32_t first = (uint32_t)d->first_idx;           /* :494 */
-    uint32_t at = first, fill = 0;
-    do {                                                     /* :498-516 */
-        const uint16_t v = depth[at];
-        out[fill] = v;
-        at = chain[at];
+    int rc = 0;
+    for (uint64_t at = 0; at < n_entries && !rc; at += QM2_FLUSH_ENTRIES) {      /* :498-516, 2^20 at a time */
+        const uint64_t m = n_entries - at < QM2_FLUSH_ENTRIES ? n_entries - at : QM2_FLUSH_ENTRIES;
+        if (qm2_chain_fetch(ctx, out, at, m)) { rc = 1; break; }
         if (qgc) {
-            if (fill == 0 && fread(gc, sizeof(uint16_t), QM2_FLUSH_ENTRIES, qgc) == 0) gc[0] = 0;
-            const uint16_t g = gc[fill];
-            if (g & 0x8000) {                                /* control-region k-mer (:504) */
-                const uint32_t b = g & 0x1FF;
-                if (b < 401) {
-                    sum[b] += v;
-                    cnt[b]++;
-                    sumsq[b] += (int)v * (int)v;
+            size_t g = fread(gc, sizeof(uint16_t), m, qgc);                      /* :502-503 */
+            if (g < m) memset(gc + g, 0, (m - g) * sizeof(uint16_t));
+            for (uint64_t i = 0; i < m; i++) {
+                const uint16_t gcv = gc[i];
+                if (gcv & 0x8000) {                          /* control-region k-mer (:504) */
+                    const uint32_t b = gcv & 0x1FF;
+                    if (b < 401) {
+                        const uint16_t v = out[i];
+                        sum[b] += v;
+                        cnt[b]++;
+                        sumsq[b] += (int)v * (int)v;
+                    }
                 }
             }
         }
-        if (++fill == QM2_FLUSH_ENTRIES) {
-            fwrite(out, sizeof(uint16_t), fill, bin);
-            fill = 0;
-        }
-    } while (at != first);
-    fwrite(out, sizeof(uint16_t), fill, bin);                /* :517 */
+        if (fwrite(out, sizeof(uint16_t), m, bin) != m) { puts("Write to .bin failed"); rc = 1; }   /* :512, :517 */
+    }
     fclose(bin);
     free(out); free(gc);
+    if (rc) { if (qgc) fclose(qgc); free(path); return 1; }
 
     if (qgc) {                                               /* :522-542 */
         fclose(qgc);

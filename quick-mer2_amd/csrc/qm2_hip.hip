@@ -21,7 +21,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../include/qm2.h"
+#include "qm2_ctx.h"
 #include "qm2_kernels.hip.h"
 #include "qm2_partition.hip.h"
 #include "qm2_plan.h"
@@ -32,7 +32,7 @@ using namespace qm2;
 
 static thread_local char g_err[512] = "";
 
-static int fail(const char *fmt, ...)
+int qm2_fail(const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -42,99 +42,18 @@ static int fail(const char *fmt, ...)
     fflush(stdout);
     return 1;
 }
-
-#define HIP_OK(call)                                                              \
-    do {                                                                          \
-        hipError_t e_ = (call);                                                   \
-        if (e_ != hipSuccess)                                                     \
-            return fail("qm2: %s failed: %s", #call, hipGetErrorString(e_));      \
-    } while (0)
+#define fail qm2_fail
 
 extern "C" const char *qm2_last_error(void) { return g_err; }
 extern "C" uint32_t qm2_abi_version(void) { return QM2_ABI_VERSION; }
 
-/* ---- context --------------------------------------------------------------- */
-
 namespace {
-
 constexpr size_t kDevPad = 64;
 #ifndef QM2_LG_S
 #define QM2_LG_S 12
 #endif
 constexpr int    kLgS = QM2_LG_S;          /* finest bucket = 2^kLgS table slots: 12 B of LDS per slot */
-constexpr int    kMaxLevels = 3;
-
-struct Slot {                               /* one pinned staging buffer */
-    char       *host = nullptr;
-    hipEvent_t  done = nullptr;             /* its H2D copy has finished */
-    bool        busy = false;
-};
-
-struct Batch {                              /* one device batch being filled by qm2_submit */
-    uint8_t    *dev = nullptr;
-    size_t      fill = 0;
-    size_t      carry = 0;                  /* leading bytes that only serve as look-back */
-    std::vector<uint64_t> wraps;            /* uint16-wrap positions, relative to dev[0]  */
-    uint64_t   *dev_wraps = nullptr;
-    size_t      wraps_cap = 0;
-    hipEvent_t  done = nullptr;             /* its kernels have finished */
-    bool        busy = false;
-};
-
-struct TimedLaunch {
-    hipEvent_t a, b;
-    int cls;
-    bool batch_end;
-};
-
-struct PartPlan {                           /* how a batch is radix-partitioned for this table */
-    int      levels = 0;
-    uint32_t bits[kMaxLevels] = {0, 0, 0};
-    uint32_t shift[kMaxLevels] = {0, 0, 0}; /* child id at level l = (home >> shift[l]) & (fan-1) */
-    uint64_t buckets[kMaxLevels] = {0, 0, 0};
-    /* sized for `reserved` payload bytes */
-    uint64_t reserved = 0;
-    uint32_t cap[kMaxLevels] = {0, 0, 0};
-    uint64_t *buf[2] = {nullptr, nullptr};
-    uint64_t  buf_slots[2] = {0, 0};
-    uint32_t *cursors = nullptr;            /* all levels, contiguous */
-    uint64_t  cursor_off[kMaxLevels] = {0, 0, 0};
-    uint64_t  n_cursors = 0;
-    uint64_t *spill = nullptr;
-    uint64_t  spill_cap = 0;
-    unsigned long long *spill_count = nullptr;
-};
-
 }  // namespace
-
-struct qm2_ctx {
-    int         device = 0;
-    uint32_t    k = 30;
-    uint64_t    H = 0;
-    uint32_t    lgH = 0;
-    uint64_t    span_lo = 0, span_hi = 0;
-    uint32_t    flags = 0;
-    uint64_t   *keys = nullptr;
-    bool        own_keys = false;
-    uint32_t   *counters = nullptr;
-    bool        own_counters = false;
-    uint16_t   *narrow = nullptr;           /* H x u16 scratch for qm2_finish */
-    DevStats   *stats = nullptr;
-    hipStream_t stream = nullptr;           /* every kernel of this context runs here, in order */
-    bool        own_stream = false;
-    hipStream_t copy_stream = nullptr;      /* H2D staging copies */
-    std::vector<Slot> slots;
-    size_t      staging_bytes = 0;
-    uint32_t    next_slot = 0;
-    Batch       batch[2];
-    size_t      batch_bytes = 0;
-    int         cur = 0;
-    int         n_cu = 256;
-    std::vector<TimedLaunch> timed;
-    std::vector<TimedLaunch> pool;
-    qm2_profile prof;
-    PartPlan    part;
-};
 
 static int use_device(qm2_ctx *c)
 {
@@ -231,7 +150,7 @@ static void part_init(qm2_ctx *c, int max_bits)
     }
 }
 
-static void part_free(PartPlan &p)
+void qm2_part_free(PartPlan &p)
 {
     for (int i = 0; i < 2; i++) { if (p.buf[i]) (void)hipFree(p.buf[i]); p.buf[i] = nullptr; p.buf_slots[i] = 0; }
     if (p.cursors) (void)hipFree(p.cursors);
@@ -251,7 +170,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     if (n <= p.reserved) return 0;
     HIP_OK(hipStreamSynchronize(c->stream));                          /* buffers may be in use */
     const uint64_t want = std::max<uint64_t>(n + n / 16, 1u << 20);   /* grow with some slack */
-    part_free(p);
+    qm2_part_free(p);
     double mean = (double)want;
     uint64_t slots[kMaxLevels] = {0, 0, 0};
     for (int l = 0; l < p.levels; l++) {
@@ -277,7 +196,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     if (e == hipSuccess) e = hipMalloc((void **)&p.spill_count, sizeof(unsigned long long));
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        part_free(p);
+        qm2_part_free(p);
         snprintf(g_err, sizeof g_err, "qm2: partition buffers for %llu bytes do not fit (%s)",
                  (unsigned long long)n, hipGetErrorString(e));
         return 1;
@@ -391,6 +310,8 @@ static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry,
                         uint64_t n_sup)
 {
     if (n == 0) return 0;
+    if (c->keys_consumed)
+        return fail("qm2: the key table was overwritten by qm2_chain_gather; this context cannot count any more");
     const SeqView sv = seq_view(data, n, carry, d_sup, n_sup);
     bool part = (c->flags & QM2_FLAG_PARTITION) != 0 || ((uint64_t)n >= c->H / 8 && n >= (1u << 20));
     if (c->flags & QM2_FLAG_DIRECT) part = false;
@@ -520,7 +441,9 @@ extern "C" void qm2_close(qm2_ctx *c)
     }
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto &t : c->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-    part_free(c->part);
+    qm2_part_free(c->part);
+    if (c->own_chain && c->chain) (void)hipFree(c->chain);
+    if (c->gathered) (void)hipFree(c->gathered);
     if (c->own_keys && c->keys) (void)hipFree(c->keys);
     if (c->own_counters && c->counters) (void)hipFree(c->counters);
     if (c->narrow) (void)hipFree(c->narrow);

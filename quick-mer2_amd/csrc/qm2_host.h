@@ -27,10 +27,12 @@ typedef struct {
 int  qm2_dict_open(const char *ref_prefix, qm2_dict_file *d);
 void qm2_dict_close(qm2_dict_file *d);
 
-/* Epilogue (:483-542): chain walk -> <out>.bin, optional .qgc stats -> <out>.txt.
- * Prints the reference's stdout lines. */
-int qm2_write_outputs(qm2_dict_file *d, const uint16_t *depth, const char *ref_prefix,
-                      const char *out_prefix);
+/* Epilogue (:483-542): counts in chain order -> <out>.bin, optional .qgc stats ->
+ * <out>.txt.  The chain walk itself (:494-516) runs on the device
+ * (qm2_chain_gather); this reads the chain from the .qm into the dead key buffer
+ * exactly as the reference does (:483, :490), hands it over, and streams the
+ * result out.  Prints the reference's stdout lines. */
+int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, const char *out_prefix);
 
 /* ---- input line discipline (:393-398, :451-455) ---------------------------- */
 typedef int (*qm2_lines_sink)(void *user, const char *lines, size_t n);

@@ -53,7 +53,8 @@ class Dup(C.Structure):
 # every symbol include/qm2.h and include/qm2_tools.h declare
 ABI_SYMBOLS = ["qm2_open", "qm2_submit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
-               "qm2_encode_device", "qm2_probe_device", "qm2_shard_span", "qm2_last_error",
+               "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch",
+               "qm2_shard_span", "qm2_last_error",
                "qm2_abi_version"]
 TOOL_SYMBOLS = ["qm2t_genome_generate", "qm2t_dict_build", "qm2t_reads_generate",
                 "qm2t_read_offsets", "qm2t_microbench"]
@@ -104,6 +105,10 @@ def lib():
     L.qm2_encode_device.argtypes = [vp, vp, C.c_size_t, vp, u64, vp, u64, u32, vp]
     L.qm2_probe_device.restype = C.c_int
     L.qm2_probe_device.argtypes = [vp, vp, u64, vp]
+    L.qm2_chain_gather.restype = C.c_int
+    L.qm2_chain_gather.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.qm2_chain_fetch.restype = C.c_int
+    L.qm2_chain_fetch.argtypes = [vp, vp, u64, u64]
     L.qm2_shard_span.restype = C.c_int
     L.qm2_shard_span.argtypes = [vp, u64, u32, u32] + [C.POINTER(u64)] * 4
     L.qm2_last_error.restype = C.c_char_p
@@ -188,6 +193,18 @@ class Counter:
 
     def reset(self):
         _check(lib().qm2_reset(self._h), "qm2_reset")
+
+    def chain_gather(self, chain, first_idx, window=None):
+        """Epilogue on the device: counts in genome (chain) order, = the .bin payload."""
+        chain = np.ascontiguousarray(chain, dtype=np.uint32)
+        n = C.c_uint64(0)
+        _check(lib().qm2_chain_gather(self._h, chain.ctypes.data, int(first_idx), C.byref(n)), "qm2_chain_gather")
+        out = np.empty(int(n.value), dtype=np.uint16)
+        step = window or max(1, len(out))
+        for a in range(0, len(out), step):
+            m = min(step, len(out) - a)
+            _check(lib().qm2_chain_fetch(self._h, out[a:].ctypes.data, a, m), "qm2_chain_fetch")
+        return out
 
     def profile(self):
         p = Profile()

@@ -340,6 +340,67 @@ def test_encode_then_probe_equals_fused(qm2, torch_cuda, tmp_path):
         assert np.array_equal(total.astype(np.uint16), exp_depth)
 
 
+# ---- 4b. epilogue on the device: chain walk as list ranking ------------
+
+def test_chain_gather_matches_reference_bin(qm2, tmp_path):
+    for setname, reads_name in (("mini", None), ("kat", "reads_fa"), ("kat", "polyA"), ("kat_k25", "reads_fa")):
+        qm = ol.load_qm(os.path.join(GOLD, setname, "ref.fa.qm"))
+        if setname == "mini":
+            fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+            lines = ol.strip_reads(rfq)
+            exp = open(os.path.join(GOLD, "mini", "reads.bin"), "rb").read()
+        else:
+            p = tmp_path / "r.fa"
+            p.write_bytes(synth.kat_cases(synth.kat_reference())[reads_name][1])
+            lines = ol.strip_reads(str(p))
+            exp = open(os.path.join(GOLD, setname, reads_name + ".bin"), "rb").read()
+        for window in (None, 1000):
+            with qm2.Counter(qm["keys"], k=qm["k"]) as c:
+                c.submit(lines)
+                out = c.chain_gather(qm["chain"], qm["first"], window=window)
+                with pytest.raises(qm2.Qm2Error):
+                    c.submit(lines)             # the key table is gone, as in the reference (:483):
+                    c.sync()                    # the staged batch cannot be launched any more
+            assert out.tobytes() == exp, (setname, reads_name)
+
+
+def test_chain_gather_large_random_cycle(qm2, torch_cuda):
+    """2^24-slot table, ~6 M keys chained in a random order; ext_keys (the table survives)."""
+    torch = torch_cuda
+    n, H, k = 6_000_000, 1 << 24, 30
+    genome = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    qm2.tools.genome_generate(genome.data_ptr(), n, seed=41)
+    keys = torch.zeros(H, dtype=torch.int64, device="cuda")
+    scratch = torch.zeros(H, dtype=torch.int64, device="cuda")
+    qm2.tools.dict_build(genome.data_ptr(), n, k, keys.data_ptr(), H, scratch.data_ptr())
+    del scratch
+    hk = keys.cpu().numpy().view(np.uint64)
+    occ = np.flatnonzero(hk).astype(np.uint32)
+    rng = np.random.default_rng(1)
+    order = occ[rng.permutation(len(occ))]
+    chain = np.zeros(H, dtype=np.uint32)
+    chain[order] = np.roll(order, -1)
+    reads = torch.zeros(300_000 * 151, dtype=torch.uint8, device="cuda")
+    qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, 300_000, 0, 150, 150, 5)
+    torch.cuda.synchronize()
+    for first in (int(order[0]), int(order[12345]), int(occ[occ % 64 == 0][3])):
+        with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr()) as c:
+            c.submit_device(reads.data_ptr(), reads.numel())
+            depth, st = c.finish()
+            out = c.chain_gather(chain, first)
+            c.submit_device(reads.data_ptr(), reads.numel())       # ext_keys: the table is still there
+            c.sync()
+        pos = int(np.flatnonzero(order == first)[0])
+        walk = np.roll(order, -pos)
+        assert len(out) == len(occ) and np.array_equal(out, depth[walk])
+    # a chain that never returns to the first index is reported, not looped on
+    bad = chain.copy()
+    bad[order[-1]] = order[5]
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr()) as c:
+        with pytest.raises(qm2.Qm2Error):
+            c.chain_gather(bad, int(order[0]))
+
+
 # ---- 5. device tooling ----------------------------------------------------------
 
 def test_tools_dictionary_is_valid_and_unique(qm2, torch_cuda):
