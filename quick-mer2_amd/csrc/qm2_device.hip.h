@@ -118,20 +118,28 @@ __host__ __device__ __forceinline__ uint32_t rc_word(uint32_t x)
 }
 
 /* Low 32 bits of DJBHash_encode (:66-76).  Only hash & (H-1) is ever used and
- * H <= 2^32, and h*33+b mod 2^32 needs only h mod 2^32. */
+ * H <= 2^32, and h*33+b mod 2^32 needs only h mod 2^32.  The recurrence is linear:
+ *   h = 5381*33^8 + S(b0..b3)*33^4 + S(b4..b7),   S(x0..x3) = x0*33^3 + x1*33^2 + x2*33 + x3 < 2^24.
+ * On the device S is two v_dot4_u32_u8 (the weights 35937, 1089, 33, 1 split into
+ * low and high bytes) and one shift-add; *33^4 is four v_lshl_add_u32: 11 full-rate
+ * instructions instead of the ~28 (with quarter-rate multiplies) hipcc makes of the loop. */
+__host__ __device__ __forceinline__ uint32_t djb_s4(uint32_t w)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* byte i of w times byte i of the weight word: 35937 = 140*256 + 97, 1089 = 4*256 + 65 */
+    const uint32_t lo = __builtin_amdgcn_udot4(w, 0x01214161u, 0u, false);
+    const uint32_t hi = __builtin_amdgcn_udot4(w, 0x0000048Cu, 0u, false);
+    return (hi << 8) + lo;
+#else
+    return (w & 0xFFu) * 35937u + ((w >> 8) & 0xFFu) * 1089u + ((w >> 16) & 0xFFu) * 33u + (w >> 24);
+#endif
+}
+
 __host__ __device__ __forceinline__ uint32_t djb32(uint64_t kmer)
 {
-    uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
-    uint32_t h = 5381u;
-    h = h * 33u + (lo & 0xFFu);
-    h = h * 33u + ((lo >> 8) & 0xFFu);
-    h = h * 33u + ((lo >> 16) & 0xFFu);
-    h = h * 33u + (lo >> 24);
-    h = h * 33u + (hi & 0xFFu);
-    h = h * 33u + ((hi >> 8) & 0xFFu);
-    h = h * 33u + ((hi >> 16) & 0xFFu);
-    h = h * 33u + (hi >> 24);
-    return h;
+    uint32_t x = djb_s4((uint32_t)kmer);
+    x = (x << 5) + x; x = (x << 5) + x; x = (x << 5) + x; x = (x << 5) + x;      /* * 33^4 */
+    return x + djb_s4((uint32_t)(kmer >> 32)) + 0x7BB34A05u;                     /* + 5381 * 33^8 mod 2^32 */
 }
 
 /* The 16 bytes of lane-slot `g` (byte offset from sv.base, a multiple of 16; may be negative
@@ -208,12 +216,22 @@ __host__ __device__ __forceinline__ Window assemble_window(const SeqView &sv, in
     }
     if (halo_lane) in_range = 0;                   /* halo lanes never emit      */
     W.n_bases = __builtin_popcount(in_range & ~p.nl);
-    /* emission: the last k characters hold no reset (run >= k, :418) */
-    uint32_t emit = 0;
-    const uint64_t kbits = (1ull << (K30 ? 30 : k)) - 1;
+    /* emission: the last k characters hold no reset (run >= k, :418).  smear = OR of the reset
+     * flags of the k positions ending at each position, by doubling (k <= 31). */
+    uint32_t emit;
+    {
+        const uint32_t kk = K30 ? 30u : k;
+        uint64_t sm = W.bad;                    /* width 1 */
+        uint32_t w = 1;
 #pragma unroll
-    for (int j = 0; j < 16; j++)
-        if (((W.bad >> (15 - j)) & kbits) == 0) emit |= 0x8000u >> j;
+        for (int step = 0; step < 5; step++) {
+            if (2 * w <= kk) { sm |= sm >> w; w *= 2; }
+        }
+        if (w < kk) sm |= sm >> (kk - w);       /* width kk: bit p = OR of bad[p .. p+kk-1] */
+        /* bit p of sm is set iff some reset lies in the kk positions ending at bit p
+         * (older bases sit in higher bits); own position j is bit 15-j */
+        emit = (uint32_t)(~sm) & 0xFFFFu;
+    }
     emit &= in_range;
     /* the reference's run counter is a uint16 (:402): in an N-free run the
      * windows ending at run positions 65536*m .. 65536*m + k-1 are dropped.

@@ -251,7 +251,7 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
     {
         SplitDst d = {p.buf[0], p.cursors + p.cursor_off[0], p.cap[0], p.spill, p.spill_count, p.spill_cap};
         const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
-        const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * (kSplitThreads >= 1024 ? 1 : 2));
+        const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * (kSplitSlots * 8 <= 72 * 1024 ? 2 : 1));
         if (time_begin(c, &t, QM2_K_SPLIT_TEXT)) return 1;
         if (c->k == 30)
             hipLaunchKernelGGL(split_text_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k, hmask,

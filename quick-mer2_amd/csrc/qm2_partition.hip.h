@@ -32,19 +32,16 @@ namespace qm2 {
 #ifndef QM2_COUNT_THREADS
 #define QM2_COUNT_THREADS 512
 #endif
-constexpr int kSplitThreads  = QM2_SPLIT_THREADS;    /* 1024: long runs per child beat occupancy (measured) */
+constexpr int kSplitThreads  = QM2_SPLIT_THREADS;    /* 1024 threads x 16 k-mers: long runs per child beat
+                                                        occupancy (512 x 16 and 1024 x 8, two workgroups
+                                                        per CU, measured 10-25 % slower)                 */
 constexpr int kSplitWaves    = kSplitThreads / kWave;
-constexpr int kSplitSlots    = kSplitThreads * 16;   /* k-mers staged in LDS per chunk          */
+constexpr int kKpt           = 16;                   /* k-mers per thread per chunk = one tile per wave  */
+constexpr int kSplitSlots    = kSplitThreads * kKpt; /* k-mers staged in LDS per chunk (128 KiB)         */
 constexpr int kSplitTextBytes = kSplitWaves * kTileBytes;   /* 15872 sequence bytes per chunk   */
 constexpr int kMaxFan        = 256;                  /* children per split                      */
-#ifndef QM2_RUN_ALIGN
-#define QM2_RUN_ALIGN 1
-#endif
-constexpr int kRunAlign      = QM2_RUN_ALIGN;        /* 8 would pad every run a workgroup appends to a
-                                                        child to whole 64-byte sectors (slack = kPad);
-                                                        measured on MI355X: no gain (18.6 vs 18.8 ms per
-                                                        C2 step), so runs are left unpadded            */
-constexpr uint64_t kPad      = ~0ull;                /* never a k-mer (k <= 31 uses at most 62 bits)   */
+constexpr uint64_t kPad      = ~0ull;                /* never a k-mer (k <= 31 uses at most 62 bits);
+                                                        fills unused input slots                         */
 constexpr int kHalo          = 256;                  /* table slots staged past a bucket's
                                                         middle-facing edge                      */
 constexpr int kCountThreads  = QM2_COUNT_THREADS;
@@ -69,31 +66,42 @@ struct SplitDst {
 };
 
 struct SplitLds {
-    alignas(16) uint64_t sorted[kSplitSlots + kMaxFan * (kRunAlign - 1)];
-    uint32_t hist[kMaxFan];
-    uint32_t off[kMaxFan];          /* exclusive prefix of the PADDED run lengths                */
-    uint32_t gbase[kMaxFan];        /* reserved start in the child's region                      */
-    uint32_t fit[kMaxFan];          /* how many of this chunk's k-mers fit the child             */
-    unsigned long long sbase[kMaxFan];   /* reserved start in the spill list for the rest        */
+    uint64_t sorted[kSplitSlots + 1];       /* the chunk sorted by child; last = trash slot          */
+    uint32_t hist[kMaxFan + 1];             /* [kMaxFan] = trash bin of the empty slots (keeps the
+                                               rank atomics and the scatter branch-free)             */
+    uint32_t off[kMaxFan];                  /* exclusive prefix of hist                              */
+    uint32_t gbase[kMaxFan];                /* reserved start in the child's region                  */
+    uint32_t fit[kMaxFan];                  /* how many of this chunk's k-mers fit the child         */
     uint32_t wsum[kMaxFan / kWave];
 };
 
-/* Steps 2-5 of a split chunk: every thread holds up to 16 k-mers km[j] with
- * tag[j] = (child << 16) | rank_in_child (rank from an LDS atomic on hist), or
- * 0xFFFFFFFF when slot j is empty.  Sorts the chunk by child in LDS and copies
- * each child's run to its region with full-wave contiguous stores. */
-__device__ __forceinline__ void split_commit(SplitLds &L, const uint64_t (&km)[16], const uint32_t (&tag)[16],
-                                             uint64_t child0, uint32_t fan, const SplitDst &d,
-                                             unsigned long long &lost)
+/* What a wave needs to copy out its share of a sorted chunk: lane l holds the run of child
+ * wave + l * kSplitWaves: its length, its start in L.sorted, how much of it fits the child,
+ * and where that goes.  Read back with v_readlane at compile-time lane indices, so the
+ * copy-out's control values live in scalar registers. */
+struct RunDesc {
+    uint32_t f, o;                  /* k-mers to copy, start in L.sorted */
+    uint32_t dst_lo, dst_hi;
+    bool live;
+};
+
+/* Sort one chunk by child in LDS.  Every thread holds kKpt k-mers km[j] with
+ * tag[j] = (child << 16) | rank_in_child (rank from an LDS atomic on hist); empty slots carry
+ * child id kMaxFan (trash bin).  On return L.sorted holds the chunk grouped by child and the
+ * wave's run descriptors are in registers; the copy-out (copy_piece) is left to the caller,
+ * which interleaves it with the NEXT chunk's compute so that the stores (HBM-bound, ~2 ms per
+ * 10 GB) drain behind VALU work instead of stalling every wave at once. */
+__device__ __forceinline__ RunDesc sort_chunk(SplitLds &L, const uint64_t (&km)[kKpt], const uint32_t (&tag)[kKpt],
+                                              uint64_t child0, uint32_t fan, const SplitDst &d,
+                                              unsigned long long &lost)
 {
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    lds_barrier();                                           /* hist complete */
-    /* exclusive scan of hist[0..fan) by the first fan threads (fan <= 256 = 4 waves) */
+    lds_barrier();                 /* hist complete; every wave is done reading the previous L.sorted */
+    /* exclusive scan of hist[0..fan) by the first kMaxFan threads (4 waves) */
     uint32_t mine = 0, incl = 0;
     static_assert(kSplitThreads >= kMaxFan, "the scan uses one thread per child");
     if (tid < kMaxFan) {
         mine = tid < (int)fan ? L.hist[tid] : 0;
-        mine = (mine + kRunAlign - 1) & ~(uint32_t)(kRunAlign - 1);        /* padded run length */
         incl = mine;
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) {
@@ -109,71 +117,77 @@ __device__ __forceinline__ void split_commit(SplitLds &L, const uint64_t (&km)[1
         uint32_t before = 0;
         for (int w = 0; w < wave; w++) before += L.wsum[w];
         L.off[tid] = before + incl - mine;
-        if (reserve) {
-            /* reserve the run in the child's region; the returned offset is only needed for the
-             * copy-out, so the round trip overlaps the LDS scatter below */
-            g = atomicAdd(&d.cursors[child0 + (uint64_t)tid], mine);
-            const uint32_t real = L.hist[tid];                 /* pad the tail of the run (kRunAlign > 1) */
-            for (uint32_t i = real; i < mine; i++) L.sorted[before + incl - mine + i] = kPad;
-        }
+        /* reserve the run in the child's region; the returned offset is only needed for the
+         * copy-out, so the round trip overlaps the LDS scatter below */
+        if (reserve) g = atomicAdd(&d.cursors[child0 + (uint64_t)tid], mine);
     }
     lds_barrier();
 #pragma unroll
-    for (int j = 0; j < 16; j++)
-        if (tag[j] != 0xFFFFFFFFu) L.sorted[L.off[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = km[j];
+    for (int j = 0; j < kKpt; j++) {
+        /* empty slots carry child id kMaxFan: they all land in the trash slot, no branch */
+        const uint32_t child = tag[j] >> 16;
+        const uint32_t pos = child >= kMaxFan ? (uint32_t)kSplitSlots : L.off[child & (kMaxFan - 1)] + (tag[j] & 0xFFFFu);
+        L.sorted[pos] = km[j];
+    }
+    uint32_t f = mine;
     if (reserve) {
-        const uint32_t f = g >= d.cap ? 0u : (d.cap - g < mine ? d.cap - g : mine);
+        f = g >= d.cap ? 0u : (d.cap - g < mine ? d.cap - g : mine);
         L.gbase[tid] = g;
-        L.fit[tid] = f;                                        /* cap is a multiple of kRunAlign, so is f */
-        if (f < mine) L.sbase[tid] = atomicAdd(d.spill_count, (unsigned long long)(mine - f));
+        L.fit[tid] = f;
     }
     lds_barrier();
-    /* run copy: wave w takes children w, w + nwaves, ...  Their run descriptors are fetched
-     * once, one per lane, and broadcast with shuffles, so the loop below has no dependent LDS
-     * look-ups in front of its copies. */
+    if (reserve && f < mine) {
+        /* rare (skewed input): the child is full; this thread moves the rest of the run to the
+         * spill list, which the direct kernel probes at the end of the batch */
+        const unsigned long long sb = atomicAdd(d.spill_count, (unsigned long long)(mine - f));
+        const uint32_t o = L.off[tid];
+        for (uint32_t i = f; i < mine; i++) {
+            const unsigned long long at = sb + (i - f);
+            if (at < d.spill_cap) d.spill[at] = L.sorted[o + i];
+            else lost++;
+        }
+    }
     static_assert(kMaxFan <= kSplitWaves * kWave, "one descriptor per lane");
-    uint32_t m_n = 0, m_o = 0, m_f = 0, m_g = 0;
-    {
-        const uint32_t mb = wave + lane * kSplitWaves;
-        if (mb < fan) {
-            m_n = L.hist[mb];
-            if (m_n) { m_o = L.off[mb]; m_f = L.fit[mb]; m_g = L.gbase[mb]; }
-            m_n = (m_n + kRunAlign - 1) & ~(uint32_t)(kRunAlign - 1);
-        }
+    RunDesc r = {0, 0, 0, 0, true};
+    const uint32_t mb = wave + lane * kSplitWaves;
+    if (mb < fan && L.hist[mb]) {
+        r.f = L.fit[mb];
+        r.o = L.off[mb];
+        const uint64_t dst = (uint64_t)(d.kmers + (child0 + mb) * (uint64_t)d.cap + L.gbase[mb]);
+        r.dst_lo = (uint32_t)dst;
+        r.dst_hi = (uint32_t)(dst >> 32);
     }
-    const uint32_t per_wave = (fan + kSplitWaves - 1) / kSplitWaves;
-    for (uint32_t it = 0; it < per_wave; it++) {
-        const uint32_t n = __shfl(m_n, it);
-        if (n == 0) continue;
-        const uint32_t b = wave + it * kSplitWaves;
-        const uint32_t o = __shfl(m_o, it), f = __shfl(m_f, it), gb = __shfl(m_g, it);
-        uint64_t *dst = d.kmers + (child0 + b) * (uint64_t)d.cap + gb;
-        if constexpr (kRunAlign >= 2) {   /* f, o and dst are multiples of kRunAlign: 16-byte lanes */
-            for (uint32_t i = 2 * lane; i < f; i += 2 * kWave)
-                *reinterpret_cast<ulonglong2 *>(dst + i) = *reinterpret_cast<const ulonglong2 *>(&L.sorted[o + i]);
-        } else {
-            for (uint32_t i = lane; i < f; i += kWave) dst[i] = L.sorted[o + i];
-        }
-        if (f < n) {                                           /* the child is full: spill the rest */
-            const unsigned long long sb = L.sbase[b];
-            for (uint32_t i = f + lane; i < n; i += kWave) {
-                const uint64_t v = L.sorted[o + i];
-                const unsigned long long at = sb + (i - f);
-                if (at < d.spill_cap) d.spill[at] = v;         /* (pads spill too; consumers skip them) */
-                else if (v != kPad) lost++;
-            }
-        }
-    }
-    lds_barrier();                                           /* LDS reusable */
+    lds_barrier();                 /* descriptors are in registers: hist / off may be reused */
+    return r;
+}
+
+/* Copy-out of the run with descriptor index IT (child wave + IT * kSplitWaves): one
+ * full-wave contiguous store per 64 k-mers.  All 64 lanes must call. */
+template <int IT>
+__device__ __forceinline__ void copy_piece(const SplitLds &L, const RunDesc &r, const SplitDst &d)
+{
+    /* (the builtin returns int: go through uint32_t, or the low half sign-extends into the pointer) */
+    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)r.f, IT);
+    if (f == 0) return;                                        /* scalar branch */
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)r.o, IT);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)r.dst_lo, IT);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)r.dst_hi, IT);
+    uint64_t *dst = (uint64_t *)(((uint64_t)hi << 32) | (uint64_t)lo);
+    for (uint32_t i = lane; i < f; i += kWave) dst[i] = L.sorted[o + i];
+}
+
+/* all pieces of a sorted chunk (kernel epilogue) */
+__device__ __forceinline__ void copy_all(const SplitLds &L, const RunDesc &r, const SplitDst &d)
+{
+    copy_piece<0>(L, r, d);  copy_piece<1>(L, r, d);  copy_piece<2>(L, r, d);  copy_piece<3>(L, r, d);
+    copy_piece<4>(L, r, d);  copy_piece<5>(L, r, d);  copy_piece<6>(L, r, d);  copy_piece<7>(L, r, d);
+    copy_piece<8>(L, r, d);  copy_piece<9>(L, r, d);  copy_piece<10>(L, r, d); copy_piece<11>(L, r, d);
+    copy_piece<12>(L, r, d); copy_piece<13>(L, r, d); copy_piece<14>(L, r, d); copy_piece<15>(L, r, d);
 }
 
 /* Level 1: sequence text -> canonical k-mers -> 2^b1 buckets by the top bits of
  * the home slot.  One chunk = 16 tiles (one per wave). */
-#if defined(QM2_ABL) && QM2_ABL >= 2
-#define QM2_RANK(b) (b)
-#else
-#define QM2_RANK(b) atomicAdd(&L.hist[b], 1u)
-#endif
 template <bool K30>
 __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, uint32_t k, uint32_t hmask,
                                                                    uint32_t shift, uint32_t fan,
@@ -182,42 +196,35 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
     __shared__ SplitLds L;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     unsigned long long n_bases = 0, n_kmers = 0, lost = 0;
+    static_assert(kMaxFan <= 16 * kSplitWaves, "a wave copies at most 16 runs per chunk");
+    RunDesc pend = {0, 0, 0, 0, false};
     /* the 16 bytes of this lane for the NEXT chunk are fetched while the current one is processed */
     uint4 bytes = load16_raw(sv, lane_offset(((uint64_t)blockIdx.x * kSplitWaves + wave) * kTileBytes, lane));
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        if (tid < kMaxFan) L.hist[tid] = 0;
-        lds_barrier();
         const uint64_t tile = chunk * kSplitWaves + wave;
         const uint4 cur = bytes;
         bytes = load16_raw(sv, lane_offset(((chunk + gridDim.x) * kSplitWaves + wave) * kTileBytes, lane));
         const Window W = make_window_from<K30>(sv, tile * kTileBytes, lane, k, cur);
         n_bases += W.n_bases;
         n_kmers += __builtin_popcount(W.emit);
-        uint64_t km[16];
-        uint32_t tag[16];
+        if (tid <= kMaxFan) L.hist[tid] = 0;
+        lds_barrier();
+        uint64_t km[kKpt];
+        uint32_t tag[kKpt];
+        /* k-mer J of this chunk, then copy-out piece J of the previous chunk */
 #define QM2_T(J)                                                                   \
         {                                                                          \
             km[J] = kmer_at<K30, J>(W, k);                                         \
-            tag[J] = 0xFFFFFFFFu;                                                  \
-            if (W.emit & (0x8000u >> J)) {                                         \
-                const uint32_t b = fan > 1 ? (djb32(km[J]) & hmask) >> shift : 0u; \
-                tag[J] = (b << 16) | QM2_RANK(b);                                  \
-            }                                                                      \
+            const uint32_t b = (W.emit & (0x8000u >> J)) ? (djb32(km[J]) & hmask) >> shift : (uint32_t)kMaxFan; \
+            tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
+            if (pend.live) copy_piece<J>(L, pend, d);                              \
         }
         QM2_T(0) QM2_T(1) QM2_T(2) QM2_T(3) QM2_T(4) QM2_T(5) QM2_T(6) QM2_T(7)
         QM2_T(8) QM2_T(9) QM2_T(10) QM2_T(11) QM2_T(12) QM2_T(13) QM2_T(14) QM2_T(15)
 #undef QM2_T
-#ifdef QM2_ABL   /* timing ablations only (results are wrong): 1 = no commit, 2 = also no LDS rank atomics */
-        {
-            uint64_t x = 0; uint32_t y = 0;
-#pragma unroll
-            for (int j = 0; j < 16; j++) { x ^= km[j]; y ^= tag[j]; }
-            asm volatile("" :: "v"(x), "v"(y));
-        }
-#else
-        split_commit(L, km, tag, 0, fan, d, lost);
-#endif
+        pend = sort_chunk(L, km, tag, 0, fan, d, lost);
     }
+    if (pend.live) copy_all(L, pend, d);
     n_bases = wave_sum(n_bases); n_kmers = wave_sum(n_kmers); lost = wave_sum(lost);
     if (lane == 0) {
         atomicAdd(&stats->n_bases, n_bases);
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
 }
 
 /* Level l >= 2: split every level l-1 bucket into 2^bl children.
- * grid.y = parent, grid.x = chunk of kSplitSlots k-mers inside the parent. */
+ * grid.y = parent; workgroup x of a parent takes its chunks x, x + gridDim.x, ... */
 __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_t *src, const uint32_t *src_cursors,
                                                                    uint32_t src_cap, uint32_t hmask, uint32_t shift,
                                                                    uint32_t fan, SplitDst d, DevStats *stats)
@@ -239,36 +246,38 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     unsigned long long lost = 0;
     const uint64_t *in = src + parent * (uint64_t)src_cap;
-    /* workgroup x of this parent takes chunks x, x + gridDim.x, ...; the next chunk's k-mers are
-     * loaded while the current one is sorted and copied out */
-    uint64_t nxt[16];
+    RunDesc pend = {0, 0, 0, 0, false};
+    /* the next chunk's k-mers are loaded while the current one is sorted and copied out */
+    uint64_t nxt[kKpt];
     {
         const uint64_t first = (uint64_t)blockIdx.x * kSplitSlots;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < kKpt; j++) {
             const uint64_t at = first + (uint64_t)j * kSplitThreads + tid;
             nxt[j] = at < n ? in[at] : kPad;
         }
     }
     for (uint64_t first = (uint64_t)blockIdx.x * kSplitSlots; first < n; first += (uint64_t)gridDim.x * kSplitSlots) {
-        if (tid < kMaxFan) L.hist[tid] = 0;
+        if (tid <= kMaxFan) L.hist[tid] = 0;
         lds_barrier();
-        uint64_t km[16];
-        uint32_t tag[16];
+        uint64_t km[kKpt];
+        uint32_t tag[kKpt];
         const uint64_t ahead = first + (uint64_t)gridDim.x * kSplitSlots;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            km[j] = nxt[j];
-            const uint64_t at = ahead + (uint64_t)j * kSplitThreads + tid;
-            nxt[j] = at < n ? in[at] : kPad;
-            tag[j] = 0xFFFFFFFFu;
-            if (km[j] != kPad) {
-                const uint32_t b = ((djb32(km[j]) & hmask) >> shift) & (fan - 1);
-                tag[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
-            }
+#define QM2_K(J)                                                                   \
+        {                                                                          \
+            km[J] = nxt[J];                                                        \
+            const uint64_t at = ahead + (uint64_t)(J) * kSplitThreads + tid;       \
+            nxt[J] = at < n ? in[at] : kPad;                                       \
+            const uint32_t b = km[J] != kPad ? ((djb32(km[J]) & hmask) >> shift) & (fan - 1) : (uint32_t)kMaxFan; \
+            tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
+            if (pend.live) copy_piece<J>(L, pend, d);                              \
         }
-        split_commit(L, km, tag, parent * fan, fan, d, lost);
+        QM2_K(0) QM2_K(1) QM2_K(2) QM2_K(3) QM2_K(4) QM2_K(5) QM2_K(6) QM2_K(7)
+        QM2_K(8) QM2_K(9) QM2_K(10) QM2_K(11) QM2_K(12) QM2_K(13) QM2_K(14) QM2_K(15)
+#undef QM2_K
+        pend = sort_chunk(L, km, tag, parent * fan, fan, d, lost);
     }
+    if (pend.live) copy_all(L, pend, d);
     lost = wave_sum(lost);
     if (lane == 0 && lost) atomicAdd(&stats->part_lost, lost);
 }
