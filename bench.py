@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WORKLOADS = {
     "c2": dict(genome=50_818_468, lgH=28, reads=10_000_000, len_lo=150, len_hi=150, sub=0.005,
                desc="chr22-like 50.8 Mb synthetic reference, k=30, H=2^28; 10M x 150 bp reads per step"),
-    "c3": dict(genome=3_100_000_000, lgH=32, reads=10_000_000, len_lo=150, len_hi=150, sub=0.005,
-               desc="hg38-like 3.1 Gb synthetic reference, k=30, H=2^32; 10M x 150 bp reads per step"),
+    "c3": dict(genome=3_100_000_000, lgH=32, reads=20_000_000, len_lo=150, len_hi=150, sub=0.005,
+               desc="hg38-like 3.1 Gb synthetic reference, k=30, H=2^32; 20M x 150 bp reads per step"),
     "c5": dict(genome=3_100_000_000, lgH=32, reads=80_000, len_lo=15_000, len_hi=20_000, sub=0.001,
                desc="hg38-like dictionary (H=2^32), HiFi-like reads U(15k,20k) bp, 80k reads per step"),
     "tiny": dict(genome=2_000_000, lgH=22, reads=200_000, len_lo=150, len_hi=150, sub=0.005,
@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=6, help="probe workers (reference recommends 6)")
+    ap.add_argument("--reads-per-step", type=int, default=0, help="override the workload's reads per step")
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "partition"],
                     help="count pipeline: auto = chosen per batch from its size vs. H")
     args = ap.parse_args()
@@ -103,7 +104,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the count path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.reads_per_step:
+        wl["reads"] = args.reads_per_step
+        import re as _re
+        wl["desc"] = _re.sub(r"\d+M x", "%.0fM x" % (args.reads_per_step / 1e6), wl["desc"])
     k, H, n = 30, 1 << wl["lgH"], wl["genome"]
 
     # ---- untimed set-up: reference, dictionary, read batches, all made on the device -------

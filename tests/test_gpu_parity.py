@@ -340,6 +340,36 @@ def test_encode_then_probe_equals_fused(qm2, torch_cuda, tmp_path):
         assert np.array_equal(total.astype(np.uint16), exp_depth)
 
 
+def test_multi_drivers_on_the_gpu_single_rank(qm2, torch_cuda, tmp_path):
+    """quick-mer2_amd/multi.py with the real HipEngine and the RCCL backend (world size 1 is all a
+    one-GPU box allows; ranks > 1 run under gloo in tests/test_multi_gloo.py): init, all_reduce,
+    all_to_all_single of ragged k-mer slabs, overhang fold and assembly all execute on the device."""
+    torch = torch_cuda
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    ge.load_package()
+    from quick_mer2_amd import multi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29577"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+        fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+        lines = ol.strip_reads(rfa)
+        exp, _ = ol.count_lines(qm["keys"], qm["k"], lines)
+        eng = multi.HipEngine(torch, torch.device("cuda", 0))
+        for job in (multi.ReplicaJob(dist, eng, qm["keys"], qm["k"]),
+                    multi.ShardedJob(dist, eng, qm["keys"], qm["k"], torch)):
+            half = lines.rfind(b"\n", 0, len(lines) // 2) + 1
+            job.count(lines[:half])
+            job.count(lines[half:])
+            got = job.finish()
+            job.close()
+            assert np.array_equal(got, exp), type(job).__name__
+    finally:
+        dist.destroy_process_group()
+
+
 # ---- 4b. epilogue on the device: chain walk as list ranking (SURVEY 8(f) f1) ------------
 
 def test_chain_gather_matches_reference_bin(qm2, tmp_path):
