@@ -49,8 +49,14 @@ int qm2_main_count(int argc, char **argv)
     (void)thread_count;  /* -t is accepted for command-line compatibility: the
                             probing workers it sized (:372-384) are GPU waves now */
 
+    const int timing = getenv("QM2_TIMING") != NULL;   /* extra phase lines; off by default so that
+                                                          stdout stays the reference's */
+    struct timespec ta, tb;
+    clock_gettime(CLOCK_MONOTONIC, &ta);
     qm2_dict_file d;
     if (qm2_dict_open(ref_prefix, &d)) return 1;
+    clock_gettime(CLOCK_MONOTONIC, &tb);
+    if (timing) printf("QM2 phase load-dictionary %.3f s\n", (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec));
     if (d.k < 1 || d.k > 31) {
         printf("Dictionary k=%u is not supported (1..31)\n", d.k);
         qm2_dict_close(&d);
@@ -62,7 +68,10 @@ int qm2_main_count(int argc, char **argv)
     memset(&o, 0, sizeof o);
     o.struct_size = sizeof o;
     o.device = -1;
+    clock_gettime(CLOCK_MONOTONIC, &ta);
     if (qm2_open(&ctx, d.keys, d.hash_size, d.k, &o)) { qm2_dict_close(&d); return 1; }
+    clock_gettime(CLOCK_MONOTONIC, &tb);
+    if (timing) printf("QM2 phase upload-dictionary %.3f s\n", (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec));
 
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);                      /* :386-387 */
@@ -75,7 +84,12 @@ int qm2_main_count(int argc, char **argv)
     printf("Counting elapse %u sec, total %lu kmers\n",       /* :481 */
            (unsigned)(t1.tv_sec - t0.tv_sec), (unsigned long)st.n_kmers);
 
+    if (timing) printf("QM2 phase count %.3f s (%.2f G bases/s)\n", (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec),
+                       st.n_bases / ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / 1e9);
+    clock_gettime(CLOCK_MONOTONIC, &ta);
     rc = qm2_write_outputs(&d, ctx, ref_prefix, out_prefix);
+    clock_gettime(CLOCK_MONOTONIC, &tb);
+    if (timing) printf("QM2 phase epilogue %.3f s\n", (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec));
     qm2_close(ctx);
     qm2_dict_close(&d);
     if (rc) return 1;
