@@ -278,7 +278,7 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
     {
         const int L = p.levels - 1;
         const uint32_t n_buckets = (uint32_t)p.buckets[L];
-        const int grid = (int)std::min<uint64_t>(n_buckets, (uint64_t)c->n_cu * 3 * 8);
+        const int grid = (int)std::min<uint64_t>(n_buckets, (uint64_t)c->n_cu * 2 * 8);
         if (time_begin(c, &t, QM2_K_BUCKET_COUNT)) return 1;
         hipLaunchKernelGGL(bucket_count_kernel<kLgS>, dim3(grid), dim3(kCountThreads), 0, s, p.buf[L & 1],
                            p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, c->stats);
