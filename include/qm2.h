@@ -134,6 +134,15 @@ int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
  * reproduced: SURVEY B.3). */
 int qm2_submit(qm2_ctx *c, const char *seq_bytes, size_t n);
 
+/* Zero-copy variant for callers that produce the sequence lines themselves (the CLI's
+ * reader strips FASTA/FASTQ straight into pinned memory): qm2_staging_acquire hands out one
+ * of the context's pinned staging buffers (blocking until its previous copy has finished);
+ * qm2_staging_commit submits the first n bytes of it under qm2_submit's contract (whole
+ * '\n'-terminated lines) without the host memcpy and returns the buffer to the pool.  At most
+ * n_staging - 1 buffers may be held at a time. */
+int qm2_staging_acquire(qm2_ctx *c, char **buf, size_t *capacity);
+int qm2_staging_commit(qm2_ctx *c, char *buf, size_t n);
+
 /* Same, for bytes ALREADY in device memory (any alignment).  Asynchronous on
  * the context's stream; the buffer must stay valid until qm2_sync/qm2_finish.
  * `suppress`/`n_suppress` (device pointer to sorted u64 byte offsets, or

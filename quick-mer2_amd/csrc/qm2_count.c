@@ -19,10 +19,9 @@ static void help_count(void)
     puts("-t [num]\tNumber of threads");
 }
 
-static int submit_sink(void *user, const char *lines, size_t n)
-{
-    return qm2_submit((qm2_ctx *)user, lines, n);
-}
+static int out_acquire(void *user, char **buf, size_t *cap) { return qm2_staging_acquire((qm2_ctx *)user, buf, cap); }
+static int out_commit(void *user, char *buf, size_t n) { return qm2_staging_commit((qm2_ctx *)user, buf, n); }
+static int out_submit(void *user, const char *lines, size_t n) { return qm2_submit((qm2_ctx *)user, lines, n); }
 
 int qm2_main_count(int argc, char **argv)
 {
@@ -75,7 +74,8 @@ int qm2_main_count(int argc, char **argv)
 
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);                      /* :386-387 */
-    int rc = qm2_stream_reads(reads, (size_t)64 << 20, submit_sink, ctx);
+    const qm2_lines_out out = {out_acquire, out_commit, out_submit, ctx};
+    int rc = qm2_stream_reads(reads, &out);
     qm2_stats st;
     memset(&st, 0, sizeof st);
     if (!rc) rc = qm2_finish(ctx, NULL, &st);                 /* :458-479; counts stay on the device */

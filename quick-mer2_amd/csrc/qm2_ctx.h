@@ -20,6 +20,7 @@ struct Slot {                               /* one pinned staging buffer */
     char       *host = nullptr;
     hipEvent_t  done = nullptr;             /* its H2D copy has finished */
     bool        busy = false;
+    bool        lent = false;               /* handed out by qm2_staging_acquire */
 };
 
 struct Batch {                              /* one device batch being filled by qm2_submit */

@@ -418,7 +418,7 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
     if (c->staging_bytes < 64) c->staging_bytes = 64;
     c->batch_bytes = o.batch_bytes ? (size_t)o.batch_bytes : ((size_t)1 << 30);
     if (c->batch_bytes < 64) c->batch_bytes = 64;
-    c->slots.resize(o.n_staging ? o.n_staging : 3);      /* buffers are allocated lazily by qm2_submit */
+    c->slots.resize(o.n_staging ? std::max<uint32_t>(o.n_staging, 2) : 4);   /* allocated lazily */
     part_init(c, o.part_max_bits >= 1 && o.part_max_bits <= 8 ? (int)o.part_max_bits : 8);
 #undef OPEN_OK
     *out = c;
@@ -502,31 +502,53 @@ static int batch_flush(qm2_ctx *c)
     return 0;
 }
 
-/* Stage [src, src+n) behind the current batch's fill through the pinned slots. */
-static int stage_bytes(qm2_ctx *c, Batch &b, const char *src, size_t n)
+static int slot_ready(qm2_ctx *c, Slot &s)
 {
+    if (!s.host) {
+        HIP_OK(hipHostMalloc((void **)&s.host, c->staging_bytes, hipHostMallocDefault));
+        HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    if (s.busy) {
+        HIP_OK(hipEventSynchronize(s.done));
+        s.busy = false;
+    }
+    return 0;
+}
+
+/* Stage [src, src+n) behind the current batch's fill.  `owner` = the pinned slot src lies in
+ * (qm2_staging_commit: copied from in place), or null: src is pageable and goes through the
+ * free pinned slots. */
+static int stage_bytes(qm2_ctx *c, Batch &b, const char *src, size_t n, Slot *owner)
+{
+    if (owner) {
+        HIP_OK(hipMemcpyAsync(b.dev + b.fill, src, n, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_OK(hipEventRecord(owner->done, c->copy_stream));
+        owner->busy = true;
+        b.fill += n;
+        return 0;
+    }
     size_t done = 0;
     while (done < n) {
-        Slot &s = c->slots[c->next_slot];
-        c->next_slot = (c->next_slot + 1) % (uint32_t)c->slots.size();
-        if (!s.host) {
-            HIP_OK(hipHostMalloc((void **)&s.host, c->staging_bytes, hipHostMallocDefault));
-            HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        Slot *s = nullptr;
+        for (size_t tries = 0; tries < c->slots.size() && !s; tries++) {
+            Slot &cand = c->slots[c->next_slot];
+            c->next_slot = (c->next_slot + 1) % (uint32_t)c->slots.size();
+            if (!cand.lent) s = &cand;
         }
-        if (s.busy) {
-            HIP_OK(hipEventSynchronize(s.done));
-            s.busy = false;
-        }
+        if (!s) return fail("qm2_submit: every staging buffer is held by qm2_staging_acquire");
+        if (slot_ready(c, *s)) return 1;
         const size_t take = std::min(c->staging_bytes, n - done);
-        memcpy(s.host, src + done, take);
-        HIP_OK(hipMemcpyAsync(b.dev + b.fill, s.host, take, hipMemcpyHostToDevice, c->copy_stream));
-        HIP_OK(hipEventRecord(s.done, c->copy_stream));
-        s.busy = true;
+        memcpy(s->host, src + done, take);
+        HIP_OK(hipMemcpyAsync(b.dev + b.fill, s->host, take, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_OK(hipEventRecord(s->done, c->copy_stream));
+        s->busy = true;
         b.fill += take;
         done += take;
     }
     return 0;
 }
+
+static int submit_lines(qm2_ctx *c, const char *buf, size_t n, Slot *owner);
 
 extern "C" int qm2_submit(qm2_ctx *c, const char *buf, size_t n)
 {
@@ -536,7 +558,11 @@ extern "C" int qm2_submit(qm2_ctx *c, const char *buf, size_t n)
     if (buf[n - 1] != '\n')
         return fail("qm2_submit: buffer must end with a newline (whole sequence lines only)");
     if (use_device(c)) return 1;
+    return submit_lines(c, buf, n, nullptr);
+}
 
+static int submit_lines(qm2_ctx *c, const char *buf, size_t n, Slot *owner)
+{
     std::vector<Part> parts;
     {
         const Batch &b0 = c->batch[c->cur];
@@ -553,13 +579,48 @@ extern "C" int qm2_submit(qm2_ctx *c, const char *buf, size_t n)
         if (batch_ready(c, b)) return 1;
         const size_t at = b.fill;             /* first staged byte of this part lands at dev[at] */
         if (pt.carry) b.carry = pt.carry;     /* (only ever the first bytes of an empty batch) */
-        if (stage_bytes(c, b, buf + pt.off - pt.carry, pt.carry + pt.take)) return 1;
+        if (stage_bytes(c, b, buf + pt.off - pt.carry, pt.carry + pt.take, owner)) return 1;
         for (uint64_t w : pt.wraps) b.wraps.push_back(w + at);
         /* every part but the last fills its batch; the last one may */
         if (i + 1 < parts.size() || b.fill - b.carry >= c->batch_bytes)
             if (batch_flush(c)) return 1;
     }
     return 0;
+}
+
+extern "C" int qm2_staging_acquire(qm2_ctx *c, char **buf, size_t *capacity)
+{
+    if (!c || !buf || !capacity) return fail("qm2_staging_acquire: null argument");
+    if (use_device(c)) return 1;
+    size_t lent = 0;
+    for (auto &s : c->slots) lent += s.lent ? 1 : 0;
+    if (lent + 1 >= c->slots.size()) return fail("qm2_staging_acquire: too many staging buffers held");
+    for (size_t tries = 0; tries < c->slots.size(); tries++) {
+        Slot &s = c->slots[c->next_slot];
+        c->next_slot = (c->next_slot + 1) % (uint32_t)c->slots.size();
+        if (s.lent) continue;
+        if (slot_ready(c, s)) return 1;
+        s.lent = true;
+        *buf = s.host;
+        *capacity = c->staging_bytes;
+        return 0;
+    }
+    return fail("qm2_staging_acquire: no staging buffer free");
+}
+
+extern "C" int qm2_staging_commit(qm2_ctx *c, char *buf, size_t n)
+{
+    if (!c || !buf) return fail("qm2_staging_commit: null argument");
+    Slot *owner = nullptr;
+    for (auto &s : c->slots) if (s.lent && s.host == buf) owner = &s;
+    if (!owner) return fail("qm2_staging_commit: not a buffer from qm2_staging_acquire");
+    owner->lent = false;
+    if (n == 0) return 0;
+    if (n > c->staging_bytes) return fail("qm2_staging_commit: more bytes than the buffer holds");
+    if (buf[n - 1] != '\n')
+        return fail("qm2_staging_commit: buffer must end with a newline (whole sequence lines only)");
+    if (use_device(c)) return 1;
+    return submit_lines(c, buf, n, owner);
 }
 
 extern "C" int qm2_submit_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup,

@@ -35,12 +35,20 @@ void qm2_dict_close(qm2_dict_file *d);
 int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, const char *out_prefix);
 
 /* ---- input line discipline (:393-398, :451-455) ---------------------------- */
-typedef int (*qm2_lines_sink)(void *user, const char *lines, size_t n);
+/* Where the stripped sequence lines go: `acquire` hands out a buffer to fill (the CLI: a
+ * pinned staging buffer of the backend, qm2_staging_acquire), `commit` takes its first n
+ * bytes (whole '\n'-terminated lines; n may be 0), `submit` takes a pageable buffer and is
+ * only used for a single line longer than an acquired buffer. */
+typedef struct {
+    int (*acquire)(void *user, char **buf, size_t *capacity);
+    int (*commit)(void *user, char *buf, size_t n);
+    int (*submit)(void *user, const char *lines, size_t n);
+    void *user;
+} qm2_lines_out;
 
-/* Streams `path` (file, pipe or /dev/fd/N), strips it to sequence lines and
- * hands batches of whole '\n'-terminated lines (<= batch_bytes unless a single
- * line is longer) to `sink`.  Returns 0, or non-zero after printing a message. */
-int qm2_stream_reads(const char *path, size_t batch_bytes, qm2_lines_sink sink, void *user);
+/* Streams `path` (file, pipe or /dev/fd/N) with a read-ahead thread, strips it to sequence
+ * lines and hands them to `out`.  Returns 0, or non-zero after printing a message. */
+int qm2_stream_reads(const char *path, const qm2_lines_out *out);
 
 /* ---- the command ----------------------------------------------------------- */
 int qm2_main_count(int argc, char **argv);

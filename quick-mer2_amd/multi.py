@@ -51,6 +51,7 @@ class HipEngine:
         self.device = device
 
     def open(self, keys_span, hash_size, k, span, counters):
+        self._torch_done()
         return pyqm2.Counter(keys_span, hash_size=hash_size, k=k, device=self.device.index or 0,
                              span=span, ext_counters=counters.data_ptr())
 
@@ -60,7 +61,13 @@ class HipEngine:
     def to_device(self, lines: bytes):
         return self.torch.frombuffer(bytearray(lines), dtype=self.torch.uint8).to(self.device)
 
+    def _torch_done(self):
+        # the library runs on its own non-blocking stream: torch-side fills / copies that produce its
+        # inputs must have finished before it is called
+        self.torch.cuda.current_stream(self.device).synchronize()
+
     def count(self, ctx, d_lines):
+        self._torch_done()
         ctx.submit_device(d_lines.data_ptr(), d_lines.numel())
         ctx.sync()
 
@@ -70,12 +77,14 @@ class HipEngine:
         cap = max(16, d_lines.numel())
         out = t.empty(n_buckets * cap, dtype=t.int64, device=self.device)
         fills = t.zeros(n_buckets, dtype=t.int64, device=self.device)
+        self._torch_done()
         ctx.encode_device(d_lines.data_ptr(), d_lines.numel(), out.data_ptr(), cap, n_buckets, fills.data_ptr())
         ctx.sync()
         return out, fills, cap
 
     def probe(self, ctx, d_kmers):
         if d_kmers.numel():
+            self._torch_done()
             ctx.probe_device(d_kmers.data_ptr(), d_kmers.numel())
             ctx.sync()
 

@@ -51,7 +51,7 @@ class Dup(C.Structure):
 
 
 # every symbol include/qm2.h and include/qm2_tools.h declare
-ABI_SYMBOLS = ["qm2_open", "qm2_submit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
+ABI_SYMBOLS = ["qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
                "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch",
                "qm2_shard_span", "qm2_last_error",
@@ -85,6 +85,10 @@ def lib():
     L.qm2_open.argtypes = [C.POINTER(vp), vp, u64, u32, C.POINTER(Opts)]
     L.qm2_submit.restype = C.c_int
     L.qm2_submit.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.qm2_staging_acquire.restype = C.c_int
+    L.qm2_staging_acquire.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.qm2_staging_commit.restype = C.c_int
+    L.qm2_staging_commit.argtypes = [vp, vp, C.c_size_t]
     L.qm2_submit_device.restype = C.c_int
     L.qm2_submit_device.argtypes = [vp, vp, C.c_size_t, vp, u64]
     L.qm2_sync.restype = C.c_int
@@ -171,6 +175,23 @@ class Counter:
 
     def submit(self, lines: bytes):
         _check(lib().qm2_submit(self._h, lines, len(lines)), "qm2_submit")
+
+    def submit_zero_copy(self, lines: bytes):
+        """qm2_staging_acquire / fill / qm2_staging_commit, one staging buffer at a time."""
+        L = lib()
+        off = 0
+        while off < len(lines):
+            buf, cap = C.c_void_p(), C.c_size_t()
+            _check(L.qm2_staging_acquire(self._h, C.byref(buf), C.byref(cap)), "qm2_staging_acquire")
+            take = min(cap.value, len(lines) - off)
+            if off + take < len(lines):
+                take = lines.rfind(b"\n", off, off + take) + 1 - off
+                if take <= 0:
+                    L.qm2_staging_commit(self._h, buf, 0)
+                    raise Qm2Error("a line is longer than a staging buffer")
+            C.memmove(buf, lines[off:off + take], take)
+            _check(L.qm2_staging_commit(self._h, buf, take), "qm2_staging_commit")
+            off += take
 
     def submit_device(self, ptr, n, suppress_ptr=None, n_suppress=0):
         _check(lib().qm2_submit_device(self._h, ptr, n, suppress_ptr, n_suppress), "qm2_submit_device")

@@ -92,13 +92,19 @@ def test_host_reader_matches_reference_line_discipline(tmp_path):
     harness = tmp_path / "h.c"
     harness.write_text('''
 #include <stdio.h>
+#include <stdlib.h>
 #include "qm2_host.h"
-static int sink(void *u, const char *p, size_t n) { fwrite(p, 1, n, (FILE *)u); return 0; }
-int main(int argc, char **argv) { (void)argc; FILE *o = fopen(argv[2], "wb");
-  int rc = qm2_stream_reads(argv[1], (size_t)atol(argv[3]), sink, o); fclose(o); return rc; }
+static size_t CAP;
+static FILE *O;
+static int acq(void *u, char **b, size_t *c) { (void)u; *b = malloc(CAP); *c = CAP; return *b == NULL; }
+static int com(void *u, char *b, size_t n) { (void)u; fwrite(b, 1, n, O); free(b); return 0; }
+static int sub(void *u, const char *p, size_t n) { (void)u; fwrite(p, 1, n, O); return 0; }
+int main(int argc, char **argv) { (void)argc; O = fopen(argv[2], "wb"); CAP = (size_t)atol(argv[3]);
+  qm2_lines_out out = {acq, com, sub, NULL};
+  int rc = qm2_stream_reads(argv[1], &out); fclose(O); return rc; }
 ''')
     exe = str(tmp_path / "h")
-    subprocess.run(["gcc", "-O1", "-I", src, "-include", "stdlib.h", "-o", exe, str(harness),
+    subprocess.run(["gcc", "-O1", "-pthread", "-I", src, "-o", exe, str(harness),
                     os.path.join(src, "qm2_reader.c")], check=True)
     import oracle_lib as ol
     import synth
@@ -108,6 +114,10 @@ int main(int argc, char **argv) { (void)argc; FILE *o = fopen(argv[2], "wb");
         "fq_truncated": ("fq", b"@a\nACGT\n+\nIIII\n@b\nGG"),
         "gt_in_fastq_seq_pos": ("fq", b"@a\nACGT\n+\nIIII\n>odd\nTTTT\n+\nIIII\n@c\nCCCC\n+\nIIII\n"),
         "empty_seq_line": ("fq", b"@a\n\n+\n\n@b\nACGT\n+\nIIII\n"),
+        # blocks are 32 MiB with a 1 MiB carry reserve: lines that straddle blocks, a line longer
+        # than the reserve, and one longer than a whole block
+        "straddle": ("fa", b">x\n" + b"ACGT" * ((33 << 20) // 4 // 150 * 37) + b"\n" + (b"ACGTTGCA" * 19 + b"\n") * 250000),
+        "huge_line": ("fa", b">h\n" + b"ACGTA" * (8 << 20) + b"\nACGT\n"),
     }
     for name, (kind, data) in list(cases.items()) + list(extra.items()):
         p = tmp_path / ("%s.%s" % (name, kind))

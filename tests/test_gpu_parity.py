@@ -286,6 +286,7 @@ def test_submit_device_unaligned(qm2, torch_cuda, tmp_path):
     for mis in (0, 1, 7, 15, 16, 33):
         buf = torch.zeros(len(blob) + 64, dtype=torch.uint8, device="cuda")
         buf[mis:mis + len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
         for flags in (qm2.FLAG_DIRECT, qm2.FLAG_PARTITION):
             with qm2.Counter(qm["keys"], k=30, flags=flags) as c:
                 c.submit_device(buf.data_ptr() + mis, len(blob))
@@ -308,6 +309,7 @@ def test_encode_then_probe_equals_fused(qm2, torch_cuda, tmp_path):
         cap = len(exp_kmers) + 16
         out = torch.zeros(n_shards * cap, dtype=torch.int64, device="cuda")
         counts = torch.zeros(n_shards, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()          # the library runs on its own stream
         with qm2.Counter(keys, k=30) as enc:
             enc.encode_device(dbuf.data_ptr(), len(blob), out.data_ptr(), cap, n_shards, counts.data_ptr())
             enc.sync()
@@ -512,6 +514,7 @@ def test_c2_scale_properties(qm2, torch_cuda):
     torch.cuda.synchronize()
     nbytes = reads.numel()
     counters = torch.zeros(H, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()              # the library runs on its own stream
     with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), flags=qm2.FLAG_DIRECT) as cd:
         cd.submit_device(reads.data_ptr(), nbytes)
         d_direct, s_direct = cd.finish()
