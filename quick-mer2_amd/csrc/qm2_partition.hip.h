@@ -14,12 +14,15 @@
  *   split_text_kernel   text -> canonical k-mers, scattered into 2^b1 level-1 buckets
  *   split_kmer_kernel   level l-1 bucket -> its 2^bl children          (0..2 times)
  *   bucket_count_kernel finest bucket + table slice -> counters
- *   probe_kernel        (direct path) for the rare spill: bucket overflow (skewed
- *                       input, e.g. poly-A) or a probe walk longer than the halo
+ *   probe_kernel        (direct path) for the rare spill: k-mers that do not fit their
+ *                       bucket (skewed input, e.g. poly-A)
+ *   count_kernel        (direct path) recount of the whole batch, decided on the device,
+ *                       if even the spill list overflowed
  *
  * Exactness: every emitted k-mer lands in exactly one finest bucket or in the
- * spill list, and is probed exactly once under the reference's rule; integer
- * adds commute, so the order inside buckets is irrelevant.
+ * spill list, and is probed exactly once under the reference's rule (a walk
+ * longer than the staged halo finishes in global memory); integer adds commute,
+ * so the order inside buckets is irrelevant.
  */
 #pragma once
 #include "qm2_device.hip.h"

@@ -554,3 +554,44 @@ def test_c2_scale_properties(qm2, torch_cuda):
         depth, st = c.finish()
     assert st["n_kmers"] == exp_st["n_kmers"] and st["n_bases"] == exp_st["n_bases"]
     assert np.array_equal(depth, exp_depth)
+
+
+def test_c3_scale_partitioned_equals_direct(qm2, torch_cuda):
+    """hg38-scale table (H = 2^32, 3.1 Gb synthetic reference, ~2.27 G dictionary k-mers, 53 % fill;
+    3 partition levels): the partitioned pipeline and the direct kernel must produce the same
+    4 G counters and the same statistics; the same stream twice doubles every counter."""
+    torch = torch_cuda
+    free, total = torch.cuda.mem_get_info()
+    if free < 150 * (1 << 30):
+        pytest.skip("needs ~120 GiB of free HBM")
+    n, H, k = 3_100_000_000, 1 << 32, 30
+    genome = torch.empty(n, dtype=torch.uint8, device="cuda")
+    qm2.tools.genome_generate(genome.data_ptr(), n, seed=38, n_blocks=[(0, 10_000_000), (1_500_000_000, 30_000_000)])
+    keys = torch.empty(H, dtype=torch.int64, device="cuda")
+    scratch = torch.empty(H, dtype=torch.int64, device="cuda")
+    n_distinct, n_unique = qm2.tools.dict_build(genome.data_ptr(), n, k, keys.data_ptr(), H, scratch.data_ptr())
+    del scratch
+    torch.cuda.empty_cache()
+    assert 2.0e9 < n_unique <= n_distinct < 3.1e9
+    n_reads, rl = 5_000_000, 150
+    reads = torch.empty(n_reads * (rl + 1), dtype=torch.uint8, device="cuda")
+    qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, n_reads, 0, rl, rl, 38)
+    a = torch.zeros(H, dtype=torch.int32, device="cuda")
+    b = torch.zeros(H, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=a.data_ptr(),
+                     flags=qm2.FLAG_DIRECT) as cd:
+        cd.submit_device(reads.data_ptr(), reads.numel())
+        _, sd = cd.finish(want_depth=False)
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=b.data_ptr(),
+                     flags=qm2.FLAG_PARTITION | qm2.FLAG_TIMING) as cp:
+        cp.submit_device(reads.data_ptr(), reads.numel())
+        _, sp = cp.finish(want_depth=False)
+        assert cp.profile()["class_launches"]["split_kmer"] == 2      # 7 + 7 + 6 bits
+        assert sp == sd and sd["n_bases"] == n_reads * rl and sd["n_hits"] > 0.7 * sd["n_kmers"]
+        assert torch.equal(a, b)
+        assert int(b.sum(dtype=torch.int64)) == sp["n_hits"]
+        cp.submit_device(reads.data_ptr(), reads.numel())
+        _, s2 = cp.finish(want_depth=False)
+        assert s2 == {x: 2 * y for x, y in sp.items()}
+        assert torch.equal(b, 2 * a)
