@@ -26,6 +26,7 @@ static int out_submit(void *user, const char *lines, size_t n) { return qm2_subm
 int qm2_main_count(int argc, char **argv)
 {
     unsigned thread_count = 0;
+    int getopt_seen_t = 0;
     if (argc < 2) { help_count(); return 1; }                /* :309-312 */
     int opt;
     optind = 1;
@@ -34,6 +35,7 @@ int qm2_main_count(int argc, char **argv)
         case 'h': help_count(); return 1;
         case 't':
             thread_count = (unsigned)atoi(optarg) & 0xFFu;   /* uint8_t in the reference (:306) */
+            getopt_seen_t = 1;
             printf("[Option] Set %u threads\n", thread_count);
             break;
         case '?':
@@ -45,8 +47,10 @@ int qm2_main_count(int argc, char **argv)
     }
     if (argc < 4) { help_count(); return 1; }
     const char *ref_prefix = argv[argc - 3], *reads = argv[argc - 2], *out_prefix = argv[argc - 1];
-    (void)thread_count;  /* -t is accepted for command-line compatibility: the
-                            probing workers it sized (:372-384) are GPU waves now */
+    /* -t sized the reference's probing workers (:372-384); those are GPU waves now.  Here it sizes
+     * the host threads that strip FASTA/FASTQ blocks into pinned staging (default 4). */
+    int n_strip = getopt_seen_t ? (int)thread_count : 4;
+    if (n_strip > 16) n_strip = 16;
 
     const int timing = getenv("QM2_TIMING") != NULL;   /* extra phase lines; off by default so that
                                                           stdout stays the reference's */
@@ -67,6 +71,7 @@ int qm2_main_count(int argc, char **argv)
     memset(&o, 0, sizeof o);
     o.struct_size = sizeof o;
     o.device = -1;
+    o.n_staging = (uint32_t)n_strip + 3;
     clock_gettime(CLOCK_MONOTONIC, &ta);
     if (qm2_open(&ctx, d.keys, d.hash_size, d.k, &o)) { qm2_dict_close(&d); return 1; }
     clock_gettime(CLOCK_MONOTONIC, &tb);
@@ -75,7 +80,7 @@ int qm2_main_count(int argc, char **argv)
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);                      /* :386-387 */
     const qm2_lines_out out = {out_acquire, out_commit, out_submit, ctx};
-    int rc = qm2_stream_reads(reads, &out);
+    int rc = qm2_stream_reads(reads, &out, n_strip);
     qm2_stats st;
     memset(&st, 0, sizeof st);
     if (!rc) rc = qm2_finish(ctx, NULL, &st);                 /* :458-479; counts stay on the device */

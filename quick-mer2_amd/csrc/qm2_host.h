@@ -47,8 +47,10 @@ typedef struct {
 } qm2_lines_out;
 
 /* Streams `path` (file, pipe or /dev/fd/N) with a read-ahead thread, strips it to sequence
- * lines and hands them to `out`.  Returns 0, or non-zero after printing a message. */
-int qm2_stream_reads(const char *path, const qm2_lines_out *out);
+ * lines on n_threads worker threads (0 = on the calling thread) and hands them to `out`, which
+ * is only ever called from the calling thread and must be able to lend n_threads + 1 buffers at
+ * a time.  Returns 0, or non-zero after printing a message. */
+int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads);
 
 /* ---- the command ----------------------------------------------------------- */
 int qm2_main_count(int argc, char **argv);

@@ -34,21 +34,23 @@
 #define QM2_BLOCK   ((size_t)32 << 20)     /* bytes per read(2) block                          */
 #define QM2_RESERVE ((size_t)1 << 20)      /* room in front of a block for the unfinished line
                                               of the block before it                          */
-#define QM2_RING    3
+#define QM2_MAX_WORKERS 16
+#define QM2_RING_MAX (QM2_MAX_WORKERS + 3)
 
 /* ---- the I/O thread -------------------------------------------------------- */
 
 typedef struct {
     int     fd;
-    char   *blk[QM2_RING];                 /* each QM2_RESERVE + QM2_BLOCK bytes               */
-    ssize_t len[QM2_RING];                 /* bytes read into blk[i] + QM2_RESERVE; 0 = EOF, <0 = error */
+    int     n_slots;                       /* workers + 3: a block stays put until its job is collected */
+    char   *blk[QM2_RING_MAX];             /* each QM2_RESERVE + QM2_BLOCK bytes               */
+    ssize_t len[QM2_RING_MAX];             /* bytes read into blk[i] + QM2_RESERVE; 0 = EOF, <0 = error */
     sem_t   free_slots, filled;
 } io_ring;
 
 static void *io_main(void *arg)
 {
     io_ring *r = (io_ring *)arg;
-    for (int i = 0;; i = (i + 1) % QM2_RING) {
+    for (int i = 0;; i = (i + 1) % r->n_slots) {
         sem_wait(&r->free_slots);
         size_t have = 0;
         ssize_t got = 0;
@@ -62,7 +64,7 @@ static void *io_main(void *arg)
         sem_post(&r->filled);
         if (got < 0 || have == 0) return NULL;          /* error or EOF */
         if (have < QM2_BLOCK) {                         /* EOF after a partial block */
-            i = (i + 1) % QM2_RING;
+            i = (i + 1) % r->n_slots;
             sem_wait(&r->free_slots);
             r->len[i] = 0;
             sem_post(&r->filled);
@@ -115,6 +117,9 @@ static int out_line(out_state *o, const char *line, size_t body)
 
 typedef struct {
     int first_line, fastq, skip, seekable;
+    int desync;     /* FASTQ: a would-be sequence line started with '>' and was skipped WITHOUT the
+                       three discards (:398 comes before :451): from here on the state is no longer
+                       a function of the line count, which the parallel path relies on */
 } line_state;
 
 static int take_line(line_state *s, out_state *o, const char *line, size_t body)
@@ -125,13 +130,71 @@ static int take_line(line_state *s, out_state *o, const char *line, size_t body)
         if (!s->seekable) return 0;                               /* :396 on a pipe */
     }
     if (s->skip) { s->skip--; return 0; }                         /* :452-454 */
-    if (body && line[0] == '>') return 0;                         /* :398 */
+    if (body && line[0] == '>') { if (s->fastq) s->desync = 1; return 0; }   /* :398 */
     if (out_line(o, line, body)) return 1;
     if (s->fastq) s->skip = 3;
     return 0;
 }
 
-int qm2_stream_reads(const char *path, const qm2_lines_out *out)
+/* ---- parallel strip -------------------------------------------------------- *
+ * With n_threads > 0 the line discipline runs on worker threads, one 32 MiB block per job.
+ * Counting is order-independent, but the line discipline is not: a job needs the state at
+ * its first line.  In FASTQ mode that state advances by exactly one step per line
+ * (skip -> skip-1 -> ... -> 0 -> emit -> 3), so the coordinator only counts the newlines of a
+ * block to know where the next one starts; the one exception (a sequence-position line that
+ * starts with '>', see line_state.desync) is detected by the worker and makes the
+ * coordinator redo the later blocks serially with the exact state.  Outputs are committed in
+ * block order. */
+typedef struct {
+    const char *data;                      /* whole lines */
+    size_t      n;
+    line_state  st;                        /* in: state at the first line; out: state after the last */
+    char       *obuf;                      /* pinned output from out->acquire */
+    size_t      ocap, olen;
+    int         rc;
+    sem_t       start, done;
+    int         quit;
+} strip_job;
+
+static int buf_acquire(void *u, char **b, size_t *c) { (void)u; (void)b; (void)c; return 1; }
+static int buf_commit(void *u, char *b, size_t n) { (void)u; (void)b; (void)n; return 0; }
+static int buf_submit(void *u, const char *p, size_t n) { (void)u; (void)p; (void)n; return 1; }
+
+static void strip_block(strip_job *j)
+{
+    /* an out_state pinned to the job's buffer: the output never exceeds the input, so it fits */
+    static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL};
+    out_state os = {&none, j->obuf, j->ocap, 0};
+    size_t at = 0;
+    j->rc = 0;
+    while (at < j->n) {
+        const char *nl = memchr(j->data + at, '\n', j->n - at);
+        const size_t body = (size_t)(nl - (j->data + at));
+        if (take_line(&j->st, &os, j->data + at, body)) { j->rc = 1; break; }
+        at += body + 1;
+    }
+    j->olen = os.len;
+}
+
+static void *strip_main(void *arg)
+{
+    strip_job *j = (strip_job *)arg;
+    for (;;) {
+        sem_wait(&j->start);
+        if (j->quit) return NULL;
+        strip_block(j);
+        sem_post(&j->done);
+    }
+}
+
+static size_t count_newlines(const char *p, size_t n)
+{
+    size_t c = 0;
+    for (size_t i = 0; i < n; i++) c += p[i] == '\n';
+    return c;
+}
+
+int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads)
 {
     io_ring ring;
     memset(&ring, 0, sizeof ring);
@@ -140,24 +203,72 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out)
         puts("Input open fail");                             /* :339-341 */
         return 1;
     }
-    line_state ls = {1, 0, 0, lseek(ring.fd, 0, SEEK_CUR) != (off_t)-1};
+    if (n_threads < 0) n_threads = 0;
+    if (n_threads > QM2_MAX_WORKERS) n_threads = QM2_MAX_WORKERS;
+    ring.n_slots = n_threads + 3;
+    line_state ls = {1, 0, 0, lseek(ring.fd, 0, SEEK_CUR) != (off_t)-1, 0};
     out_state os = {out, NULL, 0, 0};
-    for (int i = 0; i < QM2_RING; i++) {
+    for (int i = 0; i < ring.n_slots; i++) {
         ring.blk[i] = malloc(QM2_RESERVE + QM2_BLOCK + 1);
         if (!ring.blk[i]) { puts("Memory allocation failed"); close(ring.fd); return 1; }
     }
-    sem_init(&ring.free_slots, 0, QM2_RING);
+    sem_init(&ring.free_slots, 0, (unsigned)ring.n_slots);
     sem_init(&ring.filled, 0, 0);
     pthread_t io;
     if (pthread_create(&io, NULL, io_main, &ring)) { puts("Thread creation failed"); close(ring.fd); return 1; }
 
+    /* strip workers: job slot w belongs to worker w; jobs are issued and collected round-robin,
+     * i.e. in block order */
+    strip_job jobs[QM2_MAX_WORKERS];
+    pthread_t workers[QM2_MAX_WORKERS];
+    int n_workers = 0;
+    for (int w = 0; w < n_threads; w++) {
+        memset(&jobs[w], 0, sizeof jobs[w]);
+        sem_init(&jobs[w].start, 0, 0);
+        sem_init(&jobs[w].done, 0, 0);
+        if (pthread_create(&workers[w], NULL, strip_main, &jobs[w])) break;
+        n_workers++;
+    }
+    int parallel = n_workers > 0;
+    unsigned long issued = 0, collected = 0;       /* jobs in flight = issued - collected <= n_workers */
+    int release_serial = 0;                        /* a serially processed block waits to be released */
+
     int rc = 0;
+    /* collect the oldest job: commit its output, release its block; on a desync redo what was
+     * issued after it serially */
+#define QM2_COLLECT()                                                                              \
+    do {                                                                                           \
+        strip_job *j = &jobs[collected % (unsigned long)n_workers];                                \
+        sem_wait(&j->done);                                                                        \
+        collected++;                                                                               \
+        if (j->rc) rc = 1;                                                                         \
+        if (out->commit(out->user, j->obuf, rc ? 0 : j->olen)) rc = 1;                             \
+        if (!rc && j->st.desync && parallel) {                                                     \
+            parallel = 0;                                                                          \
+            ls = j->st;                           /* exact state after this block */               \
+            while (collected < issued) {          /* later blocks: their start state was a guess */ \
+                strip_job *r = &jobs[collected % (unsigned long)n_workers];                        \
+                sem_wait(&r->done);                                                                \
+                collected++;                                                                       \
+                (void)out->commit(out->user, r->obuf, 0);                                          \
+                size_t at2 = 0;                                                                    \
+                while (!rc && at2 < r->n) {                                                        \
+                    const char *nl2 = memchr(r->data + at2, '\n', r->n - at2);                     \
+                    const size_t body2 = (size_t)(nl2 - (r->data + at2));                          \
+                    if (take_line(&ls, &os, r->data + at2, body2)) rc = 1;                         \
+                    at2 += body2 + 1;                                                              \
+                }                                                                                  \
+                sem_post(&ring.free_slots);                                                        \
+            }                                                                                      \
+        }                                                                                          \
+        sem_post(&ring.free_slots);                                                                \
+    } while (0)
+
     char *acc = NULL;                      /* a line that outgrew the reserve */
     size_t acc_len = 0, acc_cap = 0;
     const char *left = NULL;               /* unfinished line of the previous block */
     size_t left_len = 0;
-    int prev = -1;
-    for (int i = 0;; i = (i + 1) % QM2_RING) {
+    for (int i = 0;; i = (i + 1) % ring.n_slots) {
         sem_wait(&ring.filled);
         const ssize_t got = ring.len[i];
         if (got < 0) { puts("Input read fail"); rc = 1; }
@@ -179,11 +290,19 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out)
             }
             left_len = 0;
         }
-        if (prev >= 0) sem_post(&ring.free_slots);          /* the previous block is no longer referenced */
-        prev = i;
+        /* The I/O thread refills slots in ring order, so blocks must be released in block order,
+         * and only once nothing points into them: a serially processed block is released here,
+         * after its unfinished line has been copied out and the jobs before it are collected. */
+        if (release_serial) {
+            while (collected < issued) QM2_COLLECT();
+            sem_post(&ring.free_slots);
+            release_serial = 0;
+        }
         if (rc) break;
         size_t at = 0;
+        int dispatched = 0;
         if (acc) {                                           /* finish the over-long line first */
+            while (collected < issued) QM2_COLLECT();        /* (keeps the order of the serial path) */
             char *nl = n ? memchr(data, '\n', n) : NULL;
             const size_t head = nl ? (size_t)(nl - data) : n;
             if (acc_len + head + 1 > acc_cap) {
@@ -202,16 +321,55 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out)
                 at = nl ? head + 1 : n;
             } else at = n;
         }
-        while (at < n) {
+        if (ls.first_line && at < n) {                       /* the first line decides the format, serially */
             char *nl = memchr(data + at, '\n', n - at);
-            if (!nl) break;
-            const size_t body = (size_t)(nl - (data + at));
-            if (take_line(&ls, &os, data + at, body)) { rc = 1; break; }
-            at += body + 1;
+            if (nl) {
+                if (take_line(&ls, &os, data + at, (size_t)(nl - (data + at)))) { rc = 1; break; }
+                at = (size_t)(nl - data) + 1;
+            }
+        }
+        if (parallel && !ls.first_line && !ls.desync && at < n) {
+            /* hand the whole lines of this block to a worker */
+            const char *last = memrchr(data + at, '\n', n - at);
+            if (last) {
+                if (os.buf && out_flush(&os)) { rc = 1; break; }            /* keep commits in order */
+                if (issued - collected == (unsigned long)n_workers) QM2_COLLECT();
+                if (rc) break;
+            }
+            if (last && parallel) {
+                strip_job *j = &jobs[issued % (unsigned long)n_workers];
+                j->data = data + at;
+                j->n = (size_t)(last - (data + at)) + 1;
+                j->st = ls;
+                if (out->acquire(out->user, &j->obuf, &j->ocap)) { rc = 1; break; }
+                if (j->ocap < j->n) {                        /* cannot happen with 64 MiB staging; be safe */
+                    (void)out->commit(out->user, j->obuf, 0);
+                } else {
+                    /* state after this block: one step per line (:451-455) */
+                    if (ls.fastq) {
+                        const size_t lines = count_newlines(j->data, j->n);
+                        ls.skip = (int)(((size_t)ls.skip + 4 - (lines & 3)) & 3);
+                    }
+                    sem_post(&j->start);
+                    issued++;
+                    dispatched = 1;
+                    at += j->n;
+                }
+            }
+        }
+        if (!dispatched) {
+            while (at < n) {
+                char *nl = memchr(data + at, '\n', n - at);
+                if (!nl) break;
+                const size_t body = (size_t)(nl - (data + at));
+                if (take_line(&ls, &os, data + at, body)) { rc = 1; break; }
+                at += body + 1;
+            }
         }
         if (rc) break;
         if (got == 0) {                                      /* EOF: a last line without '\n' still counts */
-            if (at < n && take_line(&ls, &os, data + at, n - at)) rc = 1;
+            while (collected < issued) QM2_COLLECT();
+            if (!rc && at < n && take_line(&ls, &os, data + at, n - at)) rc = 1;
             break;
         }
         left = data + at;
@@ -222,16 +380,26 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out)
             if (!acc) { puts("Memory allocation failed"); rc = 1; break; }
             acc_len = 0;
         }
+        if (!dispatched) release_serial = 1;
     }
+    while (collected < issued) QM2_COLLECT();
+#undef QM2_COLLECT
     if (!rc) rc = out_flush(&os);
     else if (os.buf) (void)out->commit(out->user, os.buf, 0);
-    /* let the I/O thread run out */
+    /* shut the threads down */
+    for (int w = 0; w < n_workers; w++) {
+        jobs[w].quit = 1;
+        sem_post(&jobs[w].start);
+        pthread_join(workers[w], NULL);
+        sem_destroy(&jobs[w].start);
+        sem_destroy(&jobs[w].done);
+    }
     if (rc) close(ring.fd);
-    for (int k = 0; k < QM2_RING + 1; k++) sem_post(&ring.free_slots);
+    for (int k = 0; k < ring.n_slots + 1; k++) sem_post(&ring.free_slots);
     pthread_join(io, NULL);
     if (!rc) close(ring.fd);
     free(acc);
-    for (int i = 0; i < QM2_RING; i++) free(ring.blk[i]);
+    for (int i = 0; i < ring.n_slots; i++) free(ring.blk[i]);
     sem_destroy(&ring.free_slots);
     sem_destroy(&ring.filled);
     return rc;

@@ -101,7 +101,7 @@ static int com(void *u, char *b, size_t n) { (void)u; fwrite(b, 1, n, O); free(b
 static int sub(void *u, const char *p, size_t n) { (void)u; fwrite(p, 1, n, O); return 0; }
 int main(int argc, char **argv) { (void)argc; O = fopen(argv[2], "wb"); CAP = (size_t)atol(argv[3]);
   qm2_lines_out out = {acq, com, sub, NULL};
-  int rc = qm2_stream_reads(argv[1], &out); fclose(O); return rc; }
+  int rc = qm2_stream_reads(argv[1], &out, atoi(argv[4])); fclose(O); return rc; }
 ''')
     exe = str(tmp_path / "h")
     subprocess.run(["gcc", "-O1", "-pthread", "-I", src, "-o", exe, str(harness),
@@ -118,19 +118,29 @@ int main(int argc, char **argv) { (void)argc; O = fopen(argv[2], "wb"); CAP = (s
         # than the reserve, and one longer than a whole block
         "straddle": ("fa", b">x\n" + b"ACGT" * ((33 << 20) // 4 // 150 * 37) + b"\n" + (b"ACGTTGCA" * 19 + b"\n") * 250000),
         "huge_line": ("fa", b">h\n" + b"ACGTA" * (8 << 20) + b"\nACGT\n"),
+        # 100 MB FASTQ = 4 blocks: exercises the newline-count state hand-over between jobs
+        "fq_blocks": ("fq", b"".join(b"@r%d\n" % i + b"ACGTTGCATG" * 15 + b"\n+\n" + b"I" * 150 + b"\n" for i in range(320000))),
+        # ... and the same with a '>' at a sequence position in the second block (QuicKmer.c:398
+        # skips it WITHOUT the three discards): every later block must be redone serially
+        "fq_desync": ("fq", b"".join(b"@r%d\n" % i + (b">oops" if i == 150000 else b"ACGTTGCATG" * 15) + b"\n+\n" + b"I" * 150 + b"\n"
+                                     for i in range(320000))),
     }
     for name, (kind, data) in list(cases.items()) + list(extra.items()):
         p = tmp_path / ("%s.%s" % (name, kind))
         p.write_bytes(data)
         exp = ol.strip_reads(str(p), seekable=True)
-        for batch in (64, 4096, 1 << 20):
+        for batch, thr in ((64, 0), (4096, 0), (1 << 20, 0), (64 << 20, 1), (64 << 20, 3), (64 << 20, 8)):
             outp = str(tmp_path / "out.bin")
-            subprocess.run([exe, str(p), outp, str(batch)], check=True)
-            assert open(outp, "rb").read() == exp, (name, batch)
+            subprocess.run([exe, str(p), outp, str(batch), str(thr)], check=True)
+            got = open(outp, "rb").read()
+            if thr == 0:
+                assert got == exp, (name, batch)
+            else:       # blocks are committed in order, so even the order is the serial one
+                assert got == exp, (name, batch, thr)
         # pipe: first line is lost unless FASTQ (QuicKmer.c:396)
         outp = str(tmp_path / "out_pipe.bin")
         with open(str(p), "rb") as f:
             pr = subprocess.Popen(["cat"], stdin=f, stdout=subprocess.PIPE)
-            subprocess.run([exe, "/dev/fd/0", outp, "4096"], stdin=pr.stdout, check=True)
+            subprocess.run([exe, "/dev/fd/0", outp, str(64 << 20), "2"], stdin=pr.stdout, check=True)
             pr.wait()
         assert open(outp, "rb").read() == ol.strip_reads(str(p), seekable=False), name
