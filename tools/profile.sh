@@ -10,7 +10,7 @@ set -u
 TAG=${1:-r01}; shift || true
 ROOTDIR=$(pwd)
 OUT=$ROOTDIR/gpurun_out/prof_$TAG
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err" || echo "trace pass failed"
