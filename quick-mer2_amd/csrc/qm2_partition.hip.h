@@ -294,7 +294,13 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
  *      (resolves ~75 % at 53 % fill, ~99 % at 14 %);
  *   B  the unresolved ones are COMPACTED into a small per-wave LDS queue and probed on in
  *      dense rows, so the long tails of few k-mers no longer idle the other lanes. */
-constexpr int kQueueCap = 128;              /* per wave; what does not fit is finished in place */
+#ifndef QM2_QUEUE_CAP
+#define QM2_QUEUE_CAP 160
+#endif
+#ifndef QM2_COUNT_GROUP
+#define QM2_COUNT_GROUP 6
+#endif
+constexpr int kQueueCap = QM2_QUEUE_CAP;    /* per wave; what does not fit is finished in place */
 
 template <int LG_S>
 __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors,
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(const uint6
     unsigned long long n_probes = 0, n_hits = 0;
 
     constexpr int kSteps = (S + kHalo + kCountThreads - 1) / kCountThreads;
-    constexpr int kGroup = 4;
+    constexpr int kGroup = QM2_COUNT_GROUP;
 
     /* geometry of bucket b: own range, staged slice (own + kHalo slots on the side its probe
      * walks leave through, i.e. towards the middle of the table, :94-95), walk direction */
