@@ -216,6 +216,29 @@ def test_fuzz_arbitrary_bytes(qm2):
         check_against_oracle(qm2, kat_qm(setname)["keys"], k, blob, staging_bytes=8192)
 
 
+def test_zero_copy_staging_and_cli_threads(qm2, tmp_path):
+    """qm2_staging_acquire/commit (what the CLI's reader uses) gives the same counters as
+    qm2_submit, and the CLI gives the same .bin for every -t (strip threads)."""
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    lines = ol.strip_reads(rfq)
+    exp_depth, exp_st = ol.count_lines(qm["keys"], 30, lines)
+    for flags in (qm2.FLAG_DIRECT, qm2.FLAG_PARTITION):
+        with qm2.Counter(qm["keys"], k=30, flags=flags, staging_bytes=100_000, n_staging=3) as c:
+            c.submit_zero_copy(lines)
+            c.submit(lines[:lines.find(b"\n", 5000) + 1])          # the two entry points mix
+            depth, st = c.finish()
+        e2, s2 = ol.count_lines(qm["keys"], 30, lines + lines[:lines.find(b"\n", 5000) + 1])
+        assert st == s2 and np.array_equal(depth, e2)
+    m = MAN["sets"]["mini"]
+    ref_prefix = os.path.join(GOLD, "mini", "ref.fa")
+    for t in ("0", "1", "8", "200"):
+        out = str(tmp_path / ("t" + t))
+        r = subprocess.run([CLI, "count", "-t", t, ref_prefix, rfq, out], stdout=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0 and ("[Option] Set %d threads" % (int(t) & 0xFF)).encode() in r.stdout
+        assert md5_file(out + ".bin") == m["bin_md5"] and md5_file(out + ".txt") == m["txt_md5"]
+
+
 def test_empty_and_degenerate_inputs(qm2):
     qm = kat_qm()
     with qm2.Counter(qm["keys"], k=30) as c:
