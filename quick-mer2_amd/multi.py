@@ -74,7 +74,10 @@ class HipEngine:
     def encode(self, ctx, d_lines, n_buckets):
         """-> (kmers int64[n_buckets * cap] on device, fills int64[n_buckets] on device, cap)"""
         t = self.torch
-        cap = max(16, d_lines.numel())
+        n = d_lines.numel()
+        # uniform hashing spreads the <= n k-mers evenly over the owners: 30 % head-room per bucket
+        # (a bucket that still overflows is reported by the library as an error, never dropped silently)
+        cap = max(16, n if n_buckets == 1 else int(n / n_buckets * 1.3) + 4096)
         out = t.empty(n_buckets * cap, dtype=t.int64, device=self.device)
         fills = t.zeros(n_buckets, dtype=t.int64, device=self.device)
         self._torch_done()
