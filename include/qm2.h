@@ -68,7 +68,8 @@ typedef struct {
                                  (default 3; each has its own stream)            */
     uint64_t staging_bytes;   /* size of each staging buffer (default 64 MiB)    */
     uint64_t batch_bytes;     /* device batch that qm2_submit accumulates before it
-                                 launches (default 1 GiB; two are kept)          */
+                                 launches (default: one byte per table slot,
+                                 clamped to 1..4 GiB; two are kept)              */
     uint32_t part_max_bits;   /* partitioned pipeline: radix bits per level, 1..8
                                  (default 8); smaller values only make sense in tests */
     uint32_t reserved0;

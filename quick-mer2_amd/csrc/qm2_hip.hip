@@ -416,7 +416,10 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
 
     c->staging_bytes = o.staging_bytes ? (size_t)o.staging_bytes : ((size_t)64 << 20);
     if (c->staging_bytes < 64) c->staging_bytes = 64;
-    c->batch_bytes = o.batch_bytes ? (size_t)o.batch_bytes : ((size_t)1 << 30);
+    /* default device batch: one byte per table slot, 1..4 GiB — the partitioned pipeline streams the
+     * whole table once per batch, so batches should not be small against it */
+    c->batch_bytes = o.batch_bytes ? (size_t)o.batch_bytes
+                                   : (size_t)std::min<uint64_t>(std::max<uint64_t>(hash_size, 1ull << 30), 4ull << 30);
     if (c->batch_bytes < 64) c->batch_bytes = 64;
     c->slots.resize(o.n_staging ? std::max<uint32_t>(o.n_staging, 2) : 4);   /* allocated lazily */
     part_init(c, o.part_max_bits >= 1 && o.part_max_bits <= 8 ? (int)o.part_max_bits : 8);
