@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=6, help="probe workers (reference recommends 6)")
+    ap.add_argument("--cpu-sweep", default="", help="comma list of extra worker counts to time on a smaller "
+                    "sample (e.g. 0,12,24; 0 = the reference's serial mode); results go to cpu_baseline.sweep")
     ap.add_argument("--reads-per-step", type=int, default=0, help="override the workload's reads per step")
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "partition"],
                     help="count pipeline: auto = chosen per batch from its size vs. H")
@@ -282,6 +284,15 @@ def main():
                "sample": "first %d reads (%d bases) of batch 0, oracle threaded model: 1 producer + %d probe workers, %.1f s"
                          % (host.count(b"\n"), cst["n_bases"], args.cpu_threads, cpu_s),
                "gpu_counts_identical_on_sample": same}
+        if args.cpu_sweep:
+            sweep = {}
+            sub = host[:max(1, len(host) // 4)]
+            sub = sub[:sub.rfind(b"\n") + 1]
+            for thr in [int(x) for x in args.cpu_sweep.split(",") if x != ""]:
+                tA = time.perf_counter()
+                _, sst = ol.count_lines(hk, k, sub if thr else sub[:max(1, len(sub) // 6)][:sub[:max(1, len(sub) // 6)].rfind(b"\n") + 1], threads=thr)
+                sweep[str(thr)] = round(sst["n_bases"] / (time.perf_counter() - tA), 1)
+            cpu["sweep_bases_per_s_by_workers"] = sweep
         del hk
 
     if rank == 0:
