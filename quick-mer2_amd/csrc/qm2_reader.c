@@ -25,8 +25,11 @@
 #include <fcntl.h>
 #include <pthread.h>
 #include <semaphore.h>
+#include <sched.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "qm2_host.h"
@@ -189,9 +192,296 @@ static void *strip_main(void *arg)
 
 static size_t count_newlines(const char *p, size_t n)
 {
-    size_t c = 0;
-    for (size_t i = 0; i < n; i++) c += p[i] == '\n';
+    size_t c = 0, i = 0;
+    const uint64_t nl = 0x0A0A0A0A0A0A0A0Aull, lo7 = 0x7F7F7F7F7F7F7F7Full;
+    for (; i + 32 <= n; i += 32) {                     /* 8 bytes per word, exact zero-byte test, 4 words a turn */
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        for (int k = 0; k < 4; k++) {
+            const uint64_t t = w[k] ^ nl;
+            c += (size_t)__builtin_popcountll(~(((t & lo7) + lo7) | t | lo7));
+        }
+    }
+    for (; i < n; i++) c += p[i] == '\n';
     return c;
+}
+
+/* ---- regular files: pread + fully parallel blocks ---------------------------- *
+ * A regular file is cut into 32 MiB blocks; block b OWNS the lines that start inside it.
+ * Worker threads take blocks round-robin and do everything for their block themselves:
+ * pread it (plus the byte before, plus the rest of its last line) into a private, warm
+ * buffer, count the owned lines, wait for the line count of the blocks before it (a chain of
+ * cheap hand-overs), derive the FASTQ state from that count, and strip into a pinned staging
+ * buffer.  The calling thread only lends buffers and commits them in block order.  (Mapping
+ * the file instead was measured slower: populating page tables for page-cache pages costs
+ * more than the copy pread makes into a buffer that stays hot.)  As in the streaming path, a
+ * FASTQ sequence-position line that starts with '>' (line_state.desync) makes the rest of the
+ * file go through the exact serial state machine. */
+typedef struct pf_shared {
+    int     fd;
+    size_t  size, start;                   /* start: first byte after the consumed FASTQ header (or 0) */
+    size_t  n_blocks;
+    int     fastq;
+    volatile size_t *lines_before;         /* [n_blocks + 1], filled in block order */
+    volatile int    *known;                /* lines_before[b] is valid */
+    volatile int     stop;
+} pf_shared;
+
+typedef struct {
+    pf_shared  *sh;
+    char       *raw;                       /* private read buffer */
+    size_t      raw_cap;
+    /* per job */
+    size_t      block;
+    char       *obuf;
+    size_t      ocap, olen;
+    size_t      lo, hi;                    /* owned bytes: raw[lo, hi) */
+    size_t      file_hi;                   /* file offset of raw[hi] */
+    size_t      before;                    /* lines before this block */
+    line_state  st_end;
+    int         too_big, rc;
+    sem_t       start, done;
+    int         quit;
+} pf_worker;
+
+static ssize_t pread_full(int fd, char *buf, size_t n, size_t off)
+{
+    size_t got = 0;
+    while (got < n) {
+        const ssize_t r = pread(fd, buf + got, n - got, (off_t)(off + got));
+        if (r < 0) { if (errno == EINTR) continue; return -1; }
+        if (r == 0) break;
+        got += (size_t)r;
+    }
+    return (ssize_t)got;
+}
+
+/* read block b and settle raw[lo, hi) = the lines that start inside it */
+static int pf_load(pf_worker *w)
+{
+    pf_shared *sh = w->sh;
+    const size_t s = sh->start + w->block * QM2_BLOCK;
+    size_t e = s + QM2_BLOCK;
+    if (e > sh->size) e = sh->size;
+    const size_t base = w->block ? s - 1 : s;              /* the byte before tells whether a line starts at s */
+    ssize_t r = pread_full(sh->fd, w->raw, e - base, base);
+    if (r < 0) return 1;
+    size_t n = (size_t)r;
+    if (base + n < e) e = base + n;                        /* the file shrank under us: treat as EOF */
+    size_t lo = 0;
+    if (w->block) {
+        if (n && w->raw[0] == '\n') lo = 1;
+        else {
+            const char *nl = n > 1 ? memchr(w->raw + 1, '\n', n - 1) : NULL;
+            if (!nl) { w->lo = w->hi = 0; w->file_hi = e; return 0; }      /* no line starts in this block */
+            lo = (size_t)(nl - w->raw) + 1;
+        }
+    }
+    /* the rest of the last line lives in the following block(s) */
+    while (n && w->raw[n - 1] != '\n' && base + n < sh->size) {
+        const size_t step = 1u << 16;
+        if (n + step > w->raw_cap) {
+            char *g = realloc(w->raw, w->raw_cap * 2);
+            if (!g) return 1;
+            w->raw = g; w->raw_cap *= 2;
+        }
+        r = pread_full(sh->fd, w->raw + n, step, base + n);
+        if (r < 0) return 1;
+        if (r == 0) break;
+        const char *nl = memchr(w->raw + n, '\n', (size_t)r);
+        if (nl) { n = (size_t)(nl - w->raw) + 1; break; }
+        n += (size_t)r;
+    }
+    w->lo = lo; w->hi = n; w->file_hi = base + n;
+    return 0;
+}
+
+static int strip_range(const char *p, size_t n, line_state *st, out_state *os)
+{
+    size_t at = 0;
+    while (at < n) {
+        const char *nl = memchr(p + at, '\n', n - at);
+        const size_t body = nl ? (size_t)(nl - (p + at)) : n - at;
+        if (take_line(st, os, p + at, body)) return 1;
+        at += body + 1;
+    }
+    return 0;
+}
+
+static line_state pf_state(const pf_shared *sh, size_t before)
+{
+    line_state st = {0, sh->fastq, sh->fastq ? (int)((4 - (before & 3)) & 3) : 0, 1, 0};
+    return st;
+}
+
+static void *pf_main(void *arg)
+{
+    pf_worker *w = (pf_worker *)arg;
+    pf_shared *sh = w->sh;
+    for (;;) {
+        sem_wait(&w->start);
+        if (w->quit) return NULL;
+        const size_t b = w->block;
+        w->olen = 0; w->too_big = 0;
+        w->rc = sh->stop ? 0 : pf_load(w);
+        if (w->rc || sh->stop) w->lo = w->hi = 0;
+        size_t lines = count_newlines(w->raw + w->lo, w->hi - w->lo);
+        if (w->hi > w->lo && w->raw[w->hi - 1] != '\n') lines++;       /* last line of the file, no newline */
+        while (!sh->known[b] && !sh->stop) sched_yield();
+        w->before = sh->lines_before[b];
+        sh->lines_before[b + 1] = w->before + lines;
+        __sync_synchronize();
+        sh->known[b + 1] = 1;
+        line_state st = pf_state(sh, w->before);
+        if (!sh->stop && !w->rc) {
+            if (w->hi - w->lo + 1 > w->ocap) w->too_big = 1;          /* more than a staging buffer holds */
+            else {
+                static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL};
+                out_state os = {&none, w->obuf, w->ocap, 0};
+                if (strip_range(w->raw + w->lo, w->hi - w->lo, &st, &os)) w->rc = 1;
+                w->olen = os.len;
+            }
+        }
+        w->st_end = st;
+        sem_post(&w->done);
+    }
+}
+
+/* exact serial state machine over file bytes [off, size) (after a desync) */
+static int pf_serial_tail(const pf_shared *sh, size_t off, line_state *st, out_state *os)
+{
+    size_t cap = (size_t)8 << 20, have = 0;
+    char *buf = malloc(cap);
+    if (!buf) return 1;
+    int rc = 0;
+    for (;;) {
+        if (cap - have < ((size_t)4 << 20)) {
+            char *g = realloc(buf, cap * 2);
+            if (!g) { rc = 1; break; }
+            buf = g; cap *= 2;
+        }
+        const ssize_t r = pread_full(sh->fd, buf + have, (size_t)4 << 20, off);
+        if (r < 0) { rc = 1; break; }
+        off += (size_t)r;
+        have += (size_t)r;
+        const int eof = r == 0;
+        size_t at = 0;
+        while (at < have) {
+            const char *nl = memchr(buf + at, '\n', have - at);
+            if (!nl && !eof) break;
+            const size_t body = nl ? (size_t)(nl - (buf + at)) : have - at;
+            if (take_line(st, os, buf + at, body)) { rc = 1; break; }
+            at += body + (nl ? 1 : 0);
+        }
+        if (rc || eof) break;
+        memmove(buf, buf + at, have - at);
+        have -= at;
+    }
+    free(buf);
+    return rc;
+}
+
+static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_threads)
+{
+    pf_shared sh;
+    memset(&sh, 0, sizeof sh);
+    sh.fd = fd; sh.size = size;
+    /* the first line decides the format (:393-395); the file is seekable, so a FASTA first line is kept */
+    {
+        char head[1 << 12];
+        size_t off = 0;
+        ssize_t r = pread_full(fd, head, sizeof head, 0);
+        if (r < 0) return 1;
+        if (r > 0 && head[0] == '@') {
+            sh.fastq = 1;
+            for (;;) {                                               /* skip the header line, however long */
+                const char *nl = memchr(head, '\n', (size_t)r);
+                if (nl) { sh.start = off + (size_t)(nl - head) + 1; break; }
+                off += (size_t)r;
+                r = pread_full(fd, head, sizeof head, off);
+                if (r <= 0) { sh.start = size; break; }
+            }
+        }
+    }
+    int rc = 0;
+    out_state os = {out, NULL, 0, 0};
+    const size_t body = size - sh.start;
+    sh.n_blocks = (body + QM2_BLOCK - 1) / QM2_BLOCK;
+    sh.lines_before = calloc(sh.n_blocks + 2, sizeof(size_t));
+    sh.known = calloc(sh.n_blocks + 2, sizeof(int));
+    pf_worker *ws = calloc((size_t)n_threads, sizeof *ws);
+    pthread_t *tids = calloc((size_t)n_threads, sizeof *tids);
+    if (!sh.lines_before || !sh.known || !ws || !tids) { puts("Memory allocation failed"); rc = 1; }
+    int n_workers = 0;
+    if (!rc) {
+        sh.known[0] = 1;
+        for (int w = 0; w < n_threads && (size_t)w < sh.n_blocks; w++) {
+            ws[w].sh = &sh;
+            ws[w].raw_cap = QM2_BLOCK + (1u << 17);
+            ws[w].raw = malloc(ws[w].raw_cap);
+            if (!ws[w].raw) break;
+            sem_init(&ws[w].start, 0, 0);
+            sem_init(&ws[w].done, 0, 0);
+            if (pthread_create(&tids[w], NULL, pf_main, &ws[w])) { free(ws[w].raw); ws[w].raw = NULL; break; }
+            n_workers++;
+        }
+        if (!n_workers && sh.n_blocks) { puts("Memory allocation failed"); rc = 1; }
+    }
+    /* issue blocks round-robin, collect in order */
+    size_t issued = 0, collected = 0;
+    line_state tail = pf_state(&sh, 0);
+    int serial_from_here = 0;
+    size_t serial_lo = 0;
+    while (!rc && collected < sh.n_blocks) {
+        while (!serial_from_here && issued < sh.n_blocks && issued - collected < (size_t)n_workers) {
+            pf_worker *w = &ws[issued % (size_t)n_workers];
+            if (out->acquire(out->user, &w->obuf, &w->ocap)) { rc = 1; break; }
+            w->block = issued++;
+            sem_post(&w->start);
+        }
+        if (rc || collected >= issued) break;
+        pf_worker *w = &ws[collected % (size_t)n_workers];
+        sem_wait(&w->done);
+        collected++;
+        if (w->rc) { (void)out->commit(out->user, w->obuf, 0); rc = 1; break; }
+        if (serial_from_here) { (void)out->commit(out->user, w->obuf, 0); continue; }   /* redone below */
+        if (w->too_big || w->st_end.desync) {
+            /* redo this block serially from the worker's own buffer (oversize lines go through
+             * out->submit) and, after a desync, everything behind it from the file */
+            (void)out->commit(out->user, w->obuf, 0);
+            line_state st = pf_state(&sh, w->before);
+            if (strip_range(w->raw + w->lo, w->hi - w->lo, &st, &os)) rc = 1;
+            if (!rc && out_flush(&os)) rc = 1;
+            if (st.desync) {
+                sh.stop = 1;
+                serial_from_here = 1;
+                serial_lo = w->file_hi;
+                tail = st;
+            }
+        } else if (out->commit(out->user, w->obuf, w->olen)) rc = 1;
+    }
+    while (collected < issued) {                                     /* drain what is still in flight */
+        pf_worker *w = &ws[collected % (size_t)n_workers];
+        sem_wait(&w->done);
+        collected++;
+        (void)out->commit(out->user, w->obuf, 0);
+    }
+    if (!rc && serial_from_here) {
+        tail.desync = 0;
+        if (pf_serial_tail(&sh, serial_lo, &tail, &os)) rc = 1;
+    }
+    if (!rc) rc = out_flush(&os);
+    else if (os.buf) (void)out->commit(out->user, os.buf, 0);
+    for (int w = 0; w < n_workers; w++) {
+        ws[w].quit = 1;
+        sem_post(&ws[w].start);
+        pthread_join(tids[w], NULL);
+        sem_destroy(&ws[w].start);
+        sem_destroy(&ws[w].done);
+        free(ws[w].raw);
+    }
+    free((void *)sh.lines_before); free((void *)sh.known); free(ws); free(tids);
+    return rc;
 }
 
 int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads)
@@ -205,6 +495,19 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads)
     }
     if (n_threads < 0) n_threads = 0;
     if (n_threads > QM2_MAX_WORKERS) n_threads = QM2_MAX_WORKERS;
+    if (n_threads > 0 && !getenv("QM2_READER_STREAM")) {
+        /* regular FASTQ file: the workers read their own blocks (measured 2.3 -> 6.0 G bases/s at C2).
+         * FASTA keeps the streaming path: it has nothing to drop but headers, and one read(2)
+         * thread feeding the strip workers is already the faster arrangement there (10 G bases/s). */
+        struct stat sb;
+        char first = 0;
+        if (fstat(ring.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && pread(ring.fd, &first, 1, 0) == 1 &&
+            (first == '@' || getenv("QM2_READER_BLOCKS"))) {
+            const int brc = stream_blocks(ring.fd, (size_t)sb.st_size, out, n_threads);
+            close(ring.fd);
+            return brc;
+        }
+    }
     ring.n_slots = n_threads + 3;
     line_state ls = {1, 0, 0, lseek(ring.fd, 0, SEEK_CUR) != (off_t)-1, 0};
     out_state os = {out, NULL, 0, 0};

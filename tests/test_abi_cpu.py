@@ -129,14 +129,14 @@ int main(int argc, char **argv) { (void)argc; O = fopen(argv[2], "wb"); CAP = (s
         p = tmp_path / ("%s.%s" % (name, kind))
         p.write_bytes(data)
         exp = ol.strip_reads(str(p), seekable=True)
-        for batch, thr in ((64, 0), (4096, 0), (1 << 20, 0), (64 << 20, 1), (64 << 20, 3), (64 << 20, 8)):
+        for batch, thr in ((64, 0), (4096, 0), (1 << 20, 0), (64 << 20, 1), (64 << 20, 3), (64 << 20, 8),
+                           (1 << 20, 3), (40 << 20, 2)):    # staging buffers smaller than a block / than one line
             outp = str(tmp_path / "out.bin")
-            subprocess.run([exe, str(p), outp, str(batch), str(thr)], check=True)
-            got = open(outp, "rb").read()
-            if thr == 0:
-                assert got == exp, (name, batch)
-            else:       # blocks are committed in order, so even the order is the serial one
-                assert got == exp, (name, batch, thr)
+            # threaded: the default choice (pread blocks for FASTQ files, read(2) stream otherwise), then each
+            # path forced for both formats; blocks are committed in order, so even the order is the serial one
+            for env in ({},) if thr == 0 else ({}, {"QM2_READER_BLOCKS": "1"}, {"QM2_READER_STREAM": "1"}):
+                subprocess.run([exe, str(p), outp, str(batch), str(thr)], check=True, env=dict(os.environ, **env))
+                assert open(outp, "rb").read() == exp, (name, batch, thr, env)
         # pipe: first line is lost unless FASTQ (QuicKmer.c:396)
         outp = str(tmp_path / "out_pipe.bin")
         with open(str(p), "rb") as f:
