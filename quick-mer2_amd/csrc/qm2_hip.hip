@@ -52,6 +52,12 @@ constexpr size_t kDevPad = 64;
 #ifndef QM2_LG_S
 #define QM2_LG_S 12
 #endif
+#ifndef QM2_COUNT_PIPE
+#define QM2_COUNT_PIPE 2          /* 0 never, 1 always, 2 by k-mers per bucket */
+#endif
+#ifndef QM2_COUNT_GRID_MULT
+#define QM2_COUNT_GRID_MULT 8        /* bucket_count workgroups = 2 per CU (what is resident) x this */
+#endif
 constexpr int    kLgS = QM2_LG_S;          /* finest bucket = 2^kLgS table slots: 12 B of LDS per slot */
 }  // namespace
 
@@ -278,10 +284,17 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
     {
         const int L = p.levels - 1;
         const uint32_t n_buckets = (uint32_t)p.buckets[L];
-        const int grid = (int)std::min<uint64_t>(n_buckets, (uint64_t)c->n_cu * 2 * 8);
+        const int grid = (int)std::min<uint64_t>(n_buckets, (uint64_t)c->n_cu * 2 * QM2_COUNT_GRID_MULT);
         if (time_begin(c, &t, QM2_K_BUCKET_COUNT)) return 1;
-        hipLaunchKernelGGL(bucket_count_kernel<kLgS>, dim3(grid), dim3(kCountThreads), 0, s, p.buf[L & 1],
-                           p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, c->stats);
+        /* few k-mers per bucket (hg38-scale tables): the counter tile is fetched a bucket ahead with
+         * the key slice; many k-mers per bucket: the flush touches only the sectors that got counts */
+        const bool pipe = QM2_COUNT_PIPE == 2 ? sv.n_total / n_buckets < (2u << kLgS) : QM2_COUNT_PIPE != 0;
+        if (pipe)
+            hipLaunchKernelGGL((bucket_count_kernel<kLgS, true>), dim3(grid), dim3(kCountThreads), 0, s, p.buf[L & 1],
+                               p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, c->stats);
+        else
+            hipLaunchKernelGGL((bucket_count_kernel<kLgS, false>), dim3(grid), dim3(kCountThreads), 0, s, p.buf[L & 1],
+                               p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, c->stats);
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
     }

@@ -300,10 +300,13 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
 #ifndef QM2_COUNT_GROUP
 #define QM2_COUNT_GROUP 6
 #endif
+#ifndef QM2_COUNT_GROUP_PIPE
+#define QM2_COUNT_GROUP_PIPE 5
+#endif
 constexpr int kQueueCap = QM2_QUEUE_CAP;    /* per wave; what does not fit is finished in place */
 
-template <int LG_S>
-__global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors,
+template <int LG_S, bool PIPE>
+__global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors,
                                                                      uint32_t cap, TableView tv, uint64_t H,
                                                                      uint32_t n_buckets, DevStats *stats)
 {
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(const uint6
     unsigned long long n_probes = 0, n_hits = 0;
 
     constexpr int kSteps = (S + kHalo + kCountThreads - 1) / kCountThreads;
-    constexpr int kGroup = QM2_COUNT_GROUP;
+    constexpr int kGroup = PIPE ? QM2_COUNT_GROUP_PIPE : QM2_COUNT_GROUP;
 
     /* geometry of bucket b: own range, staged slice (own + kHalo slots on the side its probe
      * walks leave through, i.e. towards the middle of the table, :94-95), walk direction */
@@ -337,11 +340,15 @@ __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(const uint6
         g.seg = (uint32_t)(hi - lo);
         return g;
     };
-    /* The table slice of the NEXT bucket is fetched into registers while the current one is
-     * probed, and the next group of k-mers while the current group is probed: the workgroup
-     * always has loads in flight. */
+    /* Software pipeline over the buckets of this workgroup (stride gridDim.x): everything bucket
+     * b+stride needs from HBM — its table slice, the old values of its counters, its fill and its
+     * first group of k-mers — is loaded into registers while bucket b is probed, and later groups
+     * of b while the current group is probed.  Nothing in the steady state waits for a load that
+     * was issued less than one bucket ago. */
+    const uint32_t stride = gridDim.x;
     uint64_t kv[kSteps];
-    auto fetch_keys = [&](uint32_t b) {
+    uint32_t ov[kSteps];
+    auto fetch_slice = [&](uint32_t b) {
         if (b >= n_buckets) return;
         const Geo g = geo(b);
 #pragma unroll
@@ -349,23 +356,54 @@ __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(const uint6
             const uint32_t i = tid + st * kCountThreads;
             kv[st] = i < g.seg ? tv.keys[g.seg_lo + i] : 0;
         }
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int st = 0; st < kSteps; st++) {
+                const uint32_t i = tid + st * kCountThreads;
+                const uint64_t slot = g.seg_lo + i;
+                const bool interior = i < g.seg && slot >= g.own_lo + kHalo && slot + kHalo < g.own_hi;
+                ov[st] = interior ? tv.counters[slot - tv.span_lo] : 0;
+            }
+        }
     };
-    fetch_keys(blockIdx.x);
+    auto fill_of = [&](uint32_t b) {
+        uint32_t n = b < n_buckets ? cursors[b] : 0;
+        return n > cap ? cap : n;
+    };
+    uint64_t nq[kGroup];
+    uint32_t n_next = 0, n_after = 0;
+    fetch_slice(blockIdx.x);
+    if constexpr (PIPE) {
+        n_next = fill_of(blockIdx.x);                         /* fill of the bucket about to start */
+        const uint64_t *in0 = kmers + (uint64_t)blockIdx.x * cap;
+#pragma unroll
+        for (int q = 0; q < kGroup; q++) {
+            const uint32_t i = q * kCountThreads + tid;
+            nq[q] = i < n_next ? in0[i] : kPad;
+        }
+        n_after = fill_of(blockIdx.x + stride);               /* ... and of the one after it */
+    }
 
-    for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
-        uint32_t n = cursors[b];
-        if (n > cap) n = cap;
+    for (uint32_t b = blockIdx.x; b < n_buckets; b += stride) {
+        const uint32_t n = PIPE ? n_next : fill_of(b);
         const Geo g = geo(b);
         const uint64_t own_lo = g.own_lo, own_hi = g.own_hi, seg_lo = g.seg_lo;
         const uint32_t seg = g.seg;
         const bool down = g.down;
+        /* the counter tile starts from the old values of the interior (0 elsewhere), so the LDS
+         * atomics accumulate straight onto them */
 #pragma unroll
         for (int st = 0; st < kSteps; st++) {
             const uint32_t i = tid + st * kCountThreads;
-            if (i < seg) { skey[i] = kv[st]; scnt[i] = 0; }
+            if (i < seg) { skey[i] = kv[st]; scnt[i] = PIPE ? ov[st] : 0u; }
         }
         lds_barrier();
-        fetch_keys(b + gridDim.x);
+        const uint32_t bn = b + stride;
+        fetch_slice(bn);
+        if constexpr (PIPE) {
+            n_next = n_after;
+            n_after = fill_of(bn + stride);
+        }
 
         /* continue a walk from staged position `at` (may be outside the slice: then, and when it
          * leaves the slice later, it finishes in global memory like the direct kernel) */
@@ -392,19 +430,26 @@ __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(const uint6
         };
 
         const uint64_t *in = kmers + (uint64_t)b * cap;
-        uint64_t nq[kGroup];
+        const uint64_t *in_next = kmers + (uint64_t)bn * cap;
+        if constexpr (!PIPE) {
 #pragma unroll
-        for (int q = 0; q < kGroup; q++) {
-            const uint32_t i = q * kCountThreads + tid;
-            nq[q] = i < n ? in[i] : kPad;
+            for (int q = 0; q < kGroup; q++) {
+                const uint32_t i = q * kCountThreads + tid;
+                nq[q] = i < n ? in[i] : kPad;
+            }
         }
-        for (uint32_t base = 0; base < n; base += kGroup * kCountThreads) {
+        uint32_t base = 0;
+        /* PIPE runs the body once even for an empty bucket: it carries the next bucket's prefetch */
+        while (PIPE ? (base == 0 || base < n) : base < n) {
             uint64_t kq[kGroup];
+            const bool last = PIPE && base + kGroup * kCountThreads >= n;   /* workgroup-uniform */
 #pragma unroll
             for (int q = 0; q < kGroup; q++) {
                 kq[q] = nq[q];
-                const uint32_t i = base + (kGroup + q) * kCountThreads + tid;
-                nq[q] = i < n ? in[i] : kPad;
+                /* next group of this bucket, or (PIPE) behind the last one the first of the next bucket */
+                const uint32_t j = q * kCountThreads + tid;
+                const uint32_t i = base + kGroup * kCountThreads + j;
+                nq[q] = last ? (j < n_next ? in_next[j] : kPad) : (i < n ? in[i] : kPad);
             }
             /* ---- phase A: two slots per k-mer, no loop ---- */
             uint32_t queued = 0;                                            /* wave-uniform */
@@ -454,29 +499,48 @@ __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(const uint6
                 const uint32_t a = qa[wave][e];
                 walk(km, (int32_t)(a & 0x1FFFu) - 1, (a & 0x2000u) != 0, (a >> 14) + 1);
             }
+            base += kGroup * kCountThreads;
         }
         lds_barrier();
-        /* flush: the interior of the owned range is touched by this workgroup only (plain
-         * read-modify-write, all reads issued before the writes); the kHalo slots at either
-         * end of it and the staged halo can also receive a neighbour's counts (atomic add). */
+        /* flush: the interior of the owned range is touched by this workgroup only, so the tile
+         * (old values, fetched a bucket ago, plus this bucket's counts) is stored back plainly; the
+         * kHalo slots at either end of it and the staged halo can also receive a neighbour's
+         * counts, so there the tile holds deltas and they are added atomically. */
         if (n) {
-            uint32_t cv[kSteps], old[kSteps];
+            if constexpr (PIPE) {
 #pragma unroll
-            for (int st = 0; st < kSteps; st++) {
-                const uint32_t i = tid + st * kCountThreads;
-                cv[st] = i < seg ? scnt[i] : 0;
-                old[st] = 0;
-                if (cv[st]) {
-                    const uint64_t slot = seg_lo + i;
-                    const bool interior = slot >= own_lo + kHalo && slot + kHalo < own_hi;
-                    uint32_t *p = tv.counters + (slot - tv.span_lo);
-                    if (interior) old[st] = *p;
-                    else { atomicAdd(p, cv[st]); cv[st] = 0; }
+                for (int st = 0; st < kSteps; st++) {
+                    const uint32_t i = tid + st * kCountThreads;
+                    if (i < seg) {
+                        const uint32_t cv = scnt[i];
+                        const uint64_t slot = seg_lo + i;
+                        const bool interior = slot >= own_lo + kHalo && slot + kHalo < own_hi;
+                        uint32_t *p = tv.counters + (slot - tv.span_lo);
+                        if (interior) *p = cv;
+                        else if (cv) atomicAdd(p, cv);
+                    }
                 }
-            }
+            } else {
+                /* sparse table: only the sectors that got counts are read and written (all reads
+                 * issued before the writes) */
+                uint32_t cv[kSteps], old[kSteps];
 #pragma unroll
-            for (int st = 0; st < kSteps; st++)
-                if (cv[st]) tv.counters[seg_lo + tid + st * kCountThreads - tv.span_lo] = old[st] + cv[st];
+                for (int st = 0; st < kSteps; st++) {
+                    const uint32_t i = tid + st * kCountThreads;
+                    cv[st] = i < seg ? scnt[i] : 0;
+                    old[st] = 0;
+                    if (cv[st]) {
+                        const uint64_t slot = seg_lo + i;
+                        const bool interior = slot >= own_lo + kHalo && slot + kHalo < own_hi;
+                        uint32_t *p = tv.counters + (slot - tv.span_lo);
+                        if (interior) old[st] = *p;
+                        else { atomicAdd(p, cv[st]); cv[st] = 0; }
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < kSteps; st++)
+                    if (cv[st]) tv.counters[seg_lo + tid + st * kCountThreads - tv.span_lo] = old[st] + cv[st];
+            }
         }
         lds_barrier();
     }
