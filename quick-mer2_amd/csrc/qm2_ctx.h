@@ -56,6 +56,10 @@ struct PartPlan {                           /* how a batch is radix-partitioned 
     uint64_t *spill = nullptr;
     uint64_t  spill_cap = 0;
     unsigned long long *spill_count = nullptr;
+    /* occupied runs vs the staged halo (long_run_kernel): 0 not checked yet, 1 every run is shorter
+     * than the halo, 2 some are longer and their buckets are marked in `shared`, 3 hopeless -> direct */
+    int       runs = 0;
+    uint32_t *shared = nullptr;             /* bitset over the finest buckets */
 };
 
 }  // namespace qm2

@@ -291,10 +291,10 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
         const bool pipe = QM2_COUNT_PIPE == 2 ? sv.n_total / n_buckets < (2u << kLgS) : QM2_COUNT_PIPE != 0;
         if (pipe)
             hipLaunchKernelGGL((bucket_count_kernel<kLgS, true>), dim3(grid), dim3(kCountThreads), 0, s, p.buf[L & 1],
-                               p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, c->stats);
+                               p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, p.shared, c->stats);
         else
             hipLaunchKernelGGL((bucket_count_kernel<kLgS, false>), dim3(grid), dim3(kCountThreads), 0, s, p.buf[L & 1],
-                               p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, c->stats);
+                               p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, p.shared, c->stats);
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
     }
@@ -319,6 +319,35 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
  * look-back only.  Chooses the pipeline: the partitioned one streams the whole
  * table once per batch (~16 B per slot), the direct one pays ~60 ps per k-mer in
  * sector gathers and memory-side atomics; break-even is near n = H / 13. */
+/* Looks at the runs of occupied slots once per context (see long_run_kernel); *ok = the
+ * partitioned pipeline may be used with this key table. */
+static int runs_fit(qm2_ctx *c, bool *ok)
+{
+    PartPlan &p = c->part;
+    if (p.runs == 0) {
+        const uint64_t n_buckets = p.buckets[p.levels - 1];
+        const size_t words = (size_t)((n_buckets + 31) / 32);
+        unsigned int *d_found = nullptr, found = 0;
+        uint32_t *d_shared = nullptr;
+        HIP_OK(hipMalloc((void **)&d_found, sizeof(unsigned int)));
+        HIP_OK(hipMalloc((void **)&d_shared, words * sizeof(uint32_t)));
+        HIP_OK(hipMemsetAsync(d_found, 0, sizeof(unsigned int), c->stream));
+        HIP_OK(hipMemsetAsync(d_shared, 0, words * sizeof(uint32_t), c->stream));
+        const int grid = (int)std::min<uint64_t>((c->H + 255) / 256, (uint64_t)c->n_cu * 64);
+        hipLaunchKernelGGL(long_run_kernel, dim3(grid), dim3(256), 0, c->stream, c->keys, c->H, (uint32_t)kHalo,
+                           (uint32_t)kLgS, d_shared, d_found);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync(&found, d_found, sizeof found, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipFree(d_found));
+        p.runs = (found & 2u) ? 3 : (found & 1u) ? 2 : 1;
+        if (p.runs == 2) p.shared = d_shared;
+        else HIP_OK(hipFree(d_shared));
+    }
+    *ok = p.runs != 3;
+    return 0;
+}
+
 static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry, const uint64_t *d_sup,
                         uint64_t n_sup)
 {
@@ -329,6 +358,12 @@ static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry,
     bool part = (c->flags & QM2_FLAG_PARTITION) != 0 || ((uint64_t)n >= c->H / 8 && n >= (1u << 20));
     if (c->flags & QM2_FLAG_DIRECT) part = false;
     if (c->span_lo != 0 || c->span_hi != c->H) part = false;         /* shard spans: direct only */
+    if (part && c->part.levels == 0) part = false;
+    if (part) {                                                       /* occupied runs vs the halo */
+        bool ok = false;
+        if (runs_fit(c, &ok)) return 1;
+        if (!ok) part = false;
+    }
     if (part && part_reserve(c, n)) part = false;                    /* no memory: direct */
     if (part) {
         c->prof.partitioned_batches++;
@@ -458,6 +493,7 @@ extern "C" void qm2_close(qm2_ctx *c)
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto &t : c->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     qm2_part_free(c->part);
+    if (c->part.shared) { (void)hipFree(c->part.shared); c->part.shared = nullptr; }
     if (c->own_chain && c->chain) (void)hipFree(c->chain);
     if (c->gathered) (void)hipFree(c->gathered);
     if (c->own_keys && c->keys) (void)hipFree(c->keys);

@@ -308,7 +308,8 @@ constexpr int kQueueCap = QM2_QUEUE_CAP;    /* per wave; what does not fit is fi
 template <int LG_S, bool PIPE>
 __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors,
                                                                      uint32_t cap, TableView tv, uint64_t H,
-                                                                     uint32_t n_buckets, DevStats *stats)
+                                                                     uint32_t n_buckets, const uint32_t *shared,
+                                                                     DevStats *stats)
 {
     if (stats->part_lost != 0) return;       /* this batch is recounted by the direct kernel */
     constexpr int S = 1 << LG_S;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
 
     /* geometry of bucket b: own range, staged slice (own + kHalo slots on the side its probe
      * walks leave through, i.e. towards the middle of the table, :94-95), walk direction */
-    struct Geo { uint64_t own_lo, own_hi, seg_lo; uint32_t seg; bool down; };
+    struct Geo { uint64_t own_lo, own_hi, seg_lo; uint32_t seg; bool down, shared; };
     auto geo = [&](uint32_t b) {
         Geo g;
         g.own_lo = (uint64_t)b << LG_S;
@@ -338,6 +339,8 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
         }
         g.seg_lo = lo;
         g.seg = (uint32_t)(hi - lo);
+        /* a long run of occupied slots reaches into this bucket: nothing in it is private */
+        g.shared = shared != nullptr && ((shared[b >> 5] >> (b & 31)) & 1u) != 0;
         return g;
     };
     /* Software pipeline over the buckets of this workgroup (stride gridDim.x): everything bucket
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
             for (int st = 0; st < kSteps; st++) {
                 const uint32_t i = tid + st * kCountThreads;
                 const uint64_t slot = g.seg_lo + i;
-                const bool interior = i < g.seg && slot >= g.own_lo + kHalo && slot + kHalo < g.own_hi;
+                const bool interior = !g.shared && i < g.seg && slot >= g.own_lo + kHalo && slot + kHalo < g.own_hi;
                 ov[st] = interior ? tv.counters[slot - tv.span_lo] : 0;
             }
         }
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
         const Geo g = geo(b);
         const uint64_t own_lo = g.own_lo, own_hi = g.own_hi, seg_lo = g.seg_lo;
         const uint32_t seg = g.seg;
-        const bool down = g.down;
+        const bool down = g.down, private_tile = !g.shared;
         /* the counter tile starts from the old values of the interior (0 elsewhere), so the LDS
          * atomics accumulate straight onto them */
 #pragma unroll
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
                     if (i < seg) {
                         const uint32_t cv = scnt[i];
                         const uint64_t slot = seg_lo + i;
-                        const bool interior = slot >= own_lo + kHalo && slot + kHalo < own_hi;
+                        const bool interior = private_tile && slot >= own_lo + kHalo && slot + kHalo < own_hi;
                         uint32_t *p = tv.counters + (slot - tv.span_lo);
                         if (interior) *p = cv;
                         else if (cv) atomicAdd(p, cv);
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
                     old[st] = 0;
                     if (cv[st]) {
                         const uint64_t slot = seg_lo + i;
-                        const bool interior = slot >= own_lo + kHalo && slot + kHalo < own_hi;
+                        const bool interior = private_tile && slot >= own_lo + kHalo && slot + kHalo < own_hi;
                         uint32_t *p = tv.counters + (slot - tv.span_lo);
                         if (interior) old[st] = *p;
                         else { atomicAdd(p, cv[st]); cv[st] = 0; }
@@ -548,6 +551,30 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
     if (lane == 0) {
         atomicAdd(&stats->n_probes, n_probes);
         atomicAdd(&stats->n_hits, n_hits);
+    }
+}
+
+/* bucket_count flushes the interior of a bucket with plain stores, which is only right while no
+ * OTHER workgroup adds to those slots.  A walk visits one run of occupied slots plus the slot behind
+ * it; runs shorter than kHalo keep every walk inside the walker's own slice (own slots + halo),
+ * where the neighbour uses atomics.  A longer run lets walks go on into whatever it covers, so
+ * every bucket that holds a slot of such a run, or the slot before / behind it (k-mer 0 counts on
+ * the empty slot, :96-98), is marked SHARED: its whole tile is flushed with atomic adds.  Found once
+ * per context; bit 1 of *found: a run too long to follow (the direct kernel counts that table). */
+constexpr uint32_t kRunFollow = 1u << 20;
+__global__ void long_run_kernel(const uint64_t *keys, uint64_t H, uint32_t limit, uint32_t lg_s, uint32_t *shared,
+                                unsigned int *found)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < H; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (keys[i] == 0) continue;
+        if (i != 0 && keys[i - 1] != 0) continue;             /* not the start of a run */
+        uint64_t len = 1;
+        while (len < kRunFollow && i + len < H && keys[i + len] != 0) len++;
+        if (len < limit) continue;
+        if (len >= kRunFollow) { atomicOr(found, 2u); continue; }
+        atomicOr(found, 1u);
+        const uint64_t lo = (i ? i - 1 : 0) >> lg_s, hi = (i + len < H ? i + len : H - 1) >> lg_s;
+        for (uint64_t b = lo; b <= hi; b++) atomicOr(&shared[b >> 5], 1u << (b & 31));
     }
 }
 

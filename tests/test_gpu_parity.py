@@ -295,6 +295,47 @@ def test_skewed_input_spills_and_falls_back(qm2):
     assert exp_depth[z] == (12000 * 121) % 65536       # k-mer 0 lands on the empty slot (QuicKmer.c:96-98)
 
 
+def test_long_occupied_runs(qm2):
+    """bucket_count stages a bucket's slots plus a 256-slot halo and flushes the interior with plain
+    stores; that is only exact while no foreign probe walk reaches it.  A table with a longer run
+    of occupied slots (here: the gaps of a 300- and a 9000-slot stretch filled with keys no 30-mer
+    can equal, so that walks run on through two whole buckets) must still give the reference's
+    counts: the buckets such a run touches are flushed with atomics.  A run too long to follow
+    (1 M slots) sends the table to the direct kernel."""
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    ref = synth.kat_reference().tobytes()
+    rng = np.random.default_rng(81)
+    blob = b"".join(ref[int(p):int(p) + 150] + b"\n" for p in rng.integers(0, 4800, 6000))
+    H = len(qm["keys"])
+    for name, start, length in (("lower_half", H // 4, 300), ("upper_half", 3 * H // 4, 300),
+                                ("two_buckets_up", H // 8, 9000), ("two_buckets_down", 5 * H // 8, 9000)):
+        keys = qm["keys"].copy()
+        gap = np.flatnonzero(keys[start:start + length] == 0) + start
+        keys[gap] = (np.uint64(1) << np.uint64(62)) + gap.astype(np.uint64)      # > any 60-bit k-mer
+        exp_depth, exp_st = ol.count_lines(keys, 30, blob)
+        with qm2.Counter(keys, k=30, flags=qm2.FLAG_PARTITION | qm2.FLAG_TIMING) as c:
+            c.submit(blob)
+            c.submit(blob)
+            depth, st = c.finish()
+            prof = c.profile()
+        assert st == {a: 2 * v for a, v in exp_st.items()}, name
+        assert np.array_equal(depth, (2 * exp_depth.astype(np.uint32)).astype(np.uint16)), name
+        assert prof["partitioned_batches"] >= 1 and prof["direct_batches"] == 0, (name, prof)
+    # hopeless: one run of 2^20 + 10 slots -> direct kernel, same answer
+    H2 = 1 << 22
+    keys = np.zeros(H2, dtype=np.uint64)
+    run = np.arange(1000, 1000 + (1 << 20) + 10, dtype=np.uint64)
+    keys[run] = (np.uint64(1) << np.uint64(62)) + run
+    few = blob[:151 * 6]
+    exp_depth, exp_st = ol.count_lines(keys, 30, few)
+    with qm2.Counter(keys, k=30, flags=qm2.FLAG_PARTITION | qm2.FLAG_TIMING) as c:
+        c.submit(few)
+        depth, st = c.finish()
+        prof = c.profile()
+    assert st == exp_st and np.array_equal(depth, exp_depth)
+    assert prof["partitioned_batches"] == 0 and prof["direct_batches"] >= 1, prof
+
+
 # ---- 3. device-resident input, any alignment -----------------------------------
 
 def test_submit_device_unaligned(qm2, torch_cuda, tmp_path):
