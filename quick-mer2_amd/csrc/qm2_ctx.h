@@ -47,6 +47,7 @@ struct PartPlan {                           /* how a batch is radix-partitioned 
     uint64_t buckets[kMaxLevels] = {0, 0, 0};
     /* sized for `reserved` payload bytes */
     uint64_t reserved = 0;
+    uint64_t refused = 0;                   /* smallest batch whose buffers did not fit in HBM */
     uint32_t cap[kMaxLevels] = {0, 0, 0};
     uint64_t *buf[2] = {nullptr, nullptr};
     uint64_t  buf_slots[2] = {0, 0};
@@ -78,6 +79,13 @@ struct qm2_ctx {
     bool        own_counters = false;
     uint16_t   *narrow = nullptr;           /* H x u16 scratch for qm2_finish */
     qm2::DevStats *stats = nullptr;
+    /* k-mers per input byte seen so far (sizes bucket_count's group): the stats block is copied
+     * to pinned memory behind a batch now and then and read when that copy has landed */
+    qm2::DevStats *stats_peek = nullptr;
+    hipEvent_t  peek_evt = nullptr;
+    bool        peek_pending = false;
+    uint64_t    peek_bytes = 0, bytes_launched = 0;
+    double      kmers_per_byte = 1.0;
     hipStream_t stream = nullptr;           /* every kernel of this context runs here, in order */
     bool        own_stream = false;
     hipStream_t copy_stream = nullptr;      /* H2D staging copies */

@@ -174,6 +174,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     PartPlan &p = c->part;
     if (p.levels == 0) return 1;
     if (n <= p.reserved) return 0;
+    if (p.refused && n >= p.refused) return 1;                        /* did not fit before: do not try again */
     HIP_OK(hipStreamSynchronize(c->stream));                          /* buffers may be in use */
     const uint64_t want = std::max<uint64_t>(n + n / 16, 1u << 20);   /* grow with some slack */
     qm2_part_free(p);
@@ -181,11 +182,14 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     uint64_t slots[kMaxLevels] = {0, 0, 0};
     for (int l = 0; l < p.levels; l++) {
         mean /= (double)(1u << p.bits[l]);
-        /* expected fill + a margin that covers the Poisson spread of uniform hashing;
-         * skew beyond it goes to the spill list */
+        /* expected fill + room for skew (repeated k-mers all land in one child, so the room grows
+         * with depth: each level is sized from the capacity of the one above) + the Poisson spread
+         * of uniform hashing; what still does not fit goes to the spill list.  Sizing every level
+         * from the true mean instead saves 15 % of the memory but was measured 10 % slower in
+         * split_kmer (the bucket stride matters), so the compounding stays. */
         const double capd = mean * (l == 0 ? 1.12 : 1.22) + 8.0 * std::sqrt(mean + 1.0) + 128.0;
         if (capd > 4.0e9) return fail("qm2: batch too large for the partition plan");
-        p.cap[l] = ((uint32_t)capd + 63u) & ~63u;          /* whole sectors; covers the run padding too */
+        p.cap[l] = ((uint32_t)capd + 63u) & ~63u;          /* whole sectors */
         slots[l] = p.buckets[l] * (uint64_t)p.cap[l];
         mean = (double)p.cap[l];
     }
@@ -203,6 +207,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     if (e != hipSuccess) {
         (void)hipGetLastError();
         qm2_part_free(p);
+        p.refused = n;
         snprintf(g_err, sizeof g_err, "qm2: partition buffers for %llu bytes do not fit (%s)",
                  (unsigned long long)n, hipGetErrorString(e));
         return 1;
@@ -287,14 +292,38 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
         const int grid = (int)std::min<uint64_t>(n_buckets, (uint64_t)c->n_cu * 2 * QM2_COUNT_GRID_MULT);
         if (time_begin(c, &t, QM2_K_BUCKET_COUNT)) return 1;
         /* few k-mers per bucket (hg38-scale tables): the counter tile is fetched a bucket ahead with
-         * the key slice; many k-mers per bucket: the flush touches only the sectors that got counts */
-        const bool pipe = QM2_COUNT_PIPE == 2 ? sv.n_total / n_buckets < (2u << kLgS) : QM2_COUNT_PIPE != 0;
-        if (pipe)
-            hipLaunchKernelGGL((bucket_count_kernel<kLgS, true>), dim3(grid), dim3(kCountThreads), 0, s, p.buf[L & 1],
-                               p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, p.shared, c->stats);
-        else
-            hipLaunchKernelGGL((bucket_count_kernel<kLgS, false>), dim3(grid), dim3(kCountThreads), 0, s, p.buf[L & 1],
-                               p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, p.shared, c->stats);
+         * the key slice (PIPE), and the group size is picked so that a bucket's fill (mean + 3 sigma
+         * of uniform hashing) wastes the fewest 512-k-mer rows; many k-mers per bucket: the flush
+         * touches only the sectors that got counts, and the group size hardly matters */
+        if (c->peek_pending && hipEventQuery(c->peek_evt) == hipSuccess) {
+            c->peek_pending = false;
+            if (c->peek_bytes) c->kmers_per_byte = std::min(1.0, (double)c->stats_peek->n_kmers / (double)c->peek_bytes);
+        }
+        const uint64_t per_bucket = (uint64_t)((double)sv.n_total * c->kmers_per_byte) / n_buckets;
+        const bool pipe = QM2_COUNT_PIPE == 2 ? per_bucket < (2u << kLgS) : QM2_COUNT_PIPE != 0;
+        int g = 6;
+        if (pipe) {
+            const double fill = (double)per_bucket + 3.0 * std::sqrt((double)per_bucket + 1.0);
+            const int rows = std::max(1, (int)std::ceil(fill / kCountThreads));
+            int best_rows = 1 << 30;
+            for (int cand = 4; cand <= 8; cand++) {
+                const int run = (rows + cand - 1) / cand * cand;               /* rows executed */
+                if (run <= best_rows) { best_rows = run; g = cand; }           /* ties: the larger group */
+            }
+        }
+#define QM2_LAUNCH_COUNT(PIPE_, G_)                                                                             \
+        hipLaunchKernelGGL((bucket_count_kernel<kLgS, PIPE_, G_>), dim3(grid), dim3(kCountThreads), 0, s,      \
+                           p.buf[L & 1], p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, \
+                           p.shared, c->stats)
+        if (!pipe) QM2_LAUNCH_COUNT(false, 6);
+        else switch (g) {
+            case 4: QM2_LAUNCH_COUNT(true, 4); break;
+            case 5: QM2_LAUNCH_COUNT(true, 5); break;
+            case 6: QM2_LAUNCH_COUNT(true, 6); break;
+            case 7: QM2_LAUNCH_COUNT(true, 7); break;
+            default: QM2_LAUNCH_COUNT(true, 8); break;
+        }
+#undef QM2_LAUNCH_COUNT
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
     }
@@ -311,6 +340,12 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
     /* exact fallback, decided on the device: only if even the spill list overflowed */
     if (launch_direct(c, sv, &c->stats->part_lost, false, true)) return 1;
     hipLaunchKernelGGL(part_end_kernel, dim3(1), dim3(64), 0, s, c->stats);
+    if (!c->peek_pending && c->stats_peek) {
+        HIP_OK(hipMemcpyAsync(c->stats_peek, c->stats, sizeof(DevStats), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipEventRecord(c->peek_evt, s));
+        c->peek_pending = true;
+        c->peek_bytes = c->bytes_launched;
+    }
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -355,6 +390,7 @@ static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry,
     if (c->keys_consumed)
         return fail("qm2: the key table was overwritten by qm2_chain_gather; this context cannot count any more");
     const SeqView sv = seq_view(data, n, carry, d_sup, n_sup);
+    c->bytes_launched += n;
     bool part = (c->flags & QM2_FLAG_PARTITION) != 0 || ((uint64_t)n >= c->H / 8 && n >= (1u << 20));
     if (c->flags & QM2_FLAG_DIRECT) part = false;
     if (c->span_lo != 0 || c->span_hi != c->H) part = false;         /* shard spans: direct only */
@@ -461,13 +497,16 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
     OPEN_OK(hipMalloc((void **)&c->stats, sizeof(DevStats)));
     OPEN_OK(hipMemsetAsync(c->stats, 0, sizeof(DevStats), c->stream));
     OPEN_OK(hipStreamSynchronize(c->stream));
+    OPEN_OK(hipHostMalloc((void **)&c->stats_peek, sizeof(DevStats), hipHostMallocDefault));
+    OPEN_OK(hipEventCreateWithFlags(&c->peek_evt, hipEventDisableTiming));
 
     c->staging_bytes = o.staging_bytes ? (size_t)o.staging_bytes : ((size_t)64 << 20);
     if (c->staging_bytes < 64) c->staging_bytes = 64;
-    /* default device batch: one byte per table slot, 1..4 GiB — the partitioned pipeline streams the
-     * whole table once per batch, so batches should not be small against it */
+    /* default device batch: one byte per table slot, 1..6 GiB — the partitioned pipeline streams the
+     * whole table once per batch, so batches should not be small against it (hg38 scale: 64 G bases/s
+     * at 3 G bases per batch, 70 at 4.5 and 6) */
     c->batch_bytes = o.batch_bytes ? (size_t)o.batch_bytes
-                                   : (size_t)std::min<uint64_t>(std::max<uint64_t>(hash_size, 1ull << 30), 4ull << 30);
+                                   : (size_t)std::min<uint64_t>(std::max<uint64_t>(hash_size + hash_size / 2, 1ull << 30), 6ull << 30);
     if (c->batch_bytes < 64) c->batch_bytes = 64;
     c->slots.resize(o.n_staging ? std::max<uint32_t>(o.n_staging, 2) : 4);   /* allocated lazily */
     part_init(c, o.part_max_bits >= 1 && o.part_max_bits <= 8 ? (int)o.part_max_bits : 8);
@@ -500,6 +539,8 @@ extern "C" void qm2_close(qm2_ctx *c)
     if (c->own_counters && c->counters) (void)hipFree(c->counters);
     if (c->narrow) (void)hipFree(c->narrow);
     if (c->stats) (void)hipFree(c->stats);
+    if (c->stats_peek) (void)hipHostFree(c->stats_peek);
+    if (c->peek_evt) (void)hipEventDestroy(c->peek_evt);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -699,6 +740,8 @@ extern "C" int qm2_sync(qm2_ctx *c)
     HIP_OK(hipMemcpy(&st, c->stats, sizeof st, hipMemcpyDeviceToHost));
     if (st.overflow)
         return fail("qm2: %llu k-mers did not fit their exchange bucket", st.overflow);
+    c->peek_pending = false;
+    if (c->bytes_launched) c->kmers_per_byte = std::min(1.0, (double)st.n_kmers / (double)c->bytes_launched);
     return 0;
 }
 
@@ -731,6 +774,8 @@ extern "C" int qm2_reset(qm2_ctx *c)
     const uint64_t n_slots = c->span_hi - c->span_lo;
     HIP_OK(hipMemsetAsync(c->counters, 0, n_slots * sizeof(uint32_t), c->stream));
     HIP_OK(hipMemsetAsync(c->stats, 0, sizeof(DevStats), c->stream));
+    c->bytes_launched = 0;
+    c->peek_pending = false;
     HIP_OK(hipStreamSynchronize(c->stream));
     memset(&c->prof, 0, sizeof c->prof);
     return 0;

@@ -25,6 +25,7 @@
  * so the order inside buckets is irrelevant.
  */
 #pragma once
+#include <type_traits>
 #include "qm2_device.hip.h"
 
 namespace qm2 {
@@ -294,18 +295,8 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
  *      (resolves ~75 % at 53 % fill, ~99 % at 14 %);
  *   B  the unresolved ones are COMPACTED into a small per-wave LDS queue and probed on in
  *      dense rows, so the long tails of few k-mers no longer idle the other lanes. */
-#ifndef QM2_QUEUE_CAP
-#define QM2_QUEUE_CAP 160
-#endif
-#ifndef QM2_COUNT_GROUP
-#define QM2_COUNT_GROUP 6
-#endif
-#ifndef QM2_COUNT_GROUP_PIPE
-#define QM2_COUNT_GROUP_PIPE 5
-#endif
-constexpr int kQueueCap = QM2_QUEUE_CAP;    /* per wave; what does not fit is finished in place */
 
-template <int LG_S, bool PIPE>
+template <int LG_S, bool PIPE, int G>
 __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors,
                                                                      uint32_t cap, TableView tv, uint64_t H,
                                                                      uint32_t n_buckets, const uint32_t *shared,
@@ -316,17 +307,19 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
     constexpr int kWaves = kCountThreads / kWave;
     __shared__ uint64_t skey[S + kHalo];
     __shared__ uint32_t scnt[S + kHalo];
+    constexpr int kGroup = G;                         /* k-mers per thread per group */
+    constexpr int kQueueCap = 32 * G;                 /* per wave; what does not fit is finished in place */
     __shared__ uint64_t qk[kWaves][kQueueCap];
     __shared__ uint16_t qa[kWaves][kQueueCap];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    unsigned long long n_probes = 0, n_hits = 0;
+    uint32_t n_probes = 0, n_hits = 0;      /* per lane: < 2^32 for any batch that fits the plan */
 
     constexpr int kSteps = (S + kHalo + kCountThreads - 1) / kCountThreads;
-    constexpr int kGroup = PIPE ? QM2_COUNT_GROUP_PIPE : QM2_COUNT_GROUP;
 
     /* geometry of bucket b: own range, staged slice (own + kHalo slots on the side its probe
      * walks leave through, i.e. towards the middle of the table, :94-95), walk direction */
-    struct Geo { uint64_t own_lo, own_hi, seg_lo; uint32_t seg; bool down, shared; };
+    /* int_lo / int_len: the private interior in slice coordinates (i - int_lo < int_len, unsigned) */
+    struct Geo { uint64_t own_lo, own_hi, seg_lo; uint32_t seg, int_lo, int_len; bool down, shared; };
     auto geo = [&](uint32_t b) {
         Geo g;
         g.own_lo = (uint64_t)b << LG_S;
@@ -341,6 +334,9 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
         g.seg = (uint32_t)(hi - lo);
         /* a long run of occupied slots reaches into this bucket: nothing in it is private */
         g.shared = shared != nullptr && ((shared[b >> 5] >> (b & 31)) & 1u) != 0;
+        const uint32_t own_len = (uint32_t)(g.own_hi - g.own_lo);
+        g.int_lo = (uint32_t)(g.own_lo - lo) + kHalo;
+        g.int_len = !g.shared && own_len > 2u * kHalo ? own_len - 2u * kHalo : 0u;
         return g;
     };
     /* Software pipeline over the buckets of this workgroup (stride gridDim.x): everything bucket
@@ -354,18 +350,18 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
     auto fetch_slice = [&](uint32_t b) {
         if (b >= n_buckets) return;
         const Geo g = geo(b);
+        const uint64_t *kp = tv.keys + g.seg_lo;
 #pragma unroll
         for (int st = 0; st < kSteps; st++) {
             const uint32_t i = tid + st * kCountThreads;
-            kv[st] = i < g.seg ? tv.keys[g.seg_lo + i] : 0;
+            kv[st] = i < g.seg ? kp[i] : 0;
         }
         if constexpr (PIPE) {
+            const uint32_t *cp = tv.counters + (g.seg_lo - tv.span_lo);
 #pragma unroll
             for (int st = 0; st < kSteps; st++) {
                 const uint32_t i = tid + st * kCountThreads;
-                const uint64_t slot = g.seg_lo + i;
-                const bool interior = !g.shared && i < g.seg && slot >= g.own_lo + kHalo && slot + kHalo < g.own_hi;
-                ov[st] = interior ? tv.counters[slot - tv.span_lo] : 0;
+                ov[st] = i - g.int_lo < g.int_len ? cp[i] : 0;
             }
         }
     };
@@ -390,9 +386,11 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
     for (uint32_t b = blockIdx.x; b < n_buckets; b += stride) {
         const uint32_t n = PIPE ? n_next : fill_of(b);
         const Geo g = geo(b);
-        const uint64_t own_lo = g.own_lo, own_hi = g.own_hi, seg_lo = g.seg_lo;
+        const uint64_t seg_lo = g.seg_lo;
         const uint32_t seg = g.seg;
-        const bool down = g.down, private_tile = !g.shared;
+        const bool down = g.down;
+        const uint32_t int_lo = g.int_lo, int_len = g.int_len;
+        uint32_t *const cp = tv.counters + (seg_lo - tv.span_lo);
         /* the counter tile starts from the old values of the interior (0 elsewhere), so the LDS
          * atomics accumulate straight onto them */
 #pragma unroll
@@ -454,47 +452,53 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
                 const uint32_t i = base + kGroup * kCountThreads + j;
                 nq[q] = last ? (j < n_next ? in_next[j] : kPad) : (i < n ? in[i] : kPad);
             }
-            /* ---- phase A: two slots per k-mer, no loop ---- */
+            /* ---- phase A: two slots per k-mer, no loop.  All kGroup rows run as one straight-line
+             * block even when the last ones hold no k-mer: skipping rows (a branch per row, or one
+             * block per row count) was measured 12 % SLOWER, so the host picks kGroup to fit the
+             * bucket fill instead. ---- */
             uint32_t queued = 0;                                            /* wave-uniform */
+            auto phase_a = [&]() {
 #pragma unroll
-            for (int q = 0; q < kGroup; q++) {
-                const uint64_t km = kq[q];
-                const bool live = km != kPad;
-                const uint32_t home = djb32(km) & tv.hmask;                    /* :92 */
-                /* H <= S: the single bucket holds both halves, direction per k-mer */
-                const bool dn = H > (uint64_t)S ? down : (home & tv.hhalf) != 0;
-                const int32_t at0 = live ? (int32_t)((uint64_t)home - seg_lo) : 0;
-                const int32_t at1 = at0 + (dn ? -1 : 1);
-                const bool in1 = at1 >= 0 && at1 < (int32_t)seg;
-                const uint64_t v0 = skey[at0];
-                const uint64_t v1 = skey[in1 ? at1 : at0];
-                const bool hit0 = live && v0 == km;                          /* :98 */
-                const bool end0 = hit0 || v0 == 0;
-                const bool hit1 = live && !end0 && in1 && v1 == km;
-                const bool end1 = end0 || (in1 && (hit1 || v1 == 0));
-                if (hit0) atomicAdd(&scnt[at0], 1u);                          /* :291 */
-                if (hit1) atomicAdd(&scnt[at1], 1u);
-                n_hits += (hit0 || hit1) ? 1 : 0;
-                const bool more = live && !end1;       /* both occupied by other keys, or at1 outside */
-                n_probes += live ? (end0 ? 1u : (end1 ? 2u : 0u)) : 0u;   /* unresolved: walk() adds the total */
-                /* unresolved: compact into this wave's queue; entry = position to look at next,
-                 * direction, and how many slots were counted so far */
-                const unsigned long long m = __ballot(more);
-                if (m) {
-                    const uint32_t slot = queued + __popcll(m & ((1ull << lane) - 1));
-                    const int32_t nxt = in1 ? at1 + (dn ? -1 : 1) : at1;
-                    const uint32_t seen = in1 ? 2u : 1u;
-                    if (more) {
-                        if (slot < (uint32_t)kQueueCap) {
-                            qk[wave][slot] = km;
-                            qa[wave][slot] = (uint16_t)((uint32_t)(nxt + 1) | (dn ? 0x2000u : 0u) | ((seen - 1) << 14));
-                        } else {
-                            walk(km, nxt, dn, seen);             /* queue full: finish in place */
+                for (int q = 0; q < kGroup; q++) {
+                    const uint64_t km = kq[q];
+                    const bool live = km != kPad;
+                    const uint32_t home = djb32(km) & tv.hmask;                    /* :92 */
+                    /* H <= S: the single bucket holds both halves, direction per k-mer */
+                    const bool dn = H > (uint64_t)S ? down : (home & tv.hhalf) != 0;
+                    const int32_t at0 = live ? (int32_t)((uint64_t)home - seg_lo) : 0;
+                    const int32_t at1 = at0 + (dn ? -1 : 1);
+                    const bool in1 = at1 >= 0 && at1 < (int32_t)seg;
+                    const uint64_t v0 = skey[at0];
+                    const uint64_t v1 = skey[in1 ? at1 : at0];
+                    const bool hit0 = live && v0 == km;                          /* :98 */
+                    const bool end0 = hit0 || v0 == 0;
+                    const bool hit1 = live && !end0 && in1 && v1 == km;
+                    const bool end1 = end0 || (in1 && (hit1 || v1 == 0));
+                    if (hit0) atomicAdd(&scnt[at0], 1u);                          /* :291 */
+                    if (hit1) atomicAdd(&scnt[at1], 1u);
+                    n_hits += (hit0 || hit1) ? 1 : 0;
+                    const bool more = live && !end1;       /* both occupied by other keys, or at1 outside */
+                    n_probes += live ? (end0 ? 1u : (end1 ? 2u : 0u)) : 0u;   /* unresolved: walk() adds the total */
+                    /* unresolved: compact into this wave's queue; entry = position to look at next,
+                     * direction, and how many slots were counted so far */
+                    const unsigned long long m = __ballot(more);
+                    if (m) {
+                        const uint32_t slot = queued + __popcll(m & ((1ull << lane) - 1));
+                        const int32_t nxt = in1 ? at1 + (dn ? -1 : 1) : at1;
+                        const uint32_t seen = in1 ? 2u : 1u;
+                        if (more) {
+                            if (slot < (uint32_t)kQueueCap) {
+                                qk[wave][slot] = km;
+                                qa[wave][slot] = (uint16_t)((uint32_t)(nxt + 1) | (dn ? 0x2000u : 0u) | ((seen - 1) << 14));
+                            } else {
+                                walk(km, nxt, dn, seen);             /* queue full: finish in place */
+                            }
                         }
+                        queued += __popcll(m);
                     }
-                    queued += __popcll(m);
                 }
-            }
+            };
+            phase_a();
             /* ---- phase B: dense rows over the compacted queue ---- */
             const uint32_t qn = queued < (uint32_t)kQueueCap ? queued : (uint32_t)kQueueCap;
             for (uint32_t e = lane; e < qn; e += kWave) {
@@ -516,11 +520,8 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
                     const uint32_t i = tid + st * kCountThreads;
                     if (i < seg) {
                         const uint32_t cv = scnt[i];
-                        const uint64_t slot = seg_lo + i;
-                        const bool interior = private_tile && slot >= own_lo + kHalo && slot + kHalo < own_hi;
-                        uint32_t *p = tv.counters + (slot - tv.span_lo);
-                        if (interior) *p = cv;
-                        else if (cv) atomicAdd(p, cv);
+                        if (i - int_lo < int_len) cp[i] = cv;
+                        else if (cv) atomicAdd(cp + i, cv);
                     }
                 }
             } else {
@@ -533,24 +534,21 @@ __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4
                     cv[st] = i < seg ? scnt[i] : 0;
                     old[st] = 0;
                     if (cv[st]) {
-                        const uint64_t slot = seg_lo + i;
-                        const bool interior = private_tile && slot >= own_lo + kHalo && slot + kHalo < own_hi;
-                        uint32_t *p = tv.counters + (slot - tv.span_lo);
-                        if (interior) old[st] = *p;
-                        else { atomicAdd(p, cv[st]); cv[st] = 0; }
+                        if (i - int_lo < int_len) old[st] = cp[i];
+                        else { atomicAdd(cp + i, cv[st]); cv[st] = 0; }
                     }
                 }
 #pragma unroll
                 for (int st = 0; st < kSteps; st++)
-                    if (cv[st]) tv.counters[seg_lo + tid + st * kCountThreads - tv.span_lo] = old[st] + cv[st];
+                    if (cv[st]) cp[tid + st * kCountThreads] = old[st] + cv[st];
             }
         }
         lds_barrier();
     }
-    n_probes = wave_sum(n_probes); n_hits = wave_sum(n_hits);
+    const unsigned long long w_probes = wave_sum((unsigned long long)n_probes), w_hits = wave_sum((unsigned long long)n_hits);
     if (lane == 0) {
-        atomicAdd(&stats->n_probes, n_probes);
-        atomicAdd(&stats->n_hits, n_hits);
+        atomicAdd(&stats->n_probes, w_probes);
+        atomicAdd(&stats->n_hits, w_hits);
     }
 }
 
