@@ -26,6 +26,7 @@
 #include <pthread.h>
 #include <semaphore.h>
 #include <sched.h>
+#include <stdatomic.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -222,9 +223,9 @@ typedef struct pf_shared {
     size_t  size, start;                   /* start: first byte after the consumed FASTQ header (or 0) */
     size_t  n_blocks;
     int     fastq;
-    volatile size_t *lines_before;         /* [n_blocks + 1], filled in block order */
-    volatile int    *known;                /* lines_before[b] is valid */
-    volatile int     stop;
+    size_t     *lines_before;              /* [n_blocks + 1], filled in block order; published through known[] */
+    atomic_int *known;                     /* lines_before[b] is valid (release / acquire) */
+    atomic_int  stop;
 } pf_shared;
 
 typedef struct {
@@ -323,17 +324,16 @@ static void *pf_main(void *arg)
         if (w->quit) return NULL;
         const size_t b = w->block;
         w->olen = 0; w->too_big = 0;
-        w->rc = sh->stop ? 0 : pf_load(w);
-        if (w->rc || sh->stop) w->lo = w->hi = 0;
+        w->rc = atomic_load(&sh->stop) ? 0 : pf_load(w);
+        if (w->rc || atomic_load(&sh->stop)) w->lo = w->hi = 0;
         size_t lines = count_newlines(w->raw + w->lo, w->hi - w->lo);
         if (w->hi > w->lo && w->raw[w->hi - 1] != '\n') lines++;       /* last line of the file, no newline */
-        while (!sh->known[b] && !sh->stop) sched_yield();
+        while (!atomic_load_explicit(&sh->known[b], memory_order_acquire) && !atomic_load(&sh->stop)) sched_yield();
         w->before = sh->lines_before[b];
         sh->lines_before[b + 1] = w->before + lines;
-        __sync_synchronize();
-        sh->known[b + 1] = 1;
+        atomic_store_explicit(&sh->known[b + 1], 1, memory_order_release);
         line_state st = pf_state(sh, w->before);
-        if (!sh->stop && !w->rc) {
+        if (!atomic_load(&sh->stop) && !w->rc) {
             if (w->hi - w->lo + 1 > w->ocap) w->too_big = 1;          /* more than a staging buffer holds */
             else {
                 static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL};
@@ -408,13 +408,13 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
     const size_t body = size - sh.start;
     sh.n_blocks = (body + QM2_BLOCK - 1) / QM2_BLOCK;
     sh.lines_before = calloc(sh.n_blocks + 2, sizeof(size_t));
-    sh.known = calloc(sh.n_blocks + 2, sizeof(int));
+    sh.known = calloc(sh.n_blocks + 2, sizeof(atomic_int));
     pf_worker *ws = calloc((size_t)n_threads, sizeof *ws);
     pthread_t *tids = calloc((size_t)n_threads, sizeof *tids);
     if (!sh.lines_before || !sh.known || !ws || !tids) { puts("Memory allocation failed"); rc = 1; }
     int n_workers = 0;
     if (!rc) {
-        sh.known[0] = 1;
+        atomic_store(&sh.known[0], 1);
         for (int w = 0; w < n_threads && (size_t)w < sh.n_blocks; w++) {
             ws[w].sh = &sh;
             ws[w].raw_cap = QM2_BLOCK + (1u << 17);
@@ -453,7 +453,7 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
             if (strip_range(w->raw + w->lo, w->hi - w->lo, &st, &os)) rc = 1;
             if (!rc && out_flush(&os)) rc = 1;
             if (st.desync) {
-                sh.stop = 1;
+                atomic_store(&sh.stop, 1);
                 serial_from_here = 1;
                 serial_lo = w->file_hi;
                 tail = st;
@@ -480,7 +480,7 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
         sem_destroy(&ws[w].done);
         free(ws[w].raw);
     }
-    free((void *)sh.lines_before); free((void *)sh.known); free(ws); free(tids);
+    free(sh.lines_before); free(sh.known); free(ws); free(tids);
     return rc;
 }
 
