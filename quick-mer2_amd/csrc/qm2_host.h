@@ -54,5 +54,6 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads);
 
 /* ---- the command ----------------------------------------------------------- */
 int qm2_main_count(int argc, char **argv);
+int qm2_main_est(int argc, char **argv);      /* qm2_est.c: QuicKmer.c:555-685 */
 
 #endif
