@@ -20,9 +20,11 @@
  *                       if even the spill list overflowed
  *
  * Exactness: every emitted k-mer lands in exactly one finest bucket or in the
- * spill list, and is probed exactly once under the reference's rule (a walk
- * longer than the staged halo finishes in global memory); integer adds commute,
- * so the order inside buckets is irrelevant.
+ * spill list, and is probed exactly once under the reference's rule; integer
+ * adds commute, so the order inside buckets is irrelevant.  A walk longer than
+ * the staged halo finishes in global memory; the buckets such a walk can reach
+ * (found once per table by long_run_kernel) give up their plain-store flush for
+ * atomics, so nothing it adds is overwritten.
  */
 #pragma once
 #include <type_traits>
@@ -294,13 +296,18 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
  *   A  straight-line: the home slot and the one after it are inspected for every k-mer
  *      (resolves ~75 % at 53 % fill, ~99 % at 14 %);
  *   B  the unresolved ones are COMPACTED into a small per-wave LDS queue and probed on in
- *      dense rows, so the long tails of few k-mers no longer idle the other lanes. */
-
+ *      dense rows, so the long tails of few k-mers no longer idle the other lanes.
+ *
+ * Template parameters (chosen per launch by launch_partitioned):
+ *   PIPE  few k-mers per bucket (hg38-scale tables): the counter tile is prefetched with the
+ *         key slice a bucket ahead and stored back plainly; otherwise the tile starts at zero
+ *         and only the sectors that got counts are read and written at flush time;
+ *   G     rows of kCountThreads k-mers per group (each thread holds G k-mers in registers).
+ * Two workgroups per CU (LDS), 4 waves per SIMD: the register budget is 128 VGPRs. */
 template <int LG_S, bool PIPE, int G>
-__global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors,
-                                                                     uint32_t cap, TableView tv, uint64_t H,
-                                                                     uint32_t n_buckets, const uint32_t *shared,
-                                                                     DevStats *stats)
+__global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_t cap, TableView tv, uint64_t H,
+                         uint32_t n_buckets, const uint32_t *shared, DevStats *stats)
 {
     if (stats->part_lost != 0) return;       /* this batch is recounted by the direct kernel */
     constexpr int S = 1 << LG_S;

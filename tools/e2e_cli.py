@@ -21,7 +21,14 @@ from bench import genome_layout  # noqa: E402
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 work = sys.argv[2] if len(sys.argv) > 2 else "/tmp/qm2_e2e"
 os.makedirs(work, exist_ok=True)
-n, H, k = 50_818_468, 1 << 28, 30
+scale = sys.argv[3] if len(sys.argv) > 3 else "c2"
+n, H, k = (3_100_000_000, 1 << 32, 30) if scale == "c3" else (50_818_468, 1 << 28, 30)
+if scale == "c3":                        # 51 GB .qm + reads + 4.5 GB .bin must fit on the scratch disk
+    import shutil
+    free = shutil.disk_usage(work).free
+    print("scratch disk free: %.0f GB" % (free / 1e9), flush=True)
+    if free < 70e9:
+        sys.exit("not enough scratch space for the hg38-scale run")
 genome = torch.empty(n, dtype=torch.uint8, device="cuda")
 n_blocks, dups, covered = genome_layout(n)
 pyqm2.tools.genome_generate(genome.data_ptr(), n, seed=22, n_blocks=n_blocks, dups=dups)
@@ -56,18 +63,21 @@ fq[:, 156:306] = ord("I")
 fq[:, 306] = 10
 fq = fq[:, :307]
 fq.tofile(os.path.join(work, "reads.fq"))
-fa = np.empty((n_reads, 2 + 151), dtype=np.uint8)
+fa = np.empty((n_reads if scale != "c3" else 1, 2 + 151), dtype=np.uint8)      # (c3: scratch space is tight, FASTQ only)
 fa[:, 0:2] = np.frombuffer(b">\n", dtype=np.uint8)
-fa[:, 2:] = arr
+fa[:, 2:] = arr[:len(fa)]
 fa.tofile(os.path.join(work, "reads.fa"))
 print("wrote reads (fq %.1f GB, fa %.1f GB) in %.1f s" % (fq.nbytes / 1e9, fa.nbytes / 1e9, time.time() - t), flush=True)
 del fq, fa, arr, lines
 cli = os.path.join(ROOT, "quick-mer2_amd", "quicKmer2")
 import re
 runs = [(f, t, e) for f in ("reads.fq", "reads.fa") for t, e in (("4", {"QM2_READER_STREAM": "1"}), ("4", {}), ("8", {}), ("12", {}))]
+reps = 4
+if scale == "c3":
+    runs, reps = [("reads.fq", "8", {})], 2
 for name, thr, extra in runs:
     best, walls = None, []
-    for rep in range(4):
+    for rep in range(reps):
         t = time.time()
         r = subprocess.run([cli, "count", "-t", thr, os.path.join(work, "ref.fa"), os.path.join(work, name), os.path.join(work, "out")],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, QM2_TIMING="1", **extra))
@@ -76,6 +86,6 @@ for name, thr, extra in runs:
         m = re.search(r"QM2 phase count ([0-9.]+) s", out)
         sec = float(m.group(1)) if m else float("nan")
         best = sec if best is None else min(best, sec)
-    print("== %s -t %s %s rc=%d  count phase best of 4: %.3f s = %.2f G bases/s; wall best %.2f s (incl. .qm load, upload, epilogue)" %
+    print("== %s -t %s %s rc=%d  count phase best: %.3f s = %.2f G bases/s; wall best %.2f s (incl. .qm load, upload, epilogue)" %
           (name, thr, "stream" if extra else "blocks", r.returncode, best, n_reads * 150 / best / 1e9, min(walls)), flush=True)
 print(out)
