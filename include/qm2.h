@@ -59,6 +59,8 @@ typedef struct qm2_ctx qm2_ctx;
 #define QM2_FLAG_PARTITION   0x8u  /* always use the partitioned pipeline (radix-
                                       partition by home slot, probe + count in LDS);
                                       default: chosen per batch from its size vs. H   */
+#define QM2_FLAG_KEYS_LATER  0x10u /* qm2_open(keys = NULL): allocate the device key
+                                      table but fill it later with qm2_keys_from_fd   */
 
 typedef struct {
     uint32_t struct_size;     /* = sizeof(qm2_opts); 0-filled fields = defaults  */
@@ -212,6 +214,17 @@ int qm2_probe_device(qm2_ctx *c, const uint64_t *d_kmers, uint64_t n,
  * context owns it: after qm2_chain_gather the context cannot count any more. */
 int qm2_chain_gather(qm2_ctx *c, const uint32_t *chain, uint64_t first_idx, uint64_t *n_out);
 int qm2_chain_fetch(qm2_ctx *c, uint16_t *out, uint64_t offset, uint64_t count);
+
+/* Straight from the .qm file to the device (QuicKmer.c:353-359 and :483 without the 32 GiB
+ * host array the reference mallocs at :353): the key table / the chain are read from `fd` at
+ * `file_offset` by several threads into pinned buffers and copied up as they arrive.
+ *   qm2_keys_from_fd     fills the key table of a context opened with QM2_FLAG_KEYS_LATER
+ *                        (H x u64, the .qm at offset 24); counting before it is an error.
+ *   qm2_chain_gather_fd  = qm2_chain_gather with the chain (H x u32, offset 24 + 8H) read
+ *                        from the file.
+ * A file that ends early is an error ("... truncated"). */
+int qm2_keys_from_fd(qm2_ctx *c, int fd, uint64_t file_offset);
+int qm2_chain_gather_fd(qm2_ctx *c, int fd, uint64_t file_offset, uint64_t first_idx, uint64_t *n_out);
 
 /* Pure host helper (no device needed): the slot range shard g of n_shards
  * OWNS, [*own_lo, *own_hi) = [g*H/G, (g+1)*H/G), and the range it must hold,

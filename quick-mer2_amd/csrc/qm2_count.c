@@ -56,27 +56,27 @@ int qm2_main_count(int argc, char **argv)
     const int timing = getenv("QM2_TIMING") != NULL;   /* extra phase lines; off by default so that
                                                           stdout stays the reference's */
     struct timespec ta, tb;
-    clock_gettime(CLOCK_MONOTONIC, &ta);
     qm2_dict_file d;
     if (qm2_dict_open(ref_prefix, &d)) return 1;
-    clock_gettime(CLOCK_MONOTONIC, &tb);
-    if (timing) printf("QM2 phase load-dictionary %.3f s\n", (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec));
     if (d.k < 1 || d.k > 31) {
         printf("Dictionary k=%u is not supported (1..31)\n", d.k);
         qm2_dict_close(&d);
         return 1;
     }
-    /* (the reference's Kmer_depth, :360, lives on the device: qm2_open allocates and zeroes it) */
+    /* (the reference's Kmer_hash and Kmer_depth, :353 and :360, live on the device: qm2_open allocates
+     * both and zeroes the counters; the keys are streamed from the file, never held on the host) */
     qm2_ctx *ctx = NULL;
     qm2_opts o;
     memset(&o, 0, sizeof o);
     o.struct_size = sizeof o;
     o.device = -1;
+    o.flags = QM2_FLAG_KEYS_LATER;
     o.n_staging = (uint32_t)n_strip + 3;
     clock_gettime(CLOCK_MONOTONIC, &ta);
-    if (qm2_open(&ctx, d.keys, d.hash_size, d.k, &o)) { qm2_dict_close(&d); return 1; }
+    if (qm2_open(&ctx, NULL, d.hash_size, d.k, &o)) { qm2_dict_close(&d); return 1; }
+    if (qm2_dict_load_keys(&d, ctx)) { qm2_close(ctx); qm2_dict_close(&d); return 1; }
     clock_gettime(CLOCK_MONOTONIC, &tb);
-    if (timing) printf("QM2 phase upload-dictionary %.3f s\n", (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec));
+    if (timing) printf("QM2 phase load-dictionary %.3f s (file -> device)\n", (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec));
 
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);                      /* :386-387 */

@@ -75,6 +75,7 @@ struct qm2_ctx {
     uint64_t   *keys = nullptr;
     bool        own_keys = false;
     bool        keys_consumed = false;      /* the chain was uploaded over the key table */
+    bool        keys_pending = false;       /* QM2_FLAG_KEYS_LATER: qm2_keys_from_fd has not run yet */
     uint32_t   *counters = nullptr;
     bool        own_counters = false;
     uint16_t   *narrow = nullptr;           /* H x u16 scratch for qm2_finish */
@@ -109,6 +110,8 @@ struct qm2_ctx {
 
 int qm2_fail(const char *fmt, ...);         /* sets qm2_last_error(), prints, returns 1 */
 void qm2_part_free(qm2::PartPlan &p);
+/* qm2_io.hip: nbytes of `fd` from `off` -> device memory `dst`, read by several threads through pinned buffers */
+int qm2_stream_fd(qm2_ctx *c, int fd, uint64_t off, void *dst, uint64_t nbytes, const char *what);
 
 #define HIP_OK(call)                                                              \
     do {                                                                          \

@@ -88,9 +88,12 @@ __global__ void walk_gather_kernel(ChainView cv, const uint64_t *base, uint64_t 
 
 }  // namespace
 
-extern "C" int qm2_chain_gather(qm2_ctx *c, const uint32_t *chain, uint64_t first_idx, uint64_t *n_out)
+/* the chain comes either from host memory (`chain`) or from a file (`fd` at `file_offset`) */
+static int chain_gather(qm2_ctx *c, const uint32_t *chain, int fd, uint64_t file_offset, uint64_t first_idx,
+                        uint64_t *n_out)
 {
-    if (!c || !chain) return qm2_fail("qm2_chain_gather: null argument");
+    if (!c || (!chain && fd < 0)) return qm2_fail("qm2_chain_gather: null argument");
+    if (c->keys_pending) return qm2_fail("qm2_chain_gather: the key table has not been loaded yet");
     if (c->span_lo != 0 || c->span_hi != c->H) return qm2_fail("qm2_chain_gather: needs the whole table");
     if (c->keys_consumed) return qm2_fail("qm2_chain_gather: already done for this context");
     if (qm2_sync(c)) return 1;
@@ -137,7 +140,11 @@ extern "C" int qm2_chain_gather(qm2_ctx *c, const uint32_t *chain, uint64_t firs
         HIP_OK(hipMalloc((void **)&c->chain, H * sizeof(uint32_t)));
         c->own_chain = true;
     }
-    HIP_OK(hipMemcpy(c->chain, chain, H * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (chain) HIP_OK(hipMemcpy(c->chain, chain, H * sizeof(uint32_t), hipMemcpyHostToDevice));
+    else if (qm2_stream_fd(c, fd, file_offset, c->chain, H * sizeof(uint32_t), "Dictionary chain")) {
+        (void)hipFree(d_valid); (void)hipFree(d_len); (void)hipFree(d_succ); (void)hipFree(d_base); (void)hipFree(d_bad);
+        return 1;
+    }
     cv.next = c->chain;
 
     /* 3. sub-list lengths */
@@ -183,6 +190,18 @@ extern "C" int qm2_chain_gather(qm2_ctx *c, const uint32_t *chain, uint64_t firs
     }
     (void)hipFree(d_valid); (void)hipFree(d_len); (void)hipFree(d_succ); (void)hipFree(d_base); (void)hipFree(d_bad);
     return rc;
+}
+
+extern "C" int qm2_chain_gather(qm2_ctx *c, const uint32_t *chain, uint64_t first_idx, uint64_t *n_out)
+{
+    if (!chain) return qm2_fail("qm2_chain_gather: null argument");
+    return chain_gather(c, chain, -1, 0, first_idx, n_out);
+}
+
+extern "C" int qm2_chain_gather_fd(qm2_ctx *c, int fd, uint64_t file_offset, uint64_t first_idx, uint64_t *n_out)
+{
+    if (fd < 0) return qm2_fail("qm2_chain_gather_fd: bad file descriptor");
+    return chain_gather(c, nullptr, fd, file_offset, first_idx, n_out);
 }
 
 extern "C" int qm2_chain_fetch(qm2_ctx *c, uint16_t *out, uint64_t offset, uint64_t count)

@@ -5,6 +5,7 @@
 #define _GNU_SOURCE
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include "qm2_host.h"
 
@@ -43,36 +44,35 @@ int qm2_dict_open(const char *ref_prefix, qm2_dict_file *d)
         qm2_dict_close(d);
         return 1;
     }
-    d->keys = malloc(H * sizeof(uint64_t));                  /* :353 */
-    if (!d->keys) {
-        puts("Memory allocation failed");                    /* :355 */
-        qm2_dict_close(d);
-        return 1;
-    }
-    d->keys_read = fread(d->keys, sizeof(uint64_t), H, d->fp);
-    printf("Read 0x%lX hash\n", (unsigned long)d->keys_read);/* :359 */
-    if (d->keys_read != H) {
-        puts("Dictionary file is truncated");
-        qm2_dict_close(d);
-        return 1;
-    }
+    return 0;
+}
+
+int qm2_dict_load_keys(qm2_dict_file *d, qm2_ctx *ctx)
+{
+    /* :353-359 without the host array: file -> pinned pieces -> device */
+    if (qm2_keys_from_fd(ctx, fileno(d->fp), 24)) return 1;                      /* says "... truncated" itself */
+    printf("Read 0x%lX hash\n", (unsigned long)d->hash_size);                    /* :359 */
     return 0;
 }
 
 void qm2_dict_close(qm2_dict_file *d)
 {
     if (d->fp) fclose(d->fp);
-    free(d->keys);
     d->fp = NULL;
-    d->keys = NULL;
 }
 
 int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, const char *out_prefix)
 {
     const uint64_t H = d->hash_size;
-    /* the key buffer is dead now: the chain is read over it (:483, :490) */
-    uint32_t *chain = (uint32_t *)d->keys;
-    size_t got = fread(chain, sizeof(uint32_t), H, d->fp);
+    /* :483 prints how many chain entries the file gave; the read itself happens inside
+     * qm2_chain_gather_fd, so the count comes from the file size */
+    uint64_t got = H;
+    struct stat sb;
+    if (fstat(fileno(d->fp), &sb) == 0 && S_ISREG(sb.st_mode)) {
+        const uint64_t chain_at = 24 + H * sizeof(uint64_t);
+        const uint64_t have = (uint64_t)sb.st_size > chain_at ? ((uint64_t)sb.st_size - chain_at) / sizeof(uint32_t) : 0;
+        if (have < got) got = have;
+    }
     printf("Pileup finish\nRead chain file %lu entries\n", (unsigned long)got);   /* :483 */
     if (got != H) { puts("Dictionary chain is truncated"); return 1; }
 
@@ -85,9 +85,10 @@ int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, co
     FILE *qgc = fopen(path, "rb");
     if (!qgc) printf("GC control file %s absent. Continue without GC correction!\n", path); /* :488 */
 
-    /* the walk of :494-516, as a parallel list ranking on the device */
+    /* the chain goes from the file to where the dead key table was on the device (:483, :490);
+     * the walk of :494-516 is a parallel list ranking there */
     uint64_t n_entries = 0;
-    if (qm2_chain_gather(ctx, chain, d->first_idx, &n_entries)) {
+    if (qm2_chain_gather_fd(ctx, fileno(d->fp), 24 + H * sizeof(uint64_t), d->first_idx, &n_entries)) {
         if (qgc) fclose(qgc);
         free(path);
         return 1;

@@ -389,6 +389,7 @@ static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry,
     if (n == 0) return 0;
     if (c->keys_consumed)
         return fail("qm2: the key table was overwritten by qm2_chain_gather; this context cannot count any more");
+    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
     const SeqView sv = seq_view(data, n, carry, d_sup, n_sup);
     c->bytes_launched += n;
     bool part = (c->flags & QM2_FLAG_PARTITION) != 0 || ((uint64_t)n >= c->H / 8 && n >= (1u << 20));
@@ -428,7 +429,7 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
                     (unsigned long long)hash_size);
     if (k < 1 || k > 31)
         return fail("qm2_open: k-mer size %u unsupported (1..31; k=32 is undefined in the reference)", k);
-    if (!keys && !o.ext_keys) return fail("qm2_open: no keys given");
+    if (!keys && !o.ext_keys && !(o.flags & QM2_FLAG_KEYS_LATER)) return fail("qm2_open: no keys given");
     if ((o.flags & QM2_FLAG_DIRECT) && (o.flags & QM2_FLAG_PARTITION))
         return fail("qm2_open: QM2_FLAG_DIRECT and QM2_FLAG_PARTITION exclude each other");
 
@@ -484,7 +485,8 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
     else {
         OPEN_OK(hipMalloc((void **)&c->keys, n_slots * sizeof(uint64_t)));
         c->own_keys = true;
-        OPEN_OK(hipMemcpy(c->keys, keys, n_slots * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (keys) OPEN_OK(hipMemcpy(c->keys, keys, n_slots * sizeof(uint64_t), hipMemcpyHostToDevice));
+        else c->keys_pending = true;                          /* QM2_FLAG_KEYS_LATER */
     }
     if (o.ext_counters) c->counters = (uint32_t *)o.ext_counters;
     else {
@@ -646,6 +648,7 @@ static int submit_lines(qm2_ctx *c, const char *buf, size_t n, Slot *owner);
 extern "C" int qm2_submit(qm2_ctx *c, const char *buf, size_t n)
 {
     if (!c) return fail("qm2_submit: null context");
+    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
     if (n == 0) return 0;
     if (!buf) return fail("qm2_submit: null buffer");
     if (buf[n - 1] != '\n')
@@ -684,6 +687,7 @@ static int submit_lines(qm2_ctx *c, const char *buf, size_t n, Slot *owner)
 extern "C" int qm2_staging_acquire(qm2_ctx *c, char **buf, size_t *capacity)
 {
     if (!c || !buf || !capacity) return fail("qm2_staging_acquire: null argument");
+    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
     if (use_device(c)) return 1;
     size_t lent = 0;
     for (auto &s : c->slots) lent += s.lent ? 1 : 0;
@@ -720,10 +724,23 @@ extern "C" int qm2_submit_device(qm2_ctx *c, const void *d_seq, size_t n, const 
                                  uint64_t n_sup)
 {
     if (!c) return fail("qm2_submit_device: null context");
+    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
     if (n == 0) return 0;
     if (!d_seq) return fail("qm2_submit_device: null buffer");
     if (use_device(c)) return 1;
     return launch_batch(c, (const uint8_t *)d_seq, n, 0, d_sup, n_sup);
+}
+
+extern "C" int qm2_keys_from_fd(qm2_ctx *c, int fd, uint64_t file_offset)
+{
+    if (!c) return fail("qm2_keys_from_fd: null context");
+    if (!c->keys_pending) return fail("qm2_keys_from_fd: the context was not opened with QM2_FLAG_KEYS_LATER (or is loaded already)");
+    if (use_device(c)) return 1;
+    const uint64_t n_slots = c->span_hi - c->span_lo;
+    if (qm2_stream_fd(c, fd, file_offset + c->span_lo * sizeof(uint64_t), c->keys, n_slots * sizeof(uint64_t), "Dictionary file"))
+        return 1;
+    c->keys_pending = false;
+    return 0;
 }
 
 extern "C" int qm2_sync(qm2_ctx *c)
@@ -825,6 +842,7 @@ extern "C" int qm2_probe_device(qm2_ctx *c, const uint64_t *d_kmers, uint64_t n,
     if (!c) return fail("qm2_probe_device: null context");
     if (n == 0) return 0;
     if (!d_kmers) return fail("qm2_probe_device: null buffer");
+    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
     if (use_device(c)) return 1;
     const uint64_t groups = (n + (uint64_t)kWave * kNJ - 1) / ((uint64_t)kWave * kNJ);
     const int grid = grid_for(c, groups);

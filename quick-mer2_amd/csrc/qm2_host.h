@@ -15,23 +15,23 @@
 
 /* ---- .qm dictionary ---------------------------------- */
 typedef struct {
-    FILE     *fp;          /* left open: the chain is read later (:483)          */
+    FILE     *fp;          /* left open: keys and chain are streamed from it later  */
     uint32_t  k;           /* byte @4  (:345-347)                                */
     uint64_t  hash_size;   /* u64 @8   (:348-349)                                */
     uint64_t  first_idx;   /* u64 @16  (:350-351)                                */
-    uint64_t *keys;        /* H x u64 from @24 (:353-359); later reused for the
-                              H x u32 chain exactly as the reference does (:490) */
-    uint64_t  keys_read;
 } qm2_dict_file;
 
+/* Header only.  The reference mallocs H x 8 bytes and freads the keys here (:353-359), later
+ * the chain over them (:483, :490); this build streams both from the file straight to the
+ * device (qm2_dict_load_keys -> qm2_keys_from_fd, qm2_write_outputs -> qm2_chain_gather_fd), so
+ * the host never holds the 32 GiB array. */
 int  qm2_dict_open(const char *ref_prefix, qm2_dict_file *d);
+int  qm2_dict_load_keys(qm2_dict_file *d, qm2_ctx *ctx);      /* prints the reference's "Read 0x.. hash" (:359) */
 void qm2_dict_close(qm2_dict_file *d);
 
 /* Epilogue (:483-542): counts in chain order -> <out>.bin, optional .qgc stats ->
- * <out>.txt.  The chain walk itself (:494-516) runs on the device
- * (qm2_chain_gather); this reads the chain from the .qm into the dead key buffer
- * exactly as the reference does (:483, :490), hands it over, and streams the
- * result out.  Prints the reference's stdout lines. */
+ * <out>.txt.  The chain walk itself (:494-516) runs on the device (qm2_chain_gather_fd reads
+ * the chain from the .qm); the result is streamed out.  Prints the reference's stdout lines. */
 int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, const char *out_prefix);
 
 /* ---- input line discipline (:393-398, :451-455) ---------------------------- */

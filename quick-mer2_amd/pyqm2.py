@@ -17,6 +17,7 @@ FLAG_TIMING = 0x1
 FLAG_NO_STATS = 0x2
 FLAG_DIRECT = 0x4
 FLAG_PARTITION = 0x8
+FLAG_KEYS_LATER = 0x10
 KERNEL_CLASSES = ["count_direct", "split_text", "split_kmer", "bucket_count", "probe", "encode", "-", "-"]
 
 
@@ -53,7 +54,7 @@ class Dup(C.Structure):
 # every symbol include/qm2.h and include/qm2_tools.h declare
 ABI_SYMBOLS = ["qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
-               "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch",
+               "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd",
                "qm2_shard_span", "qm2_last_error",
                "qm2_abi_version"]
 TOOL_SYMBOLS = ["qm2t_genome_generate", "qm2t_dict_build", "qm2t_reads_generate",
@@ -111,6 +112,10 @@ def lib():
     L.qm2_probe_device.argtypes = [vp, vp, u64, vp]
     L.qm2_chain_gather.restype = C.c_int
     L.qm2_chain_gather.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.qm2_keys_from_fd.restype = C.c_int
+    L.qm2_keys_from_fd.argtypes = [vp, C.c_int, u64]
+    L.qm2_chain_gather_fd.restype = C.c_int
+    L.qm2_chain_gather_fd.argtypes = [vp, C.c_int, u64, u64, C.POINTER(u64)]
     L.qm2_chain_fetch.restype = C.c_int
     L.qm2_chain_fetch.argtypes = [vp, vp, u64, u64]
     L.qm2_shard_span.restype = C.c_int
@@ -225,6 +230,20 @@ class Counter:
         for a in range(0, len(out), step):
             m = min(step, len(out) - a)
             _check(lib().qm2_chain_fetch(self._h, out[a:].ctypes.data, a, m), "qm2_chain_fetch")
+        return out
+
+    def keys_from_fd(self, fd, file_offset=24):
+        """Fill the key table of a context opened with FLAG_KEYS_LATER from a .qm file."""
+        _check(lib().qm2_keys_from_fd(self._h, int(fd), int(file_offset)), "qm2_keys_from_fd")
+
+    def chain_gather_fd(self, fd, first_idx, file_offset=None):
+        """chain_gather with the chain read from the .qm (offset 24 + 8 H by default)."""
+        n = C.c_uint64(0)
+        off = 24 + 8 * self.H if file_offset is None else int(file_offset)
+        _check(lib().qm2_chain_gather_fd(self._h, int(fd), off, int(first_idx), C.byref(n)), "qm2_chain_gather_fd")
+        out = np.empty(int(n.value), dtype=np.uint16)
+        if len(out):
+            _check(lib().qm2_chain_fetch(self._h, out.ctypes.data, 0, len(out)), "qm2_chain_fetch")
         return out
 
     def profile(self):

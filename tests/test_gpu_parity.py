@@ -336,6 +336,80 @@ def test_long_occupied_runs(qm2):
     assert prof["partitioned_batches"] == 0 and prof["direct_batches"] >= 1, prof
 
 
+def test_dictionary_streamed_from_the_file(qm2, torch_cuda, tmp_path):
+    """qm2_keys_from_fd / qm2_chain_gather_fd (what the CLI uses: no host copy of the table) against
+    the host-pointer calls, on the mini set and on a synthetic 600 MB .qm that takes several 64 MiB
+    pieces per reader thread; counting before the keys are there and a file that ends early are
+    errors."""
+    path = os.path.join(GOLD, "mini", "ref.fa.qm")
+    qm = ol.load_qm(path)
+    ref = synth.kat_reference().tobytes()
+    rng = np.random.default_rng(5)
+    blob = b"".join(ref[int(p):int(p) + 150] + b"\n" for p in rng.integers(0, 4800, 3000))
+    with qm2.Counter(qm["keys"], k=30) as c:
+        c.submit(blob)
+        depth, st = c.finish()
+        exp_bin = c.chain_gather(qm["chain"], qm["first"])
+    with open(path, "rb") as f, qm2.Counter(None, hash_size=len(qm["keys"]), k=30, flags=qm2.FLAG_KEYS_LATER) as c:
+        with pytest.raises(qm2.Qm2Error, match="not been loaded"):
+            c.submit(blob)
+        c.keys_from_fd(f.fileno())
+        with pytest.raises(qm2.Qm2Error):
+            c.keys_from_fd(f.fileno())                     # only once
+        c.submit(blob)
+        d2, s2 = c.finish()
+        assert s2 == st and np.array_equal(d2, depth)
+        assert np.array_equal(c.chain_gather_fd(f.fileno(), qm["first"]), exp_bin)
+    # truncated files
+    cut = tmp_path / "cut.qm"
+    data = open(path, "rb").read()
+    cut.write_bytes(data[:24 + 8 * len(qm["keys"]) - 100])
+    with open(cut, "rb") as f, qm2.Counter(None, hash_size=len(qm["keys"]), k=30, flags=qm2.FLAG_KEYS_LATER) as c:
+        with pytest.raises(qm2.Qm2Error, match="truncated"):
+            c.keys_from_fd(f.fileno())
+    cut.write_bytes(data[:-100])
+    with open(cut, "rb") as f, qm2.Counter(None, hash_size=len(qm["keys"]), k=30, flags=qm2.FLAG_KEYS_LATER) as c:
+        c.keys_from_fd(f.fileno())
+        with pytest.raises(qm2.Qm2Error, match="truncated"):
+            c.chain_gather_fd(f.fileno(), qm["first"])
+    # many pieces: a 12 Mb synthetic reference at H = 2^25 (256 MiB of keys + 128 MiB of chain = 6 pieces)
+    torch = torch_cuda
+    n, H = 12_000_000, 1 << 25
+    genome = torch.empty(n, dtype=torch.uint8, device="cuda")
+    qm2.tools.genome_generate(genome.data_ptr(), n, seed=9)
+    dkeys = torch.empty(H, dtype=torch.int64, device="cuda")
+    scratch = torch.empty(H, dtype=torch.int64, device="cuda")
+    qm2.tools.dict_build(genome.data_ptr(), n, 30, dkeys.data_ptr(), H, scratch.data_ptr())
+    n_reads = 200_000
+    reads = torch.empty(n_reads * 151, dtype=torch.uint8, device="cuda")
+    qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, n_reads, 0, 150, 150, 9)
+    torch.cuda.synchronize()
+    keys = dkeys.cpu().numpy().view(np.uint64)
+    lines = reads.cpu().numpy().tobytes()
+    del genome, dkeys, scratch, reads
+    occ = np.flatnonzero(keys).astype(np.uint32)
+    perm = rng.permutation(len(occ))
+    chain = np.zeros(H, dtype=np.uint32)
+    chain[occ[perm]] = occ[np.roll(perm, -1)]               # one cycle through the occupied slots, random order
+    first = int(occ[perm[0]])
+    big = tmp_path / "big.qm"
+    with open(big, "wb") as f:
+        f.write(b"QM11" + bytes([30, 0, 100, 100]) + int(H).to_bytes(8, "little") + first.to_bytes(8, "little"))
+        keys.tofile(f)
+        chain.tofile(f)
+    with qm2.Counter(keys, k=30) as c:
+        c.submit(lines)
+        depth, st = c.finish()
+        exp_bin = c.chain_gather(chain, first)
+    assert st["n_hits"] > 0.5 * st["n_kmers"]
+    with open(big, "rb") as f, qm2.Counter(None, hash_size=H, k=30, flags=qm2.FLAG_KEYS_LATER) as c:
+        c.keys_from_fd(f.fileno())
+        c.submit(lines)
+        d2, s2 = c.finish()
+        assert s2 == st and np.array_equal(d2, depth)
+        assert np.array_equal(c.chain_gather_fd(f.fileno(), first), exp_bin)
+
+
 # ---- 3. device-resident input, any alignment -----------------------------------
 
 def test_submit_device_unaligned(qm2, torch_cuda, tmp_path):
