@@ -66,12 +66,14 @@ typedef struct {
     uint32_t struct_size;     /* = sizeof(qm2_opts); 0-filled fields = defaults  */
     int32_t  device;          /* HIP device ordinal; <0 = current device         */
     uint32_t flags;           /* QM2_FLAG_*                                      */
-    uint32_t n_staging;       /* pinned host staging buffers for qm2_submit
-                                 (default 3; each has its own stream)            */
+    uint32_t n_staging;       /* pinned host staging buffers for qm2_submit /
+                                 qm2_staging_acquire (default 4)                 */
     uint64_t staging_bytes;   /* size of each staging buffer (default 64 MiB)    */
     uint64_t batch_bytes;     /* device batch that qm2_submit accumulates before it
-                                 launches (default: one byte per table slot,
-                                 clamped to 1..4 GiB; two are kept)              */
+                                 launches (default: 1.5 bytes per table slot,
+                                 clamped to 1..6 GiB; two are kept).  The
+                                 partitioned pipeline streams the whole table once
+                                 per batch, so batches should be large against it */
     uint32_t part_max_bits;   /* partitioned pipeline: radix bits per level, 1..8
                                  (default 8); smaller values only make sense in tests */
     uint32_t reserved0;
