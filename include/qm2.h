@@ -217,6 +217,23 @@ int qm2_probe_device(qm2_ctx *c, const uint64_t *d_kmers, uint64_t n,
 int qm2_chain_gather(qm2_ctx *c, const uint32_t *chain, uint64_t first_idx, uint64_t *n_out);
 int qm2_chain_fetch(qm2_ctx *c, uint16_t *out, uint64_t offset, uint64_t count);
 
+/* The input line discipline on the device (QuicKmer.c:393-398, :451-455):
+ * `d_raw` = n bytes of RAW FASTA / FASTQ text on the device, starting at a line start,
+ * 16-byte aligned.  fastq = the format the first line of the file decided (:395);
+ * skip (FASTQ only, 0..3) = lines to drop before the first sequence line of this block
+ * (1 for a block that starts at an '@' header).  Headers, '+' lines and qualities are
+ * blanked on the device and the rest is counted like qm2_submit_device.  Two things cannot
+ * be counted this way and are reported in *verdict instead (nothing of the block is
+ * counted then; the caller strips it on the host and uses qm2_submit):
+ *   QM2_RAW_DESYNC     a FASTQ sequence-position line starts with '>' (:398 skips it without
+ *                      the three discards, so the phase stops following the line number)
+ *   QM2_RAW_LONG_LINE  a line longer than 65535 bytes (uint16 run counter, :402)
+ * The call waits for the classification (not for the counting). */
+#define QM2_RAW_DESYNC    1u
+#define QM2_RAW_LONG_LINE 2u
+int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
+                          uint32_t *verdict);
+
 /* Straight from the .qm file to the device (QuicKmer.c:353-359 and :483 without the 32 GiB
  * host array the reference mallocs at :353): the key table / the chain are read from `fd` at
  * `file_offset` by several threads into pinned buffers and copied up as they arrive.

@@ -101,6 +101,12 @@ struct qm2_ctx {
     std::vector<qm2::TimedLaunch> pool;
     qm2_profile prof;
     qm2::PartPlan part;
+    /* device-side line discipline (qm2_raw.hip.h): neutralised copy of a raw block + tile scratch */
+    uint8_t    *raw_out = nullptr;
+    uint64_t    raw_cap = 0;
+    void       *raw_tiles = nullptr;        /* per 4 KiB tile: u32 count, i64 last, u64 before, i64 prev */
+    uint64_t    raw_tile_cap = 0;
+    unsigned int *raw_flags = nullptr;
     /* epilogue (qm2_epilogue.hip) */
     uint32_t   *chain = nullptr;            /* device copy of next[]; aliases keys when owned */
     bool        own_chain = false;

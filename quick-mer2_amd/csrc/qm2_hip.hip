@@ -23,6 +23,7 @@
 
 #include "qm2_ctx.h"
 #include "qm2_kernels.hip.h"
+#include "qm2_raw.hip.h"
 #include "qm2_partition.hip.h"
 #include "qm2_plan.h"
 
@@ -542,6 +543,9 @@ extern "C" void qm2_close(qm2_ctx *c)
     if (c->narrow) (void)hipFree(c->narrow);
     if (c->stats) (void)hipFree(c->stats);
     if (c->stats_peek) (void)hipHostFree(c->stats_peek);
+    if (c->raw_out) (void)hipFree(c->raw_out);
+    if (c->raw_tiles) (void)hipFree(c->raw_tiles);
+    if (c->raw_flags) (void)hipFree(c->raw_flags);
     if (c->peek_evt) (void)hipEventDestroy(c->peek_evt);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -729,6 +733,52 @@ extern "C" int qm2_submit_device(qm2_ctx *c, const void *d_seq, size_t n, const 
     if (!d_seq) return fail("qm2_submit_device: null buffer");
     if (use_device(c)) return 1;
     return launch_batch(c, (const uint8_t *)d_seq, n, 0, d_sup, n_sup);
+}
+
+extern "C" int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
+                                     uint32_t *verdict)
+{
+    if (!c || !verdict) return fail("qm2_submit_raw_device: null argument");
+    *verdict = 0;
+    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
+    if (n == 0) return 0;
+    if (!d_raw) return fail("qm2_submit_raw_device: null buffer");
+    if ((uintptr_t)d_raw & 15u) return fail("qm2_submit_raw_device: the buffer must be 16-byte aligned");
+    if (fastq && skip > 3) return fail("qm2_submit_raw_device: skip is 0..3");
+    if (use_device(c)) return 1;
+    hipStream_t s = c->stream;
+    const uint64_t n_tiles = (n + kRawTile - 1) / kRawTile;
+    if (n + 32 > c->raw_cap) {
+        HIP_OK(hipStreamSynchronize(s));
+        if (c->raw_out) HIP_OK(hipFree(c->raw_out));
+        c->raw_out = nullptr;
+        c->raw_cap = n + n / 8 + 4096;
+        HIP_OK(hipMalloc((void **)&c->raw_out, c->raw_cap));
+    }
+    if (n_tiles > c->raw_tile_cap) {
+        HIP_OK(hipStreamSynchronize(s));
+        if (c->raw_tiles) HIP_OK(hipFree(c->raw_tiles));
+        c->raw_tiles = nullptr;
+        c->raw_tile_cap = n_tiles + n_tiles / 8 + 16;
+        HIP_OK(hipMalloc(&c->raw_tiles, c->raw_tile_cap * 32));
+    }
+    if (!c->raw_flags) HIP_OK(hipMalloc((void **)&c->raw_flags, sizeof(unsigned int)));
+    /* scratch layout: i64 last[cap] | u64 before[cap] | i64 prev[cap] | u32 count[cap] */
+    long long *t_last = (long long *)c->raw_tiles;
+    uint64_t *t_before = (uint64_t *)(t_last + c->raw_tile_cap);
+    long long *t_prev = (long long *)(t_before + c->raw_tile_cap);
+    uint32_t *t_nl = (uint32_t *)(t_prev + c->raw_tile_cap);
+    RawView rv = {(const uint8_t *)d_raw, c->raw_out, (uint64_t)n, fastq ? 1u : 0u, fastq ? skip : 0u};
+    HIP_OK(hipMemsetAsync(c->raw_flags, 0, sizeof(unsigned int), s));
+    hipLaunchKernelGGL(raw_tile_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, t_nl, t_last);
+    hipLaunchKernelGGL(raw_scan_kernel, dim3(1), dim3(1024), 0, s, t_nl, t_last, n_tiles, t_before, t_prev);
+    hipLaunchKernelGGL(raw_apply_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, t_before, t_prev, c->raw_flags);
+    HIP_OK(hipGetLastError());
+    unsigned int flags = 0;
+    HIP_OK(hipMemcpyAsync(&flags, c->raw_flags, sizeof flags, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (flags) { *verdict = flags; return 0; }               /* not counted: the caller takes the host path */
+    return launch_batch(c, c->raw_out, n + 1, 0, nullptr, 0);  /* + the terminator raw_apply_kernel wrote at [n] */
 }
 
 extern "C" int qm2_keys_from_fd(qm2_ctx *c, int fd, uint64_t file_offset)

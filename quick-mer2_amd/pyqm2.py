@@ -54,7 +54,7 @@ class Dup(C.Structure):
 # every symbol include/qm2.h and include/qm2_tools.h declare
 ABI_SYMBOLS = ["qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
-               "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd",
+               "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_submit_raw_device",
                "qm2_shard_span", "qm2_last_error",
                "qm2_abi_version"]
 TOOL_SYMBOLS = ["qm2t_genome_generate", "qm2t_dict_build", "qm2t_reads_generate",
@@ -112,6 +112,8 @@ def lib():
     L.qm2_probe_device.argtypes = [vp, vp, u64, vp]
     L.qm2_chain_gather.restype = C.c_int
     L.qm2_chain_gather.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.qm2_submit_raw_device.restype = C.c_int
+    L.qm2_submit_raw_device.argtypes = [vp, vp, C.c_size_t, u32, u32, C.POINTER(u32)]
     L.qm2_keys_from_fd.restype = C.c_int
     L.qm2_keys_from_fd.argtypes = [vp, C.c_int, u64]
     L.qm2_chain_gather_fd.restype = C.c_int
@@ -231,6 +233,12 @@ class Counter:
             m = min(step, len(out) - a)
             _check(lib().qm2_chain_fetch(self._h, out[a:].ctypes.data, a, m), "qm2_chain_fetch")
         return out
+
+    def submit_raw_device(self, ptr, n, fastq, skip=0):
+        """Raw FASTA/FASTQ text on the device; returns the verdict (0 = counted)."""
+        v = C.c_uint32(0)
+        _check(lib().qm2_submit_raw_device(self._h, ptr, n, 1 if fastq else 0, skip, C.byref(v)), "qm2_submit_raw_device")
+        return int(v.value)
 
     def keys_from_fd(self, fd, file_offset=24):
         """Fill the key table of a context opened with FLAG_KEYS_LATER from a .qm file."""

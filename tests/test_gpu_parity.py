@@ -410,6 +410,77 @@ def test_dictionary_streamed_from_the_file(qm2, torch_cuda, tmp_path):
         assert np.array_equal(c.chain_gather_fd(f.fileno(), first), exp_bin)
 
 
+def test_line_discipline_on_the_device(qm2, torch_cuda, tmp_path):
+    """qm2_submit_raw_device: raw FASTA / FASTQ bytes, headers / '+' / qualities
+    blanked by the device — against the oracle's line discipline + count on every reference edge
+    case, on inputs that span many 4 KiB tiles (headers longer than a tile, lines cut at every
+    tile phase), and the two things it must refuse rather than count wrongly."""
+    torch = torch_cuda
+    qm = kat_qm()
+    keys = qm["keys"]
+    cases = dict(synth.kat_cases(synth.kat_reference()))
+    ref = synth.kat_reference().tobytes()
+    rng = np.random.default_rng(77)
+
+    def reads(n, lo, hi):
+        return [ref[int(p):int(p) + int(l)] for p, l in zip(rng.integers(0, 4000, n), rng.integers(lo, hi, n))]
+
+    cases.update({
+        "fq_many_tiles": ("fq", b"".join(b"@r%d extra words\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n"
+                                         for i, r in enumerate(reads(60000, 30, 300)))),
+        "fa_many_tiles": ("fa", b"".join(b">" + b"h" * int(h) + b"\n" + r + b"\n"
+                                         for h, r in zip(rng.integers(0, 9000, 3000), reads(3000, 1, 900)))),
+        "fa_multiline_records": ("fa", b"".join(b">c%d\n" % i + b"".join(ref[j:j + 60] + b"\n" for j in range(0, 4800, 60))
+                                                for i in range(40))),
+        "fq_no_final_newline": ("fq", b"@a\n" + ref[:150] + b"\n+\n" + b"I" * 150 + b"\n@b\n" + ref[200:290]),
+        "fq_crlf": ("fq", b"".join(b"@r\r\n" + r + b"\r\n+\r\n" + b"I" * len(r) + b"\r\n" for r in reads(500, 40, 200))),
+        "fq_empty_lines": ("fq", b"@a\n\n+\n\n@b\n" + ref[:100] + b"\n+\n" + b"I" * 100 + b"\n"),
+    })
+    refused = {}
+    with qm2.Counter(keys, k=30) as c:
+        for name, (kind, data) in cases.items():
+            if not data:
+                continue
+            p = tmp_path / ("%s.%s" % (name, kind))
+            p.write_bytes(data)
+            exp_depth, exp_st = ol.count_lines(keys, 30, ol.strip_reads(str(p)))
+            fastq = data[:1] == b"@"                                   # QuicKmer.c:395
+            d = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+            torch.cuda.synchronize()
+            c.reset()
+            verdict = c.submit_raw_device(d.data_ptr(), d.numel(), fastq, skip=1 if fastq else 0)
+            depth, st = c.finish()
+            if verdict:
+                refused[name] = verdict
+                assert st["n_bases"] == 0 and not depth.any(), name     # nothing of a refused block is counted
+                continue
+            assert st == exp_st, name
+            assert np.array_equal(depth, exp_depth), name
+        # a FASTQ block that starts in the middle of a record: skip = lines left to drop
+        body = cases["fq_many_tiles"][1]
+        lines = body.split(b"\n")
+        for drop, start in ((0, 1), (1, 4), (2, 3), (3, 2)):           # block starts at a sequence / header / quality / '+' line
+            blob = b"\n".join(lines[start:])
+            want = b"".join(l + b"\n" for l in blob.split(b"\n")[drop::4])
+            exp_depth, exp_st = ol.count_lines(keys, 30, want)
+            d = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+            torch.cuda.synchronize()
+            c.reset()
+            assert c.submit_raw_device(d.data_ptr(), d.numel(), True, skip=drop) == 0
+            depth, st = c.finish()
+            assert st["n_kmers"] == exp_st["n_kmers"] and np.array_equal(depth, exp_depth), drop
+    # refusals: lines beyond the uint16 run counter, and the '>' at a FASTQ sequence position
+    assert {n for n, v in refused.items() if v & 2} >= {"long65536", "long65566", "long70000", "long99998"}
+    assert "long65535" not in refused and "long20000" not in refused
+    fq = b"@a\n" + ref[:100] + b"\n+\n" + b"I" * 100 + b"\n@b\n>oops\n+\nIIIII\n@c\n" + ref[:50] + b"\n+\n" + b"I" * 50 + b"\n"
+    with qm2.Counter(keys, k=30) as c:
+        d = torch.frombuffer(bytearray(fq), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        assert c.submit_raw_device(d.data_ptr(), d.numel(), True, skip=1) == 1
+        with pytest.raises(qm2.Qm2Error, match="aligned"):
+            c.submit_raw_device(d.data_ptr() + 1, d.numel() - 1, True, skip=1)
+
+
 # ---- 3. device-resident input, any alignment -----------------------------------
 
 def test_submit_device_unaligned(qm2, torch_cuda, tmp_path):
