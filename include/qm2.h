@@ -234,6 +234,17 @@ int qm2_chain_fetch(qm2_ctx *c, uint16_t *out, uint64_t offset, uint64_t count);
 int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
                           uint32_t *verdict);
 
+/* The same for host input, through the pinned staging buffers: the caller fills a buffer from
+ * qm2_staging_acquire with raw text (the CLI: pread, nothing else) and commits the n bytes at
+ * `offset` in it — whole lines, in file order, with the line state at their first byte.  Blocks
+ * collect in a device batch; the line state of a batch is that of its first block (the device
+ * numbers the lines itself), so consecutive blocks must be consecutive text.  A refusal
+ * (see qm2_submit_raw_device) is sticky: qm2_raw_verdict() != 0 after qm2_sync / qm2_finish
+ * means that raw batch and everything committed raw after it were NOT counted — the caller
+ * starts over (qm2_reset) on the host path.  Do not mix with qm2_submit inside one batch. */
+int qm2_staging_commit_raw(qm2_ctx *c, char *buf, size_t offset, size_t n, uint32_t fastq, uint32_t skip);
+uint32_t qm2_raw_verdict(qm2_ctx *c);
+
 /* Straight from the .qm file to the device (QuicKmer.c:353-359 and :483 without the 32 GiB
  * host array the reference mallocs at :353): the key table / the chain are read from `fd` at
  * `file_offset` by several threads into pinned buffers and copied up as they arrive.

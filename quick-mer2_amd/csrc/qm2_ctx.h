@@ -32,6 +32,8 @@ struct Batch {                              /* one device batch being filled by 
     size_t      wraps_cap = 0;
     hipEvent_t  done = nullptr;             /* its kernels have finished */
     bool        busy = false;
+    bool        raw = false;                /* holds raw FASTA/FASTQ text (qm2_staging_commit_raw) ... */
+    uint32_t    raw_fastq = 0, raw_skip = 0;/* ... in this line state at dev[0] */
 };
 
 struct TimedLaunch {
@@ -107,6 +109,7 @@ struct qm2_ctx {
     void       *raw_tiles = nullptr;        /* per 4 KiB tile: u32 count, i64 last, u64 before, i64 prev */
     uint64_t    raw_tile_cap = 0;
     unsigned int *raw_flags = nullptr;
+    uint32_t    raw_verdict = 0;            /* sticky: a raw batch was refused (QM2_RAW_*); nothing raw is counted after it */
     /* epilogue (qm2_epilogue.hip) */
     uint32_t   *chain = nullptr;            /* device copy of next[]; aliases keys when owned */
     bool        own_chain = false;
@@ -118,6 +121,8 @@ int qm2_fail(const char *fmt, ...);         /* sets qm2_last_error(), prints, re
 void qm2_part_free(qm2::PartPlan &p);
 /* qm2_io.hip: nbytes of `fd` from `off` -> device memory `dst`, read by several threads through pinned buffers */
 int qm2_stream_fd(qm2_ctx *c, int fd, uint64_t off, void *dst, uint64_t nbytes, const char *what);
+/* qm2_hip.hip: make staging slot `s` usable (allocates its pinned buffer on first use, waits for its last copy) */
+int qm2_slot_ready(qm2_ctx *c, qm2::Slot &s);
 
 #define HIP_OK(call)                                                              \
     do {                                                                          \

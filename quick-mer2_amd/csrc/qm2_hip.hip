@@ -570,6 +570,9 @@ static int batch_ready(qm2_ctx *c, Batch &b)
     return 0;
 }
 
+static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
+                                  uint32_t *verdict);
+
 /* Launch the kernels for the batch being filled and switch to the other one. */
 static int batch_flush(qm2_ctx *c)
 {
@@ -581,6 +584,17 @@ static int batch_flush(qm2_ctx *c)
     HIP_OK(hipEventRecord(copied, c->copy_stream));
     HIP_OK(hipStreamWaitEvent(c->stream, copied, 0));
     HIP_OK(hipEventDestroy(copied));
+    if (b.raw) {                              /* raw text: line discipline on the device, then the count */
+        uint32_t verdict = 0;
+        if (raw_classify_and_count(c, b.dev, b.fill, b.raw_fastq, b.raw_skip, &verdict)) return 1;
+        if (verdict) c->raw_verdict |= verdict;
+        HIP_OK(hipEventRecord(b.done, c->stream));
+        b.busy = true;
+        b.fill = b.carry = 0;
+        b.raw = false;
+        c->cur ^= 1;
+        return 0;
+    }
     uint64_t *d_sup = nullptr;
     const uint64_t n_sup = b.wraps.size();
     if (n_sup) {                              /* long lines are rare: a small blocking copy is fine */
@@ -601,7 +615,7 @@ static int batch_flush(qm2_ctx *c)
     return 0;
 }
 
-static int slot_ready(qm2_ctx *c, Slot &s)
+int qm2_slot_ready(qm2_ctx *c, Slot &s)
 {
     if (!s.host) {
         HIP_OK(hipHostMalloc((void **)&s.host, c->staging_bytes, hipHostMallocDefault));
@@ -635,7 +649,7 @@ static int stage_bytes(qm2_ctx *c, Batch &b, const char *src, size_t n, Slot *ow
             if (!cand.lent) s = &cand;
         }
         if (!s) return fail("qm2_submit: every staging buffer is held by qm2_staging_acquire");
-        if (slot_ready(c, *s)) return 1;
+        if (qm2_slot_ready(c, *s)) return 1;
         const size_t take = std::min(c->staging_bytes, n - done);
         memcpy(s->host, src + done, take);
         HIP_OK(hipMemcpyAsync(b.dev + b.fill, s->host, take, hipMemcpyHostToDevice, c->copy_stream));
@@ -663,6 +677,7 @@ extern "C" int qm2_submit(qm2_ctx *c, const char *buf, size_t n)
 
 static int submit_lines(qm2_ctx *c, const char *buf, size_t n, Slot *owner)
 {
+    if (c->batch[c->cur].raw && batch_flush(c)) return 1;       /* a raw batch is pending: it goes first */
     std::vector<Part> parts;
     {
         const Batch &b0 = c->batch[c->cur];
@@ -700,7 +715,7 @@ extern "C" int qm2_staging_acquire(qm2_ctx *c, char **buf, size_t *capacity)
         Slot &s = c->slots[c->next_slot];
         c->next_slot = (c->next_slot + 1) % (uint32_t)c->slots.size();
         if (s.lent) continue;
-        if (slot_ready(c, s)) return 1;
+        if (qm2_slot_ready(c, s)) return 1;
         s.lent = true;
         *buf = s.host;
         *capacity = c->staging_bytes;
@@ -735,17 +750,10 @@ extern "C" int qm2_submit_device(qm2_ctx *c, const void *d_seq, size_t n, const 
     return launch_batch(c, (const uint8_t *)d_seq, n, 0, d_sup, n_sup);
 }
 
-extern "C" int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
-                                     uint32_t *verdict)
+/* classify the n raw bytes at d_raw (device, 16-byte aligned) and, unless refused, count them */
+static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
+                                  uint32_t *verdict)
 {
-    if (!c || !verdict) return fail("qm2_submit_raw_device: null argument");
-    *verdict = 0;
-    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
-    if (n == 0) return 0;
-    if (!d_raw) return fail("qm2_submit_raw_device: null buffer");
-    if ((uintptr_t)d_raw & 15u) return fail("qm2_submit_raw_device: the buffer must be 16-byte aligned");
-    if (fastq && skip > 3) return fail("qm2_submit_raw_device: skip is 0..3");
-    if (use_device(c)) return 1;
     hipStream_t s = c->stream;
     const uint64_t n_tiles = (n + kRawTile - 1) / kRawTile;
     if (n + 32 > c->raw_cap) {
@@ -780,6 +788,50 @@ extern "C" int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, ui
     if (flags) { *verdict = flags; return 0; }               /* not counted: the caller takes the host path */
     return launch_batch(c, c->raw_out, n + 1, 0, nullptr, 0);  /* + the terminator raw_apply_kernel wrote at [n] */
 }
+
+extern "C" int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
+                                     uint32_t *verdict)
+{
+    if (!c || !verdict) return fail("qm2_submit_raw_device: null argument");
+    *verdict = 0;
+    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
+    if (n == 0) return 0;
+    if (!d_raw) return fail("qm2_submit_raw_device: null buffer");
+    if ((uintptr_t)d_raw & 15u) return fail("qm2_submit_raw_device: the buffer must be 16-byte aligned");
+    if (fastq && skip > 3) return fail("qm2_submit_raw_device: skip is 0..3");
+    if (use_device(c)) return 1;
+    return raw_classify_and_count(c, d_raw, n, fastq, skip, verdict);
+}
+
+extern "C" int qm2_staging_commit_raw(qm2_ctx *c, char *buf, size_t offset, size_t n, uint32_t fastq, uint32_t skip)
+{
+    if (!c || !buf) return fail("qm2_staging_commit_raw: null argument");
+    Slot *owner = nullptr;
+    for (auto &s : c->slots) if (s.lent && s.host == buf) owner = &s;
+    if (!owner) return fail("qm2_staging_commit_raw: not a buffer from qm2_staging_acquire");
+    owner->lent = false;
+    if (n == 0 || c->raw_verdict) return 0;                   /* after a refusal nothing raw is counted any more */
+    if (offset > c->staging_bytes || n > c->staging_bytes - offset)
+        return fail("qm2_staging_commit_raw: more bytes than the buffer holds");
+    if (n > c->batch_bytes) return fail("qm2_staging_commit_raw: block larger than a device batch");
+    if (fastq && skip > 3) return fail("qm2_staging_commit_raw: skip is 0..3");
+    if (use_device(c)) return 1;
+    {
+        Batch &b = c->batch[c->cur];
+        if (b.fill && (!b.raw || b.fill + n > c->batch_bytes) && batch_flush(c)) return 1;
+    }
+    if (c->raw_verdict) return 0;
+    Batch &b = c->batch[c->cur];
+    if (batch_ready(c, b)) return 1;
+    if (b.fill == 0) { b.raw = true; b.raw_fastq = fastq ? 1u : 0u; b.raw_skip = skip; b.carry = 0; }
+    HIP_OK(hipMemcpyAsync(b.dev + b.fill, buf + offset, n, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_OK(hipEventRecord(owner->done, c->copy_stream));
+    owner->busy = true;
+    b.fill += n;
+    return 0;
+}
+
+extern "C" uint32_t qm2_raw_verdict(qm2_ctx *c) { return c ? c->raw_verdict : 0; }
 
 extern "C" int qm2_keys_from_fd(qm2_ctx *c, int fd, uint64_t file_offset)
 {
@@ -843,6 +895,7 @@ extern "C" int qm2_reset(qm2_ctx *c)
     HIP_OK(hipMemsetAsync(c->stats, 0, sizeof(DevStats), c->stream));
     c->bytes_launched = 0;
     c->peek_pending = false;
+    c->raw_verdict = 0;
     HIP_OK(hipStreamSynchronize(c->stream));
     memset(&c->prof, 0, sizeof c->prof);
     return 0;

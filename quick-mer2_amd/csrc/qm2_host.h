@@ -44,12 +44,20 @@ typedef struct {
     int (*commit)(void *user, char *buf, size_t n);
     int (*submit)(void *user, const char *lines, size_t n);
     void *user;
+    /* optional: when set, regular files are NOT stripped on the host; the workers only
+     * pread their blocks into acquired buffers and the n raw bytes at `offset` are handed over with
+     * the line state at their first byte (fastq, lines still to drop), in file order.  n = 0 just
+     * returns the buffer.  Returns 0, 1 (error, message printed) or 2 (give up on raw hand-over:
+     * qm2_stream_reads returns 2). */
+    int (*commit_raw)(void *user, char *buf, size_t offset, size_t n, int fastq, unsigned skip);
 } qm2_lines_out;
 
 /* Streams `path` (file, pipe or /dev/fd/N) with a read-ahead thread, strips it to sequence
  * lines on n_threads worker threads (0 = on the calling thread) and hands them to `out`, which
  * is only ever called from the calling thread and must be able to lend n_threads + 1 buffers at
- * a time.  Returns 0, or non-zero after printing a message. */
+ * a time.  Returns 0, or 1 after printing a message, or 2 when raw hand-over (commit_raw) met
+ * something it cannot pass on (a line longer than a buffer): nothing is printed, the caller
+ * starts over without commit_raw. */
 int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads);
 
 /* ---- the command ----------------------------------------------------------- */

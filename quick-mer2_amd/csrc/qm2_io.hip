@@ -5,6 +5,9 @@
  * the pieces does not matter (each knows its destination), so nobody waits for a straggler.
  * Replaces malloc(H * 8) + one fread + one hipMemcpy: no 32 GiB host array, and the page-cache
  * copy (the slow part, ~6 GB/s per thread) runs on several cores while the DMA is under way.
+ * The ring is made of the context's own staging buffers (idle at both times this runs: before
+ * the first read is submitted and after the last one is counted): pinning and unpinning extra
+ * buffers here was measured to cost the counting phase that follows 50-70 ms.
  */
 #include <unistd.h>
 
@@ -20,7 +23,6 @@
 
 namespace {
 
-constexpr size_t kPiece = (size_t)64 << 20;
 constexpr int    kRing = 6;
 constexpr int    kReaders = 4;
 
@@ -39,6 +41,7 @@ struct Ring {
     std::condition_variable cv;
     Piece                   piece[kRing];
     uint64_t                next = 0, total = 0;      /* pieces handed to readers / in all */
+    size_t                  piece_bytes = 0;
     bool                    failed = false, short_file = false;
 };
 
@@ -58,8 +61,8 @@ void reader(Ring *r, int fd, uint64_t off, uint64_t nbytes)
             p->index = r->next++;
             p->state = State::Filling;
         }
-        const uint64_t at = p->index * kPiece;
-        const size_t want = (size_t)std::min<uint64_t>(kPiece, nbytes - at);
+        const uint64_t at = p->index * r->piece_bytes;
+        const size_t want = (size_t)std::min<uint64_t>(r->piece_bytes, nbytes - at);
         size_t got = 0;
         bool bad = false;
         while (got < want) {
@@ -83,13 +86,17 @@ int qm2_stream_fd(qm2_ctx *c, int fd, uint64_t off, void *dst, uint64_t nbytes, 
 {
     if (nbytes == 0) return 0;
     Ring r;
-    r.total = (nbytes + kPiece - 1) / kPiece;
-    const int n_bufs = (int)std::min<uint64_t>(kRing, r.total);
+    r.piece_bytes = c->staging_bytes;
+    r.total = (nbytes + r.piece_bytes - 1) / r.piece_bytes;
+    const int n_bufs = (int)std::min<uint64_t>(std::min<size_t>(kRing, c->slots.size()), r.total);
     int rc = 0;
     for (int i = 0; i < n_bufs && !rc; i++) {
-        if (hipHostMalloc((void **)&r.piece[i].host, (size_t)std::min<uint64_t>(kPiece, nbytes), hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&r.piece[i].copied, hipEventDisableTiming) != hipSuccess)
+        qm2::Slot &slot = c->slots[i];
+        if (slot.lent) rc = qm2_fail("qm2: staging buffers are held while %s is loaded", what);
+        else if (qm2_slot_ready(c, slot)) rc = 1;
+        else if (hipEventCreateWithFlags(&r.piece[i].copied, hipEventDisableTiming) != hipSuccess)
             rc = qm2_fail("Memory allocation failed");
+        r.piece[i].host = slot.host;
     }
     for (int i = n_bufs; i < kRing; i++) r.piece[i].state = State::Copying;   /* never used: neither Free nor Full */
     std::vector<std::thread> readers;
@@ -122,7 +129,7 @@ int qm2_stream_fd(qm2_ctx *c, int fd, uint64_t off, void *dst, uint64_t nbytes, 
             if (p) p->state = State::Copying;
         }
         if (!p) break;
-        if (hipMemcpyAsync((char *)dst + p->index * kPiece, p->host, p->len, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+        if (hipMemcpyAsync((char *)dst + p->index * r.piece_bytes, p->host, p->len, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
             hipEventRecord(p->copied, c->copy_stream) != hipSuccess) {
             rc = qm2_fail("qm2: upload of %s failed", what);
             std::lock_guard<std::mutex> lk(r.m);
@@ -138,9 +145,7 @@ int qm2_stream_fd(qm2_ctx *c, int fd, uint64_t off, void *dst, uint64_t nbytes, 
     for (auto &t : readers) t.join();
     (void)hipStreamSynchronize(c->copy_stream);
     if (!rc && r.failed) rc = qm2_fail(r.short_file ? "%s is truncated" : "Cannot read %s", what);
-    for (int i = 0; i < n_bufs; i++) {
-        if (r.piece[i].host) (void)hipHostFree(r.piece[i].host);
+    for (int i = 0; i < n_bufs; i++)
         if (r.piece[i].copied) (void)hipEventDestroy(r.piece[i].copied);
-    }
     return rc;
 }

@@ -167,7 +167,7 @@ static int buf_submit(void *u, const char *p, size_t n) { (void)u; (void)p; (voi
 static void strip_block(strip_job *j)
 {
     /* an out_state pinned to the job's buffer: the output never exceeds the input, so it fits */
-    static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL};
+    static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL, NULL};
     out_state os = {&none, j->obuf, j->ocap, 0};
     size_t at = 0;
     j->rc = 0;
@@ -241,6 +241,7 @@ typedef struct {
     size_t      before;                    /* lines before this block */
     line_state  st_end;
     int         too_big, rc;
+    int         raw_mode;                  /* read straight into obuf, do not strip */
     sem_t       start, done;
     int         quit;
 } pf_worker;
@@ -265,6 +266,11 @@ static int pf_load(pf_worker *w)
     size_t e = s + QM2_BLOCK;
     if (e > sh->size) e = sh->size;
     const size_t base = w->block ? s - 1 : s;              /* the byte before tells whether a line starts at s */
+    if (w->raw_mode) {                                      /* the pinned buffer itself; it cannot grow */
+        w->raw = w->obuf;
+        w->raw_cap = w->ocap;
+        if (e - base > w->raw_cap) { w->too_big = 1; w->lo = w->hi = 0; w->file_hi = e; return 0; }
+    }
     ssize_t r = pread_full(sh->fd, w->raw, e - base, base);
     if (r < 0) return 1;
     size_t n = (size_t)r;
@@ -282,6 +288,7 @@ static int pf_load(pf_worker *w)
     while (n && w->raw[n - 1] != '\n' && base + n < sh->size) {
         const size_t step = 1u << 16;
         if (n + step > w->raw_cap) {
+            if (w->raw_mode) { w->too_big = 1; break; }
             char *g = realloc(w->raw, w->raw_cap * 2);
             if (!g) return 1;
             w->raw = g; w->raw_cap *= 2;
@@ -325,6 +332,7 @@ static void *pf_main(void *arg)
         const size_t b = w->block;
         w->olen = 0; w->too_big = 0;
         w->rc = atomic_load(&sh->stop) ? 0 : pf_load(w);
+        if (w->too_big) w->lo = w->hi = 0;
         if (w->rc || atomic_load(&sh->stop)) w->lo = w->hi = 0;
         size_t lines = count_newlines(w->raw + w->lo, w->hi - w->lo);
         if (w->hi > w->lo && w->raw[w->hi - 1] != '\n') lines++;       /* last line of the file, no newline */
@@ -333,10 +341,10 @@ static void *pf_main(void *arg)
         sh->lines_before[b + 1] = w->before + lines;
         atomic_store_explicit(&sh->known[b + 1], 1, memory_order_release);
         line_state st = pf_state(sh, w->before);
-        if (!atomic_load(&sh->stop) && !w->rc) {
+        if (!atomic_load(&sh->stop) && !w->rc && !w->raw_mode) {
             if (w->hi - w->lo + 1 > w->ocap) w->too_big = 1;          /* more than a staging buffer holds */
             else {
-                static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL};
+                static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL, NULL};
                 out_state os = {&none, w->obuf, w->ocap, 0};
                 if (strip_range(w->raw + w->lo, w->hi - w->lo, &st, &os)) w->rc = 1;
                 w->olen = os.len;
@@ -383,6 +391,7 @@ static int pf_serial_tail(const pf_shared *sh, size_t off, line_state *st, out_s
 
 static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_threads)
 {
+    const int raw_mode = out->commit_raw != NULL;
     pf_shared sh;
     memset(&sh, 0, sizeof sh);
     sh.fd = fd; sh.size = size;
@@ -417,12 +426,15 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
         atomic_store(&sh.known[0], 1);
         for (int w = 0; w < n_threads && (size_t)w < sh.n_blocks; w++) {
             ws[w].sh = &sh;
-            ws[w].raw_cap = QM2_BLOCK + (1u << 17);
-            ws[w].raw = malloc(ws[w].raw_cap);
-            if (!ws[w].raw) break;
+            ws[w].raw_mode = raw_mode;
+            if (!raw_mode) {
+                ws[w].raw_cap = QM2_BLOCK + (1u << 17);
+                ws[w].raw = malloc(ws[w].raw_cap);
+                if (!ws[w].raw) break;
+            }
             sem_init(&ws[w].start, 0, 0);
             sem_init(&ws[w].done, 0, 0);
-            if (pthread_create(&tids[w], NULL, pf_main, &ws[w])) { free(ws[w].raw); ws[w].raw = NULL; break; }
+            if (pthread_create(&tids[w], NULL, pf_main, &ws[w])) { if (!raw_mode) free(ws[w].raw); ws[w].raw = NULL; break; }
             n_workers++;
         }
         if (!n_workers && sh.n_blocks) { puts("Memory allocation failed"); rc = 1; }
@@ -444,6 +456,12 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
         sem_wait(&w->done);
         collected++;
         if (w->rc) { (void)out->commit(out->user, w->obuf, 0); rc = 1; break; }
+        if (raw_mode) {
+            if (w->too_big) { (void)out->commit(out->user, w->obuf, 0); rc = 2; break; }     /* the caller starts over */
+            const line_state st = pf_state(&sh, w->before);
+            rc = out->commit_raw(out->user, w->obuf, w->lo, w->hi - w->lo, sh.fastq, (unsigned)st.skip);   /* 0, 1 or 2 */
+            continue;
+        }
         if (serial_from_here) { (void)out->commit(out->user, w->obuf, 0); continue; }   /* redone below */
         if (w->too_big || w->st_end.desync) {
             /* redo this block serially from the worker's own buffer (oversize lines go through
@@ -478,7 +496,7 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
         pthread_join(tids[w], NULL);
         sem_destroy(&ws[w].start);
         sem_destroy(&ws[w].done);
-        free(ws[w].raw);
+        if (!raw_mode) free(ws[w].raw);
     }
     free(sh.lines_before); free(sh.known); free(ws); free(tids);
     return rc;
@@ -502,7 +520,7 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads)
         struct stat sb;
         char first = 0;
         if (fstat(ring.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && pread(ring.fd, &first, 1, 0) == 1 &&
-            (first == '@' || getenv("QM2_READER_BLOCKS"))) {
+            (first == '@' || getenv("QM2_READER_BLOCKS") || out->commit_raw)) {
             const int brc = stream_blocks(ring.fd, (size_t)sb.st_size, out, n_threads);
             close(ring.fd);
             return brc;

@@ -54,7 +54,7 @@ class Dup(C.Structure):
 # every symbol include/qm2.h and include/qm2_tools.h declare
 ABI_SYMBOLS = ["qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
-               "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_submit_raw_device",
+               "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_submit_raw_device", "qm2_staging_commit_raw", "qm2_raw_verdict",
                "qm2_shard_span", "qm2_last_error",
                "qm2_abi_version"]
 TOOL_SYMBOLS = ["qm2t_genome_generate", "qm2t_dict_build", "qm2t_reads_generate",
@@ -114,6 +114,10 @@ def lib():
     L.qm2_chain_gather.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.qm2_submit_raw_device.restype = C.c_int
     L.qm2_submit_raw_device.argtypes = [vp, vp, C.c_size_t, u32, u32, C.POINTER(u32)]
+    L.qm2_staging_commit_raw.restype = C.c_int
+    L.qm2_staging_commit_raw.argtypes = [vp, vp, C.c_size_t, C.c_size_t, u32, u32]
+    L.qm2_raw_verdict.restype = u32
+    L.qm2_raw_verdict.argtypes = [vp]
     L.qm2_keys_from_fd.restype = C.c_int
     L.qm2_keys_from_fd.argtypes = [vp, C.c_int, u64]
     L.qm2_chain_gather_fd.restype = C.c_int

@@ -99,8 +99,11 @@ static FILE *O;
 static int acq(void *u, char **b, size_t *c) { (void)u; *b = malloc(CAP); *c = CAP; return *b == NULL; }
 static int com(void *u, char *b, size_t n) { (void)u; fwrite(b, 1, n, O); free(b); return 0; }
 static int sub(void *u, const char *p, size_t n) { (void)u; fwrite(p, 1, n, O); return 0; }
-int main(int argc, char **argv) { (void)argc; O = fopen(argv[2], "wb"); CAP = (size_t)atol(argv[3]);
-  qm2_lines_out out = {acq, com, sub, NULL};
+static int raw(void *u, char *b, size_t off, size_t n, int fastq, unsigned skip) { (void)u;
+  if (n) { unsigned hdr[3] = {(unsigned)n, (unsigned)fastq, skip}; fwrite(hdr, 4, 3, O); fwrite(b + off, 1, n, O); }
+  free(b); return 0; }
+int main(int argc, char **argv) { O = fopen(argv[2], "wb"); CAP = (size_t)atol(argv[3]);
+  qm2_lines_out out = {acq, com, sub, NULL, argc > 5 ? raw : NULL};
   int rc = qm2_stream_reads(argv[1], &out, atoi(argv[4])); fclose(O); return rc; }
 ''')
     exe = str(tmp_path / "h")
@@ -137,6 +140,32 @@ int main(int argc, char **argv) { (void)argc; O = fopen(argv[2], "wb"); CAP = (s
             for env in ({},) if thr == 0 else ({}, {"QM2_READER_BLOCKS": "1"}, {"QM2_READER_STREAM": "1"}):
                 subprocess.run([exe, str(p), outp, str(batch), str(thr)], check=True, env=dict(os.environ, **env))
                 assert open(outp, "rb").read() == exp, (name, batch, thr, env)
+        # raw hand-over (what the CLI does by default): blocks of untouched text + the line state at their
+        # first byte; applying the device's rule (tests restate it here) to each block must give `exp`
+        if name not in ("fq_desync", "gt_in_fastq_seq_pos"):
+            for batch, thr in ((64 << 20, 1), (64 << 20, 3), (64 << 20, 8)):
+                outp = str(tmp_path / "raw.bin")
+                r = subprocess.run([exe, str(p), outp, str(batch), str(thr), "raw"])
+                blob = open(outp, "rb").read()
+                if r.returncode == 2:             # a line that does not fit a buffer: the caller starts over
+                    assert name == "huge_line" or max(len(l) for l in data.split(b"\n")) > (32 << 20), name
+                    continue
+                assert r.returncode == 0, name
+                kept, at = [], 0
+                while at < len(blob):
+                    n, fastq, skip = np.frombuffer(blob, dtype=np.uint32, count=3, offset=at)
+                    text = blob[at + 12:at + 12 + int(n)]
+                    at += 12 + int(n)
+                    lines = text.split(b"\n")
+                    if lines and lines[-1] == b"":
+                        lines.pop()
+                    for i, l in enumerate(lines):
+                        if fastq:
+                            if i >= skip and (i - skip) % 4 == 0 and not l.startswith(b">"):
+                                kept.append(l)
+                        elif not l.startswith(b">"):
+                            kept.append(l)
+                assert b"".join(l + b"\n" for l in kept) == exp, (name, thr)
         # pipe: first line is lost unless FASTQ (QuicKmer.c:396)
         outp = str(tmp_path / "out_pipe.bin")
         with open(str(p), "rb") as f:

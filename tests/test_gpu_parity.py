@@ -103,6 +103,42 @@ def test_cli_matches_reference_vectors(setname, name, tmp_path):
     assert txt.rstrip().endswith("Exit quicK-mer2 count")
 
 
+@pytest.mark.parametrize("raw", ["1", "0"])
+def test_cli_raw_and_host_line_discipline(raw, tmp_path):
+    """The CLI's default for regular files: the host only preads, the device does the line discipline
+    (SURVEY 8(f) f3); QM2_READER_RAW=0: stripped on the host.  Every k = 30 reference vector must come
+    out byte-identical both ways; the inputs the device path refuses (lines beyond 65535 bytes) must
+    silently go round again through the host path."""
+    refused = []
+    env = dict(os.environ, QM2_READER_RAW=raw, QM2_TIMING="1")
+    for name, c in MAN["sets"]["kat"]["cases"].items():
+        rp = _reads_path("kat", name, str(tmp_path))
+        out = str(tmp_path / ("raw_" + name))
+        r = subprocess.run([CLI, "count", "-t", "3", os.path.join(GOLD, "kat", "ref.fa"), rp, out], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        txt = r.stdout.decode(errors="replace")
+        assert r.returncode == 0, (name, txt)
+        assert "total %d kmers" % c["n_kmers"] in txt, name
+        assert open(out + ".bin", "rb").read() == open(os.path.join(GOLD, "kat", name + ".bin"), "rb").read(), name
+        assert md5_file(out + ".txt") == c["txt_md5"], name
+        if "raw input refused" in txt:
+            refused.append(name)
+    if raw == "1":
+        assert set(refused) >= {"long65536", "long65566", "long70000", "long99998"}, refused
+        assert not {"reads_fq", "reads_fa", "crlf", "wrap70000", "long65535"} & set(refused), refused
+    else:
+        assert not refused
+    # several device batches of raw FASTQ (1 MiB batches would need the API; the CLI's are >= 1 GiB): mini set
+    m = MAN["sets"]["mini"]
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    for tag, reads in (("fa", rfa), ("fq", rfq)):
+        out = str(tmp_path / ("rawmini_" + tag))
+        r = subprocess.run([CLI, "count", "-t", "8", os.path.join(GOLD, "mini", "ref.fa"), reads, out], env=env,
+                           stdout=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0 and b"raw input refused" not in r.stdout
+        assert md5_file(out + ".bin") == m["bin_md5"] and md5_file(out + ".txt") == m["txt_md5"]
+
+
 def test_cli_mini_fasta_fastq_and_pipe(tmp_path):
     m = MAN["sets"]["mini"]
     fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
@@ -479,6 +515,47 @@ def test_line_discipline_on_the_device(qm2, torch_cuda, tmp_path):
         assert c.submit_raw_device(d.data_ptr(), d.numel(), True, skip=1) == 1
         with pytest.raises(qm2.Qm2Error, match="aligned"):
             c.submit_raw_device(d.data_ptr() + 1, d.numel() - 1, True, skip=1)
+
+
+def test_raw_blocks_through_staging_cross_device_batches(qm2):
+    """qm2_staging_commit_raw the way the CLI's reader drives it — line-aligned raw blocks with the
+    line state at their first byte — but with device batches of 256 KiB, so that one FASTQ file
+    becomes dozens of raw batches whose state comes from whichever block happens to open them."""
+    import ctypes as C
+    qm = kat_qm()
+    keys = qm["keys"]
+    ref = synth.kat_reference().tobytes()
+    rng = np.random.default_rng(12)
+    recs = [ref[int(p):int(p) + int(l)] for p, l in zip(rng.integers(0, 4000, 30000), rng.integers(30, 300, 30000))]
+    fq = b"".join(b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(recs))
+    fa = b"".join(b">r%d\n" % i + r + b"\n" for i, r in enumerate(recs))
+    want = b"".join(r + b"\n" for r in recs)
+    exp_depth, exp_st = ol.count_lines(keys, 30, want)
+    L = qm2.lib()
+    for data, fastq in ((fq, True), (fa, False)):
+        with qm2.Counter(keys, k=30, staging_bytes=48 << 10, batch_bytes=256 << 10, n_staging=4) as c:
+            at, lines_before = 0, 0
+            while at < len(data):
+                end = min(len(data), at + int(rng.integers(1, 48 << 10)))
+                end = data.rfind(b"\n", at, end) + 1
+                if end <= at:
+                    end = data.find(b"\n", at) + 1
+                skip = (1 - lines_before) % 4 if fastq else 0          # file starts at an '@' header: sequence lines are 1, 5, 9, ...
+                buf, cap = C.c_void_p(), C.c_size_t()
+                assert L.qm2_staging_acquire(c._h, C.byref(buf), C.byref(cap)) == 0
+                assert end - at <= cap.value
+                off = int(rng.integers(0, 64))                          # the reader's blocks do not start at the buffer's first byte
+                off = min(off, cap.value - (end - at))
+                C.memmove(buf.value + off, data[at:end], end - at)
+                assert L.qm2_staging_commit_raw(c._h, buf, off, end - at, 1 if fastq else 0, skip) == 0
+                lines_before += data.count(b"\n", at, end)
+                at = end
+            depth, st = c.finish()
+            assert L.qm2_raw_verdict(c._h) == 0
+            prof = c.profile()
+            assert prof["direct_batches"] + prof["partitioned_batches"] >= 8      # really many batches
+        assert st == exp_st, fastq
+        assert np.array_equal(depth, exp_depth), fastq
 
 
 # ---- 3. device-resident input, any alignment -----------------------------------

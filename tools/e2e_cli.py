@@ -69,9 +69,10 @@ fa[:, 2:] = arr[:len(fa)]
 fa.tofile(os.path.join(work, "reads.fa"))
 print("wrote reads (fq %.1f GB, fa %.1f GB) in %.1f s" % (fq.nbytes / 1e9, fa.nbytes / 1e9, time.time() - t), flush=True)
 del fq, fa, arr, lines
-cli = os.path.join(ROOT, "quick-mer2_amd", "quicKmer2")
+cli = os.environ.get("QM2_E2E_CLI") or os.path.join(ROOT, "quick-mer2_amd", "quicKmer2")
 import re
-runs = [(f, t, e) for f in ("reads.fq", "reads.fa") for t, e in (("4", {"QM2_READER_STREAM": "1"}), ("4", {}), ("8", {}), ("12", {}))]
+runs = [(f, t, e) for f in ("reads.fq", "reads.fa")
+        for t, e in (("4", {}), ("8", {}), ("12", {}), ("8", {"QM2_READER_RAW": "0"}), ("4", {"QM2_READER_RAW": "0", "QM2_READER_STREAM": "1"}))]
 reps = 4
 if scale == "c3":
     runs, reps = [("reads.fq", "8", {})], 2
@@ -87,5 +88,5 @@ for name, thr, extra in runs:
         sec = float(m.group(1)) if m else float("nan")
         best = sec if best is None else min(best, sec)
     print("== %s -t %s %s rc=%d  count phase best: %.3f s = %.2f G bases/s; wall best %.2f s (incl. .qm load, upload, epilogue)" %
-          (name, thr, "stream" if extra else "blocks", r.returncode, best, n_reads * 150 / best / 1e9, min(walls)), flush=True)
+          (name, thr, "host strip, read(2) stream" if "QM2_READER_STREAM" in extra else "host strip, pread blocks" if extra else "device line discipline", r.returncode, best, n_reads * 150 / best / 1e9, min(walls)), flush=True)
 print(out)
