@@ -1,3 +1,6 @@
+/* tools/reader_bench.c — throughput of the host reader alone (qm2_reader.c, no GPU): stripped bytes per second
+ * for a FASTA/FASTQ file and a thread count.  gcc -O3 -pthread -I quick-mer2_amd/csrc tools/reader_bench.c
+ * quick-mer2_amd/csrc/qm2_reader.c; QM2_READER_STREAM / QM2_READER_BLOCKS pick the arrangement. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
