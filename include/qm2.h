@@ -11,14 +11,18 @@
  *   reference region replaced                          entry point
  *   -------------------------------------------------  -------------------------
  *   Kmer_hash/Kmer_depth alloc, QuicKmer.c:353-366      qm2_open
+ *     fread of the key table, :353-359                    (qm2_open's keys, or qm2_keys_from_fd)
  *   thread pool start-up, :368-384                      qm2_open
- *   per-line encode + dispatch loop, :397-456           qm2_submit / qm2_submit_device
+ *   format sniff + line discipline, :393-398, :451-455  caller (qm2_submit takes sequence lines), or
+ *                                                       qm2_staging_commit_raw / qm2_submit_raw_device
+ *   per-line encode + dispatch loop, :397-456           qm2_submit / qm2_staging_commit / qm2_submit_device
  *     rolling 2-bit encoder + canonicaliser, :399-420
  *     Kmer_count_TSK batch worker, :256-296
  *     DJBHash_encode :66-76, Find_hash :90-99
  *     counter increment, :291 / :443
  *   drain + join, :458-479                              qm2_finish
  *   "total %lu kmers" bookkeeping, :445, :481           qm2_stats
+ *   chain read + walk -> depth in genome order, :483-516  qm2_chain_gather(_fd) / qm2_chain_fetch
  *   free, :519-520                                      qm2_close
  *
  * Plain C types only: no torch / HIP types cross this boundary (device
