@@ -178,7 +178,9 @@ def main():
     reduce_ms = None
     if use_dist:
         tr0 = time.perf_counter()
-        dist.reduce(counters, dst=0)
+        step_elems = 1 << 28                     # 1 GiB pieces: no 2^31-element count reaches the collective
+        for a in range(0, counters.numel(), step_elems):
+            dist.reduce(counters[a:a + step_elems], dst=0)
         torch.cuda.synchronize()
         barrier()
         reduce_ms = 1e3 * (time.perf_counter() - tr0)

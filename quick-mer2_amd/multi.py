@@ -114,7 +114,9 @@ class ReplicaJob:
     def finish(self):
         """-> uint16[H] on every rank (mod-2^16 truncation commutes with the sum)."""
         if self.dist.get_world_size() > 1:
-            self.dist.all_reduce(self.counters)
+            step = 1 << 28                   # 1 GiB pieces: no 2^31-element count reaches the collective
+            for a in range(0, self.counters.numel(), step):
+                self.dist.all_reduce(self.counters[a:a + step])
         return (self.counters.cpu().numpy().view(np.uint32) & 0xFFFF).astype(np.uint16)
 
     def close(self):
