@@ -123,6 +123,9 @@ typedef struct {
     uint64_t class_launches[QM2_K_CLASSES];
     double   class_ms[QM2_K_CLASSES];
     uint64_t partitioned_batches, direct_batches;
+    uint64_t fallback_batches; /* partitioned batches whose spill list overflowed: recounted by the
+                                  direct kernel (decided on the device; read at qm2_get_profile,
+                                  which therefore waits for the work submitted so far) */
 } qm2_profile;
 
 /* Create a counting context for a dictionary of `hash_size` slots (power of

@@ -198,7 +198,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     p.buf_slots[1] = slots[1];
     p.n_cursors = 0;
     for (int l = 0; l < p.levels; l++) { p.cursor_off[l] = p.n_cursors; p.n_cursors += p.buckets[l]; }
-    p.spill_cap = want / 2 + 4096;
+    p.spill_cap = want / 4 + 4096;                                     /* 2 B of HBM per input byte */
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++)
         if (p.buf_slots[i]) e = hipMalloc((void **)&p.buf[i], p.buf_slots[i] * sizeof(uint64_t));
@@ -904,6 +904,10 @@ extern "C" int qm2_reset(qm2_ctx *c)
 extern "C" int qm2_get_profile(qm2_ctx *c, qm2_profile *p)
 {
     if (!c || !p) return fail("qm2_get_profile: null argument");
+    if (qm2_sync(c)) return 1;
+    DevStats st;
+    HIP_OK(hipMemcpy(&st, c->stats, sizeof st, hipMemcpyDeviceToHost));
+    c->prof.fallback_batches = st.fallbacks;
     *p = c->prof;
     return 0;
 }

@@ -40,7 +40,7 @@ class Stats(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("n_launches", C.c_uint64), ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double),
                 ("class_launches", C.c_uint64 * 8), ("class_ms", C.c_double * 8),
-                ("partitioned_batches", C.c_uint64), ("direct_batches", C.c_uint64)]
+                ("partitioned_batches", C.c_uint64), ("direct_batches", C.c_uint64), ("fallback_batches", C.c_uint64)]
 
 
 class Range(C.Structure):
@@ -265,7 +265,8 @@ class Counter:
                 "last_kernel_ms": float(p.last_kernel_ms),
                 "class_launches": {KERNEL_CLASSES[i]: int(p.class_launches[i]) for i in range(6)},
                 "class_ms": {KERNEL_CLASSES[i]: float(p.class_ms[i]) for i in range(6)},
-                "partitioned_batches": int(p.partitioned_batches), "direct_batches": int(p.direct_batches)}
+                "partitioned_batches": int(p.partitioned_batches), "direct_batches": int(p.direct_batches),
+                "fallback_batches": int(p.fallback_batches)}
 
     @property
     def counters_ptr(self):

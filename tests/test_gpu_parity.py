@@ -314,13 +314,14 @@ def test_skewed_input_spills_and_falls_back(qm2):
     ref = synth.kat_reference().tobytes()
     rng = np.random.default_rng(8)
     normal = b"".join(ref[int(p):int(p) + 150] + b"\n" for p in rng.integers(0, 4800, 4000))
-    mild = normal + (b"A" * 150 + b"\n") * 2500 + (b"T" * 150 + b"\n") * 500
+    mild = normal + (b"A" * 150 + b"\n") * 600 + (b"T" * 150 + b"\n") * 150      # 16 % of the batch in one bucket: spill list
     total = (b"A" * 150 + b"\n") * 12000
     for name, blob in (("mild", mild), ("total", total)):
         exp_depth, exp_st = ol.count_lines(keys, 30, blob)
         with qm2.Counter(keys, k=30, flags=qm2.FLAG_PARTITION | qm2.FLAG_TIMING) as c:
             c.submit(blob)
             depth, st = c.finish()
+            assert c.profile()["fallback_batches"] == (1 if name == "total" else 0), name   # spill list vs recount
             c.submit(normal)                       # the context keeps working after a fallback
             depth2, st2 = c.finish()
         assert st == exp_st, name
