@@ -113,6 +113,7 @@ enum {
     QM2_K_BUCKET_COUNT = 3,   /* bucket_count_kernel: probe + count in LDS        */
     QM2_K_PROBE        = 4,   /* probe_kernel: spill list / qm2_probe_device      */
     QM2_K_ENCODE       = 5,   /* encode_kernel (qm2_encode_device)                */
+    QM2_K_LINES        = 6,   /* raw_tile / raw_scan / raw_apply: line discipline   */
     QM2_K_CLASSES      = 8
 };
 

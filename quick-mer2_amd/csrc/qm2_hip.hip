@@ -768,20 +768,29 @@ static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint3
         if (c->raw_tiles) HIP_OK(hipFree(c->raw_tiles));
         c->raw_tiles = nullptr;
         c->raw_tile_cap = n_tiles + n_tiles / 8 + 16;
-        HIP_OK(hipMalloc(&c->raw_tiles, c->raw_tile_cap * 32));
+        HIP_OK(hipMalloc(&c->raw_tiles, c->raw_tile_cap * 40));
     }
     if (!c->raw_flags) HIP_OK(hipMalloc((void **)&c->raw_flags, sizeof(unsigned int)));
-    /* scratch layout: i64 last[cap] | u64 before[cap] | i64 prev[cap] | u32 count[cap] */
+    /* scratch layout (cap = tile capacity; the group arrays use its first n_groups entries):
+     * i64 tile_last[cap] | i64 group_last[cap] | u64 group_before[cap] | i64 group_prev[cap] | u32 tile_nl[cap] | u32 group_nl[cap] */
+    const uint64_t n_groups = (n_tiles + kRawGroup - 1) / kRawGroup;
     long long *t_last = (long long *)c->raw_tiles;
-    uint64_t *t_before = (uint64_t *)(t_last + c->raw_tile_cap);
-    long long *t_prev = (long long *)(t_before + c->raw_tile_cap);
-    uint32_t *t_nl = (uint32_t *)(t_prev + c->raw_tile_cap);
+    long long *g_last = t_last + c->raw_tile_cap;
+    uint64_t *g_before = (uint64_t *)(g_last + c->raw_tile_cap);
+    long long *g_prev = (long long *)(g_before + c->raw_tile_cap);
+    uint32_t *t_nl = (uint32_t *)(g_prev + c->raw_tile_cap);
+    uint32_t *g_nl = t_nl + c->raw_tile_cap;
     RawView rv = {(const uint8_t *)d_raw, c->raw_out, (uint64_t)n, fastq ? 1u : 0u, fastq ? skip : 0u};
     HIP_OK(hipMemsetAsync(c->raw_flags, 0, sizeof(unsigned int), s));
+    TimedLaunch t;
+    if (time_begin(c, &t, QM2_K_LINES)) return 1;
     hipLaunchKernelGGL(raw_tile_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, t_nl, t_last);
-    hipLaunchKernelGGL(raw_scan_kernel, dim3(1), dim3(1024), 0, s, t_nl, t_last, n_tiles, t_before, t_prev);
-    hipLaunchKernelGGL(raw_apply_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, t_before, t_prev, c->raw_flags);
+    hipLaunchKernelGGL(raw_group_kernel, dim3((uint32_t)n_groups), dim3(kRawThreads), 0, s, t_nl, t_last, n_tiles, g_nl, g_last);
+    hipLaunchKernelGGL(raw_scan_kernel, dim3(1), dim3(1024), 0, s, g_nl, g_last, n_groups, g_before, g_prev);
+    hipLaunchKernelGGL(raw_apply_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, t_nl, t_last, g_before, g_prev,
+                       c->raw_flags);
     HIP_OK(hipGetLastError());
+    if (time_end(c, &t)) return 1;
     unsigned int flags = 0;
     HIP_OK(hipMemcpyAsync(&flags, c->raw_flags, sizeof flags, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));

@@ -17,12 +17,14 @@
  * a flag word instead of being counted wrongly; the caller takes the host path for
  * such a block.
  *
- * Three passes over 4 KiB tiles (256 threads x 16 bytes):
+ * Passes over 4 KiB tiles (256 threads x 16 bytes), 256 tiles to a group:
  *   raw_tile_kernel   per tile: number of '\n', position of the last one
- *   raw_scan_kernel   exclusive prefix of the counts (= line number at the tile's
- *                     first byte) and running maximum of the positions (= where the
- *                     line in progress there started), one workgroup
- *   raw_apply_kernel  per byte: line number, first byte of its line -> keep or '\n'
+ *   raw_group_kernel  the same per group of 256 tiles
+ *   raw_scan_kernel   over the groups (a few thousand: one workgroup): exclusive prefix of the
+ *                     counts and running maximum of the positions
+ *   raw_apply_kernel  finishes the prefix inside its group (256 values, one per thread), which
+ *                     gives the line number at the tile's first byte and where the line in
+ *                     progress there started; then per byte: keep, or '\n'
  * All streaming: 1 B read + 1 B read + 1 B written per input byte.
  */
 #pragma once
@@ -93,7 +95,38 @@ __global__ __launch_bounds__(kRawThreads) void raw_tile_kernel(RawView rv, uint3
     }
 }
 
-/* one workgroup: tile_before[t] = newlines in tiles < t; tile_prev[t] = last newline position in tiles < t (-1: none) */
+constexpr int kRawGroup = kRawThreads;      /* tiles per group: one per thread of raw_apply_kernel */
+
+/* sum / max of a value pair over the workgroup (all threads get the result) */
+__device__ __forceinline__ void raw_block_reduce(uint32_t &cnt, long long &last, uint32_t *s_cnt, long long *s_last)
+{
+    for (int d = 1; d < kWave; d <<= 1) {
+        cnt += __shfl_xor(cnt, d);
+        const long long o = __shfl_xor(last, d);
+        last = o > last ? o : last;
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    __syncthreads();                                          /* s_* may still be read from a previous use */
+    if (lane == 0) { s_cnt[wave] = cnt; s_last[wave] = last; }
+    __syncthreads();
+    cnt = 0;
+    last = -1;
+    for (int w = 0; w < kRawThreads / kWave; w++) { cnt += s_cnt[w]; last = s_last[w] > last ? s_last[w] : last; }
+}
+
+__global__ __launch_bounds__(kRawThreads) void raw_group_kernel(const uint32_t *tile_nl, const long long *tile_last, uint64_t n_tiles,
+                                                                uint32_t *group_nl, long long *group_last)
+{
+    __shared__ uint32_t s_cnt[kRawThreads / kWave];
+    __shared__ long long s_last[kRawThreads / kWave];
+    const uint64_t t = (uint64_t)blockIdx.x * kRawGroup + threadIdx.x;
+    uint32_t cnt = t < n_tiles ? tile_nl[t] : 0;
+    long long last = t < n_tiles ? tile_last[t] : -1;
+    raw_block_reduce(cnt, last, s_cnt, s_last);
+    if (threadIdx.x == 0) { group_nl[blockIdx.x] = cnt; group_last[blockIdx.x] = last; }
+}
+
+/* one workgroup over the GROUPS: before[g] = newlines in groups < g; prev[g] = last newline position in groups < g (-1: none) */
 __global__ __launch_bounds__(1024) void raw_scan_kernel(const uint32_t *tile_nl, const long long *tile_last, uint64_t n_tiles,
                                                         uint64_t *tile_before, long long *tile_prev)
 {
@@ -130,11 +163,25 @@ __global__ __launch_bounds__(1024) void raw_scan_kernel(const uint32_t *tile_nl,
     }
 }
 
-__global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, const uint64_t *tile_before, const long long *tile_prev,
+__global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, const uint32_t *tile_nl, const long long *tile_last,
+                                                                const uint64_t *group_before, const long long *group_prev,
                                                                 unsigned int *flags)
 {
     __shared__ uint32_t s_cnt[kRawThreads / kWave];
     __shared__ long long s_last[kRawThreads / kWave];
+    /* the tiles of this group in front of this one: thread t looks at tile t of the group */
+    uint64_t tile_line;
+    long long tile_prev_nl;
+    {
+        const uint32_t g = blockIdx.x / kRawGroup, j = blockIdx.x % kRawGroup;
+        const uint64_t t = (uint64_t)g * kRawGroup + threadIdx.x;
+        uint32_t c = threadIdx.x < j ? tile_nl[t] : 0;
+        long long l = threadIdx.x < j ? tile_last[t] : -1;
+        raw_block_reduce(c, l, s_cnt, s_last);
+        tile_line = group_before[g] + c;
+        tile_prev_nl = group_prev[g] > l ? group_prev[g] : l;
+        __syncthreads();
+    }
     const uint64_t at = (uint64_t)blockIdx.x * kRawTile + threadIdx.x * 16;
     const uint4 v = load_raw16(rv, at);
     const uint32_t m = newline_mask16(v);
@@ -151,8 +198,8 @@ __global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, cons
     }
     if (lane == kWave - 1) { s_cnt[wave] = icnt; s_last[wave] = ilast; }
     __syncthreads();
-    uint64_t line = tile_before[blockIdx.x];
-    long long prev = tile_prev[blockIdx.x];
+    uint64_t line = tile_line;
+    long long prev = tile_prev_nl;
     for (int w = 0; w < wave; w++) { line += s_cnt[w]; prev = s_last[w] > prev ? s_last[w] : prev; }
     {
         const uint32_t ec = __shfl_up(icnt, 1);

@@ -18,7 +18,7 @@ FLAG_NO_STATS = 0x2
 FLAG_DIRECT = 0x4
 FLAG_PARTITION = 0x8
 FLAG_KEYS_LATER = 0x10
-KERNEL_CLASSES = ["count_direct", "split_text", "split_kmer", "bucket_count", "probe", "encode", "-", "-"]
+KERNEL_CLASSES = ["count_direct", "split_text", "split_kmer", "bucket_count", "probe", "encode", "lines", "-"]
 
 
 class Opts(C.Structure):
@@ -263,8 +263,8 @@ class Counter:
         _check(lib().qm2_get_profile(self._h, C.byref(p)), "qm2_get_profile")
         return {"n_launches": int(p.n_launches), "kernel_ms": float(p.kernel_ms),
                 "last_kernel_ms": float(p.last_kernel_ms),
-                "class_launches": {KERNEL_CLASSES[i]: int(p.class_launches[i]) for i in range(6)},
-                "class_ms": {KERNEL_CLASSES[i]: float(p.class_ms[i]) for i in range(6)},
+                "class_launches": {KERNEL_CLASSES[i]: int(p.class_launches[i]) for i in range(7)},
+                "class_ms": {KERNEL_CLASSES[i]: float(p.class_ms[i]) for i in range(7)},
                 "partitioned_batches": int(p.partitioned_batches), "direct_batches": int(p.direct_batches),
                 "fallback_batches": int(p.fallback_batches)}
 
