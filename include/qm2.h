@@ -230,15 +230,17 @@ int qm2_chain_fetch(qm2_ctx *c, uint16_t *out, uint64_t offset, uint64_t count);
  * 16-byte aligned.  fastq = the format the first line of the file decided (:395);
  * skip (FASTQ only, 0..3) = lines to drop before the first sequence line of this block
  * (1 for a block that starts at an '@' header).  Headers, '+' lines and qualities are
- * blanked on the device and the rest is counted like qm2_submit_device.  Two things cannot
+ * blanked on the device and the rest is counted like qm2_submit_device (long lines included:
+ * the uint16 wrap of :402 is reproduced).  Two things cannot
  * be counted this way and are reported in *verdict instead (nothing of the block is
  * counted then; the caller strips it on the host and uses qm2_submit):
  *   QM2_RAW_DESYNC     a FASTQ sequence-position line starts with '>' (:398 skips it without
  *                      the three discards, so the phase stops following the line number)
- *   QM2_RAW_LONG_LINE  a line longer than 65535 bytes (uint16 run counter, :402)
+ *   QM2_RAW_MANY_WRAPS more than 8192 runs of >= 65536 bases without 'N' in one batch (the uint16
+ *                      run counter of :402 wraps there; the device keeps a list of those places)
  * The call waits for the classification (not for the counting). */
 #define QM2_RAW_DESYNC    1u
-#define QM2_RAW_LONG_LINE 2u
+#define QM2_RAW_MANY_WRAPS 2u
 int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
                           uint32_t *verdict);
 

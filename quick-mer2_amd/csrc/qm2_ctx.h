@@ -106,9 +106,10 @@ struct qm2_ctx {
     /* device-side line discipline (qm2_raw.hip.h): neutralised copy of a raw block + tile scratch */
     uint8_t    *raw_out = nullptr;
     uint64_t    raw_cap = 0;
-    void       *raw_tiles = nullptr;        /* per 4 KiB tile: u32 count, i64 last, u64 before, i64 prev */
+    void       *raw_tiles = nullptr;        /* scan scratch: 40 bytes per 4 KiB tile */
     uint64_t    raw_tile_cap = 0;
-    unsigned int *raw_flags = nullptr;
+    unsigned int *raw_flags = nullptr;      /* [0] refusal bits, [1] wrap count */
+    uint64_t   *raw_wraps = nullptr;        /* where the uint16 run counter wraps (qm2_raw.hip.h), sorted */
     uint32_t    raw_verdict = 0;            /* sticky: a raw batch was refused (QM2_RAW_*); nothing raw is counted after it */
     /* epilogue (qm2_epilogue.hip) */
     uint32_t   *chain = nullptr;            /* device copy of next[]; aliases keys when owned */

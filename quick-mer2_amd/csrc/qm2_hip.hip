@@ -546,6 +546,7 @@ extern "C" void qm2_close(qm2_ctx *c)
     if (c->raw_out) (void)hipFree(c->raw_out);
     if (c->raw_tiles) (void)hipFree(c->raw_tiles);
     if (c->raw_flags) (void)hipFree(c->raw_flags);
+    if (c->raw_wraps) (void)hipFree(c->raw_wraps);
     if (c->peek_evt) (void)hipEventDestroy(c->peek_evt);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -770,32 +771,35 @@ static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint3
         c->raw_tile_cap = n_tiles + n_tiles / 8 + 16;
         HIP_OK(hipMalloc(&c->raw_tiles, c->raw_tile_cap * 40));
     }
-    if (!c->raw_flags) HIP_OK(hipMalloc((void **)&c->raw_flags, sizeof(unsigned int)));
-    /* scratch layout (cap = tile capacity; the group arrays use its first n_groups entries):
-     * i64 tile_last[cap] | i64 group_last[cap] | u64 group_before[cap] | i64 group_prev[cap] | u32 tile_nl[cap] | u32 group_nl[cap] */
-    const uint64_t n_groups = (n_tiles + kRawGroup - 1) / kRawGroup;
-    long long *t_last = (long long *)c->raw_tiles;
-    long long *g_last = t_last + c->raw_tile_cap;
-    uint64_t *g_before = (uint64_t *)(g_last + c->raw_tile_cap);
-    long long *g_prev = (long long *)(g_before + c->raw_tile_cap);
-    uint32_t *t_nl = (uint32_t *)(g_prev + c->raw_tile_cap);
-    uint32_t *g_nl = t_nl + c->raw_tile_cap;
+    if (!c->raw_flags) {
+        HIP_OK(hipMalloc((void **)&c->raw_flags, 2 * sizeof(unsigned int)));
+        HIP_OK(hipMalloc((void **)&c->raw_wraps, kRawWrapCap * sizeof(uint64_t)));
+    }
+    /* scratch: three channels (i64 last newline, i64 last reset, u32 newline count) per tile and per
+     * group; the group arrays use the first n_groups entries of their cap-sized slices */
+    const uint64_t n_groups = (n_tiles + kRawGroup - 1) / kRawGroup, cap = c->raw_tile_cap;
+    long long *i64s = (long long *)c->raw_tiles;
+    uint32_t *u32s = (uint32_t *)(i64s + 4 * cap);
+    const RawArrays tile = {u32s, i64s, i64s + cap}, group = {u32s + cap, i64s + 2 * cap, i64s + 3 * cap};
     RawView rv = {(const uint8_t *)d_raw, c->raw_out, (uint64_t)n, fastq ? 1u : 0u, fastq ? skip : 0u};
-    HIP_OK(hipMemsetAsync(c->raw_flags, 0, sizeof(unsigned int), s));
+    /* raw_flags[0] = refusal bits, [1] = number of wrap positions */
+    HIP_OK(hipMemsetAsync(c->raw_flags, 0, 2 * sizeof(unsigned int), s));
     TimedLaunch t;
     if (time_begin(c, &t, QM2_K_LINES)) return 1;
-    hipLaunchKernelGGL(raw_tile_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, t_nl, t_last);
-    hipLaunchKernelGGL(raw_group_kernel, dim3((uint32_t)n_groups), dim3(kRawThreads), 0, s, t_nl, t_last, n_tiles, g_nl, g_last);
-    hipLaunchKernelGGL(raw_scan_kernel, dim3(1), dim3(1024), 0, s, g_nl, g_last, n_groups, g_before, g_prev);
-    hipLaunchKernelGGL(raw_apply_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, t_nl, t_last, g_before, g_prev,
-                       c->raw_flags);
+    hipLaunchKernelGGL(raw_tile_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, tile);
+    hipLaunchKernelGGL(raw_group_kernel, dim3((uint32_t)n_groups), dim3(kRawThreads), 0, s, tile, n_tiles, group);
+    hipLaunchKernelGGL(raw_scan_kernel, dim3(1), dim3(1024), 0, s, group, n_groups);
+    hipLaunchKernelGGL(raw_apply_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, tile, group, c->raw_flags,
+                       c->raw_wraps, c->raw_flags + 1);
+    hipLaunchKernelGGL(raw_sort_kernel, dim3(1), dim3(1024), 0, s, c->raw_wraps, c->raw_flags + 1);
     HIP_OK(hipGetLastError());
     if (time_end(c, &t)) return 1;
-    unsigned int flags = 0;
-    HIP_OK(hipMemcpyAsync(&flags, c->raw_flags, sizeof flags, hipMemcpyDeviceToHost, s));
+    unsigned int fl[2] = {0, 0};
+    HIP_OK(hipMemcpyAsync(fl, c->raw_flags, sizeof fl, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
-    if (flags) { *verdict = flags; return 0; }               /* not counted: the caller takes the host path */
-    return launch_batch(c, c->raw_out, n + 1, 0, nullptr, 0);  /* + the terminator raw_apply_kernel wrote at [n] */
+    if (fl[0]) { *verdict = fl[0]; return 0; }               /* not counted: the caller takes the host path */
+    /* + the terminator raw_apply_kernel wrote at [n]; the wrap list plays the part of qm2_plan.h's */
+    return launch_batch(c, c->raw_out, n + 1, 0, fl[1] ? c->raw_wraps : nullptr, fl[1]);
 }
 
 extern "C" int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,

@@ -12,19 +12,25 @@
  *   FASTA  line L is a sequence line  iff  its first byte is not '>'.
  * A FASTQ sequence-position line that starts with '>' is skipped WITHOUT the three
  * drops (:398 comes before :451): from there on the phase is no longer a function
- * of the line number.  That, and a line longer than 65535 bytes (the uint16 run
- * counter of :402 would wrap and this path carries no wrap list), are reported in
- * a flag word instead of being counted wrongly; the caller takes the host path for
- * such a block.
+ * of the line number.  That is reported in a flag word instead of being counted
+ * wrongly; the caller takes the host path for such a block.
+ *
+ * The uint16 run counter of :402 wraps after 65535 bases without an 'N' or a line
+ * end, and the k-1 windows behind the wrap are lost (:418).  The count kernels take
+ * the wrap positions as a sorted list (as qm2_submit's host planner makes it,
+ * qm2_plan.h); here the same list comes from a third scan channel — the position of
+ * the last RESET ('N' or '\n') — so that every kept byte knows how far into its
+ * N-free run it is.  Only a batch with more wraps than the list holds is refused.
  *
  * Passes over 4 KiB tiles (256 threads x 16 bytes), 256 tiles to a group:
- *   raw_tile_kernel   per tile: number of '\n', position of the last one
+ *   raw_tile_kernel   per tile: number of '\n', position of the last one, of the last reset
  *   raw_group_kernel  the same per group of 256 tiles
  *   raw_scan_kernel   over the groups (a few thousand: one workgroup): exclusive prefix of the
- *                     counts and running maximum of the positions
+ *                     counts and running maxima of the positions
  *   raw_apply_kernel  finishes the prefix inside its group (256 values, one per thread), which
- *                     gives the line number at the tile's first byte and where the line in
- *                     progress there started; then per byte: keep, or '\n'
+ *                     gives the line number at the tile's first byte and where the line and
+ *                     the N-free run in progress there started; then per byte: keep, or '\n'
+ *   raw_sort_kernel   the (few) wrap positions, appended in any order, into ascending order
  * All streaming: 1 B read + 1 B read + 1 B written per input byte.
  */
 #pragma once
@@ -34,9 +40,10 @@ namespace qm2 {
 
 constexpr int      kRawThreads = 256;
 constexpr uint32_t kRawTile = kRawThreads * 16;
+constexpr int      kRawGroup = kRawThreads;  /* tiles per group: one per thread of raw_apply_kernel */
 constexpr uint32_t kRawDesync = 1u;          /* flag bits */
-constexpr uint32_t kRawLongLine = 2u;
-constexpr uint32_t kRawMaxLine = 65535;
+constexpr uint32_t kRawTooManyWraps = 2u;
+constexpr uint32_t kRawWrapCap = 8192;       /* wrap positions per batch (one per 65536-base run: thousands of such reads) */
 
 struct RawView {
     const uint8_t *in;      /* 16-byte aligned */
@@ -45,14 +52,37 @@ struct RawView {
     uint32_t       fastq, skip;
 };
 
-/* 16-bit mask of the '\n' bytes of v (bit j = byte j) */
-__device__ __forceinline__ uint32_t newline_mask16(uint4 v)
+/* what the scans carry: newlines so far, position of the last newline, of the last reset ('N' or newline) */
+struct RawAgg {
+    uint32_t  cnt;
+    long long nl, rst;
+};
+__device__ __forceinline__ RawAgg raw_join(RawAgg a, RawAgg b)
+{
+    RawAgg r;
+    r.cnt = a.cnt + b.cnt;
+    r.nl = a.nl > b.nl ? a.nl : b.nl;
+    r.rst = a.rst > b.rst ? a.rst : b.rst;
+    return r;
+}
+constexpr RawAgg kRawNone = {0u, -1, -1};
+
+/* per-tile / per-group arrays of the three channels */
+struct RawArrays {
+    uint32_t  *cnt;
+    long long *nl, *rst;
+};
+__device__ __forceinline__ RawAgg raw_get(const RawArrays &a, uint64_t i) { RawAgg r = {a.cnt[i], a.nl[i], a.rst[i]}; return r; }
+__device__ __forceinline__ void raw_put(const RawArrays &a, uint64_t i, RawAgg v) { a.cnt[i] = v.cnt; a.nl[i] = v.nl; a.rst[i] = v.rst; }
+
+/* 16-bit mask of the bytes of v that equal c (bit j = byte j) */
+__device__ __forceinline__ uint32_t byte_mask16(uint4 v, uint32_t c)
 {
     uint32_t m = 0;
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const uint32_t z = zero_bytes(w[i] ^ 0x0A0A0A0Au);      /* 0x80 in every byte that is '\n' */
+        const uint32_t z = zero_bytes(w[i] ^ (c * 0x01010101u));      /* 0x80 in every byte that is c */
         m |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * i);
     }
     return m;
@@ -70,147 +100,118 @@ __device__ __forceinline__ uint4 load_raw16(const RawView &rv, uint64_t at)
     return v;
 }
 
-__global__ __launch_bounds__(kRawThreads) void raw_tile_kernel(RawView rv, uint32_t *tile_nl, long long *tile_last)
+/* what one thread's 16 bytes contribute */
+__device__ __forceinline__ RawAgg raw_of16(uint4 v, uint64_t at)
 {
-    __shared__ uint32_t s_cnt[kRawThreads / kWave];
-    __shared__ long long s_last[kRawThreads / kWave];
+    const uint32_t nl = byte_mask16(v, '\n'), rs = nl | byte_mask16(v, 'N');
+    RawAgg a;
+    a.cnt = __popc(nl);
+    a.nl = nl ? (long long)at + (31 - __clz(nl)) : -1;
+    a.rst = rs ? (long long)at + (31 - __clz(rs)) : -1;
+    return a;
+}
+
+/* join over the workgroup (all threads get the result) */
+__device__ __forceinline__ RawAgg raw_block_reduce(RawAgg v, RawAgg *s)
+{
+    for (int d = 1; d < kWave; d <<= 1) {
+        RawAgg o;
+        o.cnt = __shfl_xor(v.cnt, d);
+        o.nl = __shfl_xor(v.nl, d);
+        o.rst = __shfl_xor(v.rst, d);
+        v = raw_join(v, o);
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    __syncthreads();                                          /* s may still be read from a previous use */
+    if (lane == 0) s[wave] = v;
+    __syncthreads();
+    RawAgg r = kRawNone;
+    for (int w = 0; w < kRawThreads / kWave; w++) r = raw_join(r, s[w]);
+    return r;
+}
+
+__global__ __launch_bounds__(kRawThreads) void raw_tile_kernel(RawView rv, RawArrays tile)
+{
+    __shared__ RawAgg s[kRawThreads / kWave];
     const uint64_t at = (uint64_t)blockIdx.x * kRawTile + threadIdx.x * 16;
-    const uint32_t m = newline_mask16(load_raw16(rv, at));
-    uint32_t cnt = __popc(m);
-    long long last = m ? (long long)at + (31 - __clz(m)) : -1;
-    for (int d = 1; d < kWave; d <<= 1) {
-        cnt += __shfl_xor(cnt, d);
-        const long long o = __shfl_xor(last, d);
-        last = o > last ? o : last;
-    }
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (lane == 0) { s_cnt[wave] = cnt; s_last[wave] = last; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t c = 0;
-        long long l = -1;
-        for (int w = 0; w < kRawThreads / kWave; w++) { c += s_cnt[w]; l = s_last[w] > l ? s_last[w] : l; }
-        tile_nl[blockIdx.x] = c;
-        tile_last[blockIdx.x] = l;
-    }
+    const RawAgg r = raw_block_reduce(raw_of16(load_raw16(rv, at), at), s);
+    if (threadIdx.x == 0) raw_put(tile, blockIdx.x, r);
 }
 
-constexpr int kRawGroup = kRawThreads;      /* tiles per group: one per thread of raw_apply_kernel */
-
-/* sum / max of a value pair over the workgroup (all threads get the result) */
-__device__ __forceinline__ void raw_block_reduce(uint32_t &cnt, long long &last, uint32_t *s_cnt, long long *s_last)
+__global__ __launch_bounds__(kRawThreads) void raw_group_kernel(RawArrays tile, uint64_t n_tiles, RawArrays group)
 {
-    for (int d = 1; d < kWave; d <<= 1) {
-        cnt += __shfl_xor(cnt, d);
-        const long long o = __shfl_xor(last, d);
-        last = o > last ? o : last;
-    }
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    __syncthreads();                                          /* s_* may still be read from a previous use */
-    if (lane == 0) { s_cnt[wave] = cnt; s_last[wave] = last; }
-    __syncthreads();
-    cnt = 0;
-    last = -1;
-    for (int w = 0; w < kRawThreads / kWave; w++) { cnt += s_cnt[w]; last = s_last[w] > last ? s_last[w] : last; }
-}
-
-__global__ __launch_bounds__(kRawThreads) void raw_group_kernel(const uint32_t *tile_nl, const long long *tile_last, uint64_t n_tiles,
-                                                                uint32_t *group_nl, long long *group_last)
-{
-    __shared__ uint32_t s_cnt[kRawThreads / kWave];
-    __shared__ long long s_last[kRawThreads / kWave];
+    __shared__ RawAgg s[kRawThreads / kWave];
     const uint64_t t = (uint64_t)blockIdx.x * kRawGroup + threadIdx.x;
-    uint32_t cnt = t < n_tiles ? tile_nl[t] : 0;
-    long long last = t < n_tiles ? tile_last[t] : -1;
-    raw_block_reduce(cnt, last, s_cnt, s_last);
-    if (threadIdx.x == 0) { group_nl[blockIdx.x] = cnt; group_last[blockIdx.x] = last; }
+    const RawAgg r = raw_block_reduce(t < n_tiles ? raw_get(tile, t) : kRawNone, s);
+    if (threadIdx.x == 0) raw_put(group, blockIdx.x, r);
 }
 
-/* one workgroup over the GROUPS: before[g] = newlines in groups < g; prev[g] = last newline position in groups < g (-1: none) */
-__global__ __launch_bounds__(1024) void raw_scan_kernel(const uint32_t *tile_nl, const long long *tile_last, uint64_t n_tiles,
-                                                        uint64_t *tile_before, long long *tile_prev)
+/* one workgroup over the GROUPS, in place: group[g] becomes the join of the groups in front of g */
+__global__ __launch_bounds__(1024) void raw_scan_kernel(RawArrays group, uint64_t n_groups)
 {
-    __shared__ uint64_t s_sum[1024];
-    __shared__ long long s_max[1024];
-    const uint64_t per = (n_tiles + 1023) / 1024;
-    const uint64_t lo = (uint64_t)threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
-    uint64_t sum = 0;
-    long long mx = -1;
-    for (uint64_t t = lo; t < hi; t++) { sum += tile_nl[t]; mx = tile_last[t] > mx ? tile_last[t] : mx; }
-    s_sum[threadIdx.x] = sum;
-    s_max[threadIdx.x] = mx;
+    __shared__ RawAgg s[1024];
+    const uint64_t per = (n_groups + 1023) / 1024;
+    const uint64_t lo = (uint64_t)threadIdx.x * per, hi = lo + per < n_groups ? lo + per : n_groups;
+    RawAgg acc = kRawNone;
+    for (uint64_t g = lo; g < hi; g++) acc = raw_join(acc, raw_get(group, g));
+    s[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {                                   /* 1024 partials: serial is microseconds */
-        uint64_t run = 0;
-        long long rmx = -1;
+        RawAgg run = kRawNone;
         for (int i = 0; i < 1024; i++) {
-            const uint64_t s = s_sum[i];
-            const long long m = s_max[i];
-            s_sum[i] = run;
-            s_max[i] = rmx;
-            run += s;
-            rmx = m > rmx ? m : rmx;
+            const RawAgg mine = s[i];
+            s[i] = run;
+            run = raw_join(run, mine);
         }
     }
     __syncthreads();
-    sum = s_sum[threadIdx.x];
-    mx = s_max[threadIdx.x];
-    for (uint64_t t = lo; t < hi; t++) {
-        tile_before[t] = sum;
-        tile_prev[t] = mx;
-        sum += tile_nl[t];
-        mx = tile_last[t] > mx ? tile_last[t] : mx;
+    acc = s[threadIdx.x];
+    for (uint64_t g = lo; g < hi; g++) {
+        const RawAgg mine = raw_get(group, g);
+        raw_put(group, g, acc);
+        acc = raw_join(acc, mine);
     }
 }
 
-__global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, const uint32_t *tile_nl, const long long *tile_last,
-                                                                const uint64_t *group_before, const long long *group_prev,
-                                                                unsigned int *flags)
+__global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, RawArrays tile, RawArrays group_before,
+                                                                unsigned int *flags, uint64_t *wraps, unsigned int *n_wraps)
 {
-    __shared__ uint32_t s_cnt[kRawThreads / kWave];
-    __shared__ long long s_last[kRawThreads / kWave];
+    __shared__ RawAgg s[kRawThreads / kWave];
     /* the tiles of this group in front of this one: thread t looks at tile t of the group */
-    uint64_t tile_line;
-    long long tile_prev_nl;
-    {
-        const uint32_t g = blockIdx.x / kRawGroup, j = blockIdx.x % kRawGroup;
-        const uint64_t t = (uint64_t)g * kRawGroup + threadIdx.x;
-        uint32_t c = threadIdx.x < j ? tile_nl[t] : 0;
-        long long l = threadIdx.x < j ? tile_last[t] : -1;
-        raw_block_reduce(c, l, s_cnt, s_last);
-        tile_line = group_before[g] + c;
-        tile_prev_nl = group_prev[g] > l ? group_prev[g] : l;
-        __syncthreads();
-    }
+    const uint32_t g = blockIdx.x / kRawGroup, j_tile = blockIdx.x % kRawGroup;
+    RawAgg before = raw_block_reduce((uint32_t)threadIdx.x < j_tile ? raw_get(tile, (uint64_t)g * kRawGroup + threadIdx.x) : kRawNone, s);
+    before = raw_join(raw_get(group_before, g), before);
+    __syncthreads();
     const uint64_t at = (uint64_t)blockIdx.x * kRawTile + threadIdx.x * 16;
     const uint4 v = load_raw16(rv, at);
-    const uint32_t m = newline_mask16(v);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    /* inclusive scans over the wave, then made exclusive */
-    uint32_t cnt = __popc(m);
-    long long last = m ? (long long)at + (31 - __clz(m)) : -1;
-    uint32_t icnt = cnt;
-    long long ilast = last;
+    /* inclusive scan over the wave, then made exclusive */
+    const RawAgg mine = raw_of16(v, at);
+    RawAgg inc = mine;
     for (int d = 1; d < kWave; d <<= 1) {
-        const uint32_t c = __shfl_up(icnt, d);
-        const long long l = __shfl_up(ilast, d);
-        if (lane >= d) { icnt += c; ilast = l > ilast ? l : ilast; }
+        RawAgg o;
+        o.cnt = __shfl_up(inc.cnt, d);
+        o.nl = __shfl_up(inc.nl, d);
+        o.rst = __shfl_up(inc.rst, d);
+        if (lane >= d) inc = raw_join(o, inc);
     }
-    if (lane == kWave - 1) { s_cnt[wave] = icnt; s_last[wave] = ilast; }
+    if (lane == kWave - 1) s[wave] = inc;
     __syncthreads();
-    uint64_t line = tile_line;
-    long long prev = tile_prev_nl;
-    for (int w = 0; w < wave; w++) { line += s_cnt[w]; prev = s_last[w] > prev ? s_last[w] : prev; }
+    for (int w = 0; w < wave; w++) before = raw_join(before, s[w]);
     {
-        const uint32_t ec = __shfl_up(icnt, 1);
-        const long long el = __shfl_up(ilast, 1);
-        if (lane > 0) { line += ec; prev = el > prev ? el : prev; }
+        RawAgg e;
+        e.cnt = __shfl_up(inc.cnt, 1);
+        e.nl = __shfl_up(inc.nl, 1);
+        e.rst = __shfl_up(inc.rst, 1);
+        if (lane > 0) before = raw_join(before, e);
     }
     if (at >= rv.n) return;
-    /* the line in progress at this thread's first byte started at `start`; its first byte decides FASTA lines */
-    uint64_t start = (uint64_t)(prev + 1);
+    /* the line in progress at this thread's first byte started at `start`; its first byte decides FASTA
+     * lines; the N-free run in progress started at `run` */
+    uint64_t line = before.cnt;
+    uint64_t start = (uint64_t)(before.nl + 1), run = (uint64_t)(before.rst + 1);
     const uint8_t *b = (const uint8_t *)&v;
-    uint8_t first = start == at ? b[0] : rv.in[start];
+    const uint8_t first = start == at ? b[0] : rv.in[start];
     auto keep_line = [&](uint64_t l, uint8_t fc) {
         if (rv.fastq) {
             const bool seq = l >= rv.skip && ((l - rv.skip) & 3u) == 0;
@@ -221,7 +222,6 @@ __global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, cons
     };
     bool keep = keep_line(line, first);
     uint8_t o[16];
-    unsigned int fl = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint64_t p = at + j;
@@ -229,17 +229,45 @@ __global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, cons
         const uint8_t ch = b[j];
         o[j] = keep ? ch : (uint8_t)'\n';
         if (ch == '\n') {
-            if (p - start > kRawMaxLine) fl |= kRawLongLine;
             line++;
-            start = p + 1;
+            start = run = p + 1;
             if (j + 1 < 16 && p + 1 < rv.n) keep = keep_line(line, b[j + 1]);
-        } else if (p + 1 == rv.n) {                          /* last line of the buffer, no newline */
-            if (p + 1 - start > kRawMaxLine) fl |= kRawLongLine;
+        } else if (ch == 'N') {
+            run = p + 1;                                     /* :404-408 */
+        } else if (keep && ((p - run + 1) & 0xFFFFu) == 0) {
+            /* base number 65536 m of its run: cur_chars wraps here (:402, :410) */
+            const unsigned int w = atomicAdd(n_wraps, 1u);
+            if (w < kRawWrapCap) wraps[w] = p;
+            else atomicOr(flags, kRawTooManyWraps);
         }
     }
-    if (fl) atomicOr(flags, fl);
     *(uint4 *)(rv.out + at) = *(const uint4 *)o;
-    if (at + 16 >= rv.n && at < rv.n) rv.out[rv.n] = '\n';    /* terminator for an unterminated last line */
+    if (at + 16 >= rv.n) rv.out[rv.n] = '\n';                /* terminator for an unterminated last line */
+}
+
+/* ascending order for the wrap list (n <= kRawWrapCap): bitonic sort in LDS, one workgroup */
+__global__ __launch_bounds__(1024) void raw_sort_kernel(uint64_t *wraps, const unsigned int *n_wraps)
+{
+    __shared__ uint64_t s[kRawWrapCap];
+    const uint32_t n = *n_wraps < kRawWrapCap ? *n_wraps : kRawWrapCap;
+    if (n < 2) return;
+    uint32_t m = 2;
+    while (m < n) m <<= 1;
+    for (uint32_t i = threadIdx.x; i < m; i += 1024) s[i] = i < n ? wraps[i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const uint64_t a = s[i], b = s[x];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s[i] = b; s[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) wraps[i] = s[i];
 }
 
 }  // namespace qm2

@@ -107,8 +107,8 @@ def test_cli_matches_reference_vectors(setname, name, tmp_path):
 def test_cli_raw_and_host_line_discipline(raw, tmp_path):
     """The CLI's default for regular files: the host only preads, the device does the line discipline
     (SURVEY 8(f) f3); QM2_READER_RAW=0: stripped on the host.  Every k = 30 reference vector must come
-    out byte-identical both ways; the inputs the device path refuses (lines beyond 65535 bytes) must
-    silently go round again through the host path."""
+    out byte-identical both ways; an input the device path refuses must silently go round again through
+    the host path."""
     refused = []
     env = dict(os.environ, QM2_READER_RAW=raw, QM2_TIMING="1")
     for name, c in MAN["sets"]["kat"]["cases"].items():
@@ -123,11 +123,22 @@ def test_cli_raw_and_host_line_discipline(raw, tmp_path):
         assert md5_file(out + ".txt") == c["txt_md5"], name
         if "raw input refused" in txt:
             refused.append(name)
-    if raw == "1":
-        assert set(refused) >= {"long65536", "long65566", "long70000", "long99998"}, refused
-        assert not {"reads_fq", "reads_fa", "crlf", "wrap70000", "long65535"} & set(refused), refused
-    else:
-        assert not refused
+    assert not refused, refused             # long lines included: the device keeps its own wrap list
+    # the one thing the device path refuses: a '>' at a FASTQ sequence position (QuicKmer.c:398 skips that
+    # line without the three discards).  The CLI must then go round again through the host path.
+    ref = synth.kat_reference().tobytes()
+    recs = [b"@r%d\n" % i + (b">oops" if i == 700 else ref[i:i + 120]) + b"\n+\n" + b"I" * 120 + b"\n" for i in range(2000)]
+    p = tmp_path / "desync.fq"
+    p.write_bytes(b"".join(recs))
+    out = str(tmp_path / "desync")
+    r = subprocess.run([CLI, "count", "-t", "3", os.path.join(GOLD, "kat", "ref.fa"), str(p), out], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0
+    assert (b"raw input refused" in r.stdout) == (raw == "1")
+    exp_depth, exp_st = ol.count_lines(kat_qm()["keys"], 30, ol.strip_reads(str(p)))
+    assert ("total %d kmers" % exp_st["n_kmers"]).encode() in r.stdout
+    order = ol.chain_order(kat_qm())                                  # .bin = depth in chain order (QuicKmer.c:494-516)
+    assert open(out + ".bin", "rb").read() == exp_depth[order].astype("<u2").tobytes()
     # several device batches of raw FASTQ (1 MiB batches would need the API; the CLI's are >= 1 GiB): mini set
     m = MAN["sets"]["mini"]
     fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
@@ -451,7 +462,8 @@ def test_line_discipline_on_the_device(qm2, torch_cuda, tmp_path):
     """qm2_submit_raw_device: raw FASTA / FASTQ bytes, headers / '+' / qualities
     blanked by the device — against the oracle's line discipline + count on every reference edge
     case, on inputs that span many 4 KiB tiles (headers longer than a tile, lines cut at every
-    tile phase), and the two things it must refuse rather than count wrongly."""
+    tile phase, lines that wrap the uint16 run counter), and the two things it must refuse rather than
+    count wrongly."""
     torch = torch_cuda
     qm = kat_qm()
     keys = qm["keys"]
@@ -506,9 +518,18 @@ def test_line_discipline_on_the_device(qm2, torch_cuda, tmp_path):
             assert c.submit_raw_device(d.data_ptr(), d.numel(), True, skip=drop) == 0
             depth, st = c.finish()
             assert st["n_kmers"] == exp_st["n_kmers"] and np.array_equal(depth, exp_depth), drop
-    # refusals: lines beyond the uint16 run counter, and the '>' at a FASTQ sequence position
-    assert {n for n, v in refused.items() if v & 2} >= {"long65536", "long65566", "long70000", "long99998"}
-    assert "long65535" not in refused and "long20000" not in refused
+    # lines beyond the uint16 run counter are counted on the device too (wrap list from the reset scan) ...
+    assert not refused, refused
+    # ... unless there are more wraps than the list holds: 8200 lines of 65536 bases
+    with qm2.Counter(keys, k=30) as c:
+        big = torch.full((8200, 65537), ord("A"), dtype=torch.uint8, device="cuda")
+        big[:, 65536] = 10
+        torch.cuda.synchronize()
+        assert c.submit_raw_device(big.data_ptr(), big.numel(), False) == 2
+        depth, st = c.finish()
+        assert st["n_bases"] == 0 and not depth.any()
+        del big
+    # and the '>' at a FASTQ sequence position
     fq = b"@a\n" + ref[:100] + b"\n+\n" + b"I" * 100 + b"\n@b\n>oops\n+\nIIIII\n@c\n" + ref[:50] + b"\n+\n" + b"I" * 50 + b"\n"
     with qm2.Counter(keys, k=30) as c:
         d = torch.frombuffer(bytearray(fq), dtype=torch.uint8).cuda()
