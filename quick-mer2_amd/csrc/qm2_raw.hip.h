@@ -221,6 +221,9 @@ __global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, RawA
         return fc != '>';
     };
     bool keep = keep_line(line, first);
+    /* a wrap needs 65536 bases since the last reset: with a run that began less than that before
+     * this thread's last byte (nearly always) there is nothing to track */
+    const bool may_wrap = at + 16 - run >= 65536;
     uint8_t o[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -232,13 +235,14 @@ __global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, RawA
             line++;
             start = run = p + 1;
             if (j + 1 < 16 && p + 1 < rv.n) keep = keep_line(line, b[j + 1]);
-        } else if (ch == 'N') {
-            run = p + 1;                                     /* :404-408 */
-        } else if (keep && ((p - run + 1) & 0xFFFFu) == 0) {
-            /* base number 65536 m of its run: cur_chars wraps here (:402, :410) */
-            const unsigned int w = atomicAdd(n_wraps, 1u);
-            if (w < kRawWrapCap) wraps[w] = p;
-            else atomicOr(flags, kRawTooManyWraps);
+        } else if (may_wrap) {
+            if (ch == 'N') run = p + 1;                      /* :404-408 */
+            else if (keep && ((p - run + 1) & 0xFFFFu) == 0) {
+                /* base number 65536 m of its run: cur_chars wraps here (:402, :410) */
+                const unsigned int w = atomicAdd(n_wraps, 1u);
+                if (w < kRawWrapCap) wraps[w] = p;
+                else atomicOr(flags, kRawTooManyWraps);
+            }
         }
     }
     *(uint4 *)(rv.out + at) = *(const uint4 *)o;
