@@ -179,7 +179,11 @@ __device__ __forceinline__ void copy_piece(const SplitLds &L, const RunDesc &r, 
     const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)r.o, IT);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)r.dst_lo, IT);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)r.dst_hi, IT);
-    uint64_t *dst = (uint64_t *)(((uint64_t)hi << 32) | (uint64_t)lo);
+    /* a GLOBAL pointer (address space 1): rebuilt from two integers the compiler would otherwise treat
+     * it as generic and emit flat_store, which also counts on lgkmcnt — and every LDS wait and
+     * lds_barrier() in these kernels would then wait for the copy-out stores as well */
+    typedef uint64_t __attribute__((address_space(1))) global_u64;
+    global_u64 *dst = (global_u64 *)(((uint64_t)hi << 32) | (uint64_t)lo);
     for (uint32_t i = lane; i < f; i += kWave) dst[i] = L.sorted[o + i];
 }
 
