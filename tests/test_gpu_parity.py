@@ -481,6 +481,10 @@ def test_line_discipline_on_the_device(qm2, torch_cuda, tmp_path):
                                          for h, r in zip(rng.integers(0, 9000, 3000), reads(3000, 1, 900)))),
         "fa_multiline_records": ("fa", b"".join(b">c%d\n" % i + b"".join(ref[j:j + 60] + b"\n" for j in range(0, 4800, 60))
                                                 for i in range(40))),
+        # a header and a sequence line longer than a GROUP of tiles (1 MiB): the start of the line in progress
+        # comes from the scan over the groups; the 3 MB line wraps the uint16 run counter 45 times, with Ns
+        "fa_huge_header": ("fa", b">" + b"x" * (3 << 20) + b"\n" + ref[:3000] + b"\n>y\n" + ref[1000:4000] + b"\n"),
+        "fa_huge_line": ("fa", b">c\n" + ref[:4800] * 300 + b"N" + ref[:4800] * 250 + b"NN" + ref[:4800] * 150 + b"\n" + ref[:500] + b"\n"),
         "fq_no_final_newline": ("fq", b"@a\n" + ref[:150] + b"\n+\n" + b"I" * 150 + b"\n@b\n" + ref[200:290]),
         "fq_crlf": ("fq", b"".join(b"@r\r\n" + r + b"\r\n+\r\n" + b"I" * len(r) + b"\r\n" for r in reads(500, 40, 200))),
         "fq_empty_lines": ("fq", b"@a\n\n+\n\n@b\n" + ref[:100] + b"\n+\n" + b"I" * 100 + b"\n"),
