@@ -236,8 +236,8 @@ int qm2_chain_fetch(qm2_ctx *c, uint16_t *out, uint64_t offset, uint64_t count);
  * counted then; the caller strips it on the host and uses qm2_submit):
  *   QM2_RAW_DESYNC     a FASTQ sequence-position line starts with '>' (:398 skips it without
  *                      the three discards, so the phase stops following the line number)
- *   QM2_RAW_MANY_WRAPS more than 8192 runs of >= 65536 bases without 'N' in one batch (the uint16
- *                      run counter of :402 wraps there; the device keeps a list of those places)
+ *   QM2_RAW_MANY_WRAPS more than 2^20 places in one batch where the uint16 run counter of :402 wraps
+ *                      (every 65536 bases of a run without 'N'; the device keeps a list of them)
  * The call waits for the classification (not for the counting). */
 #define QM2_RAW_DESYNC    1u
 #define QM2_RAW_MANY_WRAPS 2u

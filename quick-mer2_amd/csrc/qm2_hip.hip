@@ -791,13 +791,18 @@ static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint3
     hipLaunchKernelGGL(raw_scan_kernel, dim3(1), dim3(1024), 0, s, group, n_groups);
     hipLaunchKernelGGL(raw_apply_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, tile, group, c->raw_flags,
                        c->raw_wraps, c->raw_flags + 1);
-    hipLaunchKernelGGL(raw_sort_kernel, dim3(1), dim3(1024), 0, s, c->raw_wraps, c->raw_flags + 1);
     HIP_OK(hipGetLastError());
     if (time_end(c, &t)) return 1;
     unsigned int fl[2] = {0, 0};
     HIP_OK(hipMemcpyAsync(fl, c->raw_flags, sizeof fl, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     if (fl[0]) { *verdict = fl[0]; return 0; }               /* not counted: the caller takes the host path */
+    if (fl[1] > 1) {                                         /* the kernels want the wrap list ascending; it is short */
+        std::vector<uint64_t> w(fl[1]);
+        HIP_OK(hipMemcpy(w.data(), c->raw_wraps, w.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        std::sort(w.begin(), w.end());
+        HIP_OK(hipMemcpy(c->raw_wraps, w.data(), w.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
     /* + the terminator raw_apply_kernel wrote at [n]; the wrap list plays the part of qm2_plan.h's */
     return launch_batch(c, c->raw_out, n + 1, 0, fl[1] ? c->raw_wraps : nullptr, fl[1]);
 }

@@ -20,7 +20,8 @@
  * the wrap positions as a sorted list (as qm2_submit's host planner makes it,
  * qm2_plan.h); here the same list comes from a third scan channel — the position of
  * the last RESET ('N' or '\n') — so that every kept byte knows how far into its
- * N-free run it is.  Only a batch with more wraps than the list holds is refused.
+ * N-free run it is (the few positions, appended in any order, are sorted on the host).
+ * Only a batch with more wraps than the list holds is refused.
  *
  * Passes over 4 KiB tiles (256 threads x 16 bytes), 256 tiles to a group:
  *   raw_tile_kernel   per tile: number of '\n', position of the last one, of the last reset
@@ -30,7 +31,6 @@
  *   raw_apply_kernel  finishes the prefix inside its group (256 values, one per thread), which
  *                     gives the line number at the tile's first byte and where the line and
  *                     the N-free run in progress there started; then per byte: keep, or '\n'
- *   raw_sort_kernel   the (few) wrap positions, appended in any order, into ascending order
  * All streaming: 1 B read + 1 B read + 1 B written per input byte.
  */
 #pragma once
@@ -43,7 +43,8 @@ constexpr uint32_t kRawTile = kRawThreads * 16;
 constexpr int      kRawGroup = kRawThreads;  /* tiles per group: one per thread of raw_apply_kernel */
 constexpr uint32_t kRawDesync = 1u;          /* flag bits */
 constexpr uint32_t kRawTooManyWraps = 2u;
-constexpr uint32_t kRawWrapCap = 8192;       /* wrap positions per batch (one per 65536-base run: thousands of such reads) */
+constexpr uint32_t kRawWrapCap = 1u << 20;   /* wrap positions per batch (one per 65536 bases of an N-free run: a 6 GiB batch
+                                                of nothing but such runs has < 100 k) */
 
 struct RawView {
     const uint8_t *in;      /* 16-byte aligned */
@@ -247,31 +248,6 @@ __global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, RawA
     }
     *(uint4 *)(rv.out + at) = *(const uint4 *)o;
     if (at + 16 >= rv.n) rv.out[rv.n] = '\n';                /* terminator for an unterminated last line */
-}
-
-/* ascending order for the wrap list (n <= kRawWrapCap): bitonic sort in LDS, one workgroup */
-__global__ __launch_bounds__(1024) void raw_sort_kernel(uint64_t *wraps, const unsigned int *n_wraps)
-{
-    __shared__ uint64_t s[kRawWrapCap];
-    const uint32_t n = *n_wraps < kRawWrapCap ? *n_wraps : kRawWrapCap;
-    if (n < 2) return;
-    uint32_t m = 2;
-    while (m < n) m <<= 1;
-    for (uint32_t i = threadIdx.x; i < m; i += 1024) s[i] = i < n ? wraps[i] : ~0ull;
-    __syncthreads();
-    for (uint32_t k = 2; k <= m; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-                const uint32_t x = i ^ j;
-                if (x > i) {
-                    const uint64_t a = s[i], b = s[x];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { s[i] = b; s[x] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) wraps[i] = s[i];
 }
 
 }  // namespace qm2
