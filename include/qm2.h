@@ -230,14 +230,14 @@ int qm2_chain_fetch(qm2_ctx *c, uint16_t *out, uint64_t offset, uint64_t count);
  * 16-byte aligned.  fastq = the format the first line of the file decided (:395);
  * skip (FASTQ only, 0..3) = lines to drop before the first sequence line of this block
  * (1 for a block that starts at an '@' header).  Headers, '+' lines and qualities are
- * blanked on the device and the rest is counted like qm2_submit_device (long lines included:
- * the uint16 wrap of :402 is reproduced).  Two things cannot
- * be counted this way and are reported in *verdict instead (nothing of the block is
- * counted then; the caller strips it on the host and uses qm2_submit):
- *   QM2_RAW_DESYNC     a FASTQ sequence-position line starts with '>' (:398 skips it without
- *                      the three discards, so the phase stops following the line number)
- *   QM2_RAW_MANY_WRAPS more than 2^20 places in one batch where the uint16 run counter of :402 wraps
- *                      (every 65536 bases of a run without 'N'; the device keeps a list of them)
+ * blanked on the device and the rest is counted like qm2_submit_device.  The reference's corner
+ * cases are reproduced on the device too: the uint16 run-counter wrap of long lines (:402) and the
+ * FASTQ sequence-position line that starts with '>' (:398 skips it without the three discards, so
+ * every later sequence line comes one line later).  Only absurd amounts of either are reported in
+ * *verdict instead (nothing of the block is counted then; the caller strips it on the host and
+ * uses qm2_submit):
+ *   QM2_RAW_DESYNC     more than 64 such '>' lines in one block
+ *   QM2_RAW_MANY_WRAPS more than 2^20 places in one block where the run counter wraps
  * The call waits for the classification (not for the counting). */
 #define QM2_RAW_DESYNC    1u
 #define QM2_RAW_MANY_WRAPS 2u

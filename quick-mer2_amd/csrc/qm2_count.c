@@ -86,11 +86,11 @@ int qm2_main_count(int argc, char **argv)
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);                      /* :386-387 */
     /* Regular files are not stripped on the host: the workers only pread and the device does the line
-     * discipline (measured 0.25 -> 0.19 s for 3 GB of FASTQ), uint16 run-counter wraps
-     * of long lines included.  What that path refuses (a '>' at a FASTQ sequence position; known at
-     * the end of the first device batch that holds one) makes the whole input go through the host
-     * path again, from zeroed counters: exact either way, nothing extra on stdout.  QM2_READER_RAW=0
-     * goes straight to the host path. */
+     * discipline (measured 0.25 -> 0.19 s for 3 GB of FASTQ), the reference's corner
+     * cases included (uint16 run-counter wraps of long lines, '>' at FASTQ sequence positions).  Only
+     * absurd amounts of those are refused (known at the end of the device batch that holds them):
+     * the whole input then goes through the host path again, from zeroed counters — exact either
+     * way, nothing extra on stdout.  QM2_READER_RAW=0 goes straight to the host path. */
     const char *raw_env = getenv("QM2_READER_RAW");
     const int want_raw = !(raw_env && strcmp(raw_env, "0") == 0);
     qm2_lines_out out = {out_acquire, out_commit, out_submit, ctx, want_raw ? out_commit_raw : NULL};

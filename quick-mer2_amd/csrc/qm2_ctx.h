@@ -108,8 +108,9 @@ struct qm2_ctx {
     uint64_t    raw_cap = 0;
     void       *raw_tiles = nullptr;        /* scan scratch: 40 bytes per 4 KiB tile */
     uint64_t    raw_tile_cap = 0;
-    unsigned int *raw_flags = nullptr;      /* [0] refusal bits, [1] wrap count */
+    unsigned int *raw_flags = nullptr;      /* [0] refusal bits, [1] wrap count, [2..3] first unlisted desync line */
     uint64_t   *raw_wraps = nullptr;        /* where the uint16 run counter wraps (qm2_raw.hip.h), sorted */
+    uint32_t    raw_shift = 0;              /* '>' lines at FASTQ sequence positions so far in this text, mod 4 */
     uint32_t    raw_verdict = 0;            /* sticky: a raw batch was refused (QM2_RAW_*); nothing raw is counted after it */
     /* epilogue (qm2_epilogue.hip) */
     uint32_t   *chain = nullptr;            /* device copy of next[]; aliases keys when owned */

@@ -572,7 +572,7 @@ static int batch_ready(qm2_ctx *c, Batch &b)
 }
 
 static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
-                                  uint32_t *verdict);
+                                  uint32_t *verdict, bool continues);
 
 /* Launch the kernels for the batch being filled and switch to the other one. */
 static int batch_flush(qm2_ctx *c)
@@ -587,7 +587,7 @@ static int batch_flush(qm2_ctx *c)
     HIP_OK(hipEventDestroy(copied));
     if (b.raw) {                              /* raw text: line discipline on the device, then the count */
         uint32_t verdict = 0;
-        if (raw_classify_and_count(c, b.dev, b.fill, b.raw_fastq, b.raw_skip, &verdict)) return 1;
+        if (raw_classify_and_count(c, b.dev, b.fill, b.raw_fastq, b.raw_skip, &verdict, true)) return 1;
         if (verdict) c->raw_verdict |= verdict;
         HIP_OK(hipEventRecord(b.done, c->stream));
         b.busy = true;
@@ -751,9 +751,10 @@ extern "C" int qm2_submit_device(qm2_ctx *c, const void *d_seq, size_t n, const 
     return launch_batch(c, (const uint8_t *)d_seq, n, 0, d_sup, n_sup);
 }
 
-/* classify the n raw bytes at d_raw (device, 16-byte aligned) and, unless refused, count them */
+/* classify the n raw bytes at d_raw (device, 16-byte aligned) and, unless refused, count them.
+ * continues: the block follows the previous raw block of this context in the same text (staged input) */
 static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
-                                  uint32_t *verdict)
+                                  uint32_t *verdict, bool continues)
 {
     hipStream_t s = c->stream;
     const uint64_t n_tiles = (n + kRawTile - 1) / kRawTile;
@@ -772,7 +773,7 @@ static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint3
         HIP_OK(hipMalloc(&c->raw_tiles, c->raw_tile_cap * 40));
     }
     if (!c->raw_flags) {
-        HIP_OK(hipMalloc((void **)&c->raw_flags, 2 * sizeof(unsigned int)));
+        HIP_OK(hipMalloc((void **)&c->raw_flags, 4 * sizeof(unsigned int)));
         HIP_OK(hipMalloc((void **)&c->raw_wraps, kRawWrapCap * sizeof(uint64_t)));
     }
     /* scratch: three channels (i64 last newline, i64 last reset, u32 newline count) per tile and per
@@ -781,30 +782,46 @@ static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint3
     long long *i64s = (long long *)c->raw_tiles;
     uint32_t *u32s = (uint32_t *)(i64s + 4 * cap);
     const RawArrays tile = {u32s, i64s, i64s + cap}, group = {u32s + cap, i64s + 2 * cap, i64s + 3 * cap};
-    RawView rv = {(const uint8_t *)d_raw, c->raw_out, (uint64_t)n, fastq ? 1u : 0u, fastq ? skip : 0u};
-    /* raw_flags[0] = refusal bits, [1] = number of wrap positions */
-    HIP_OK(hipMemsetAsync(c->raw_flags, 0, 2 * sizeof(unsigned int), s));
+    RawView rv;
+    rv.in = (const uint8_t *)d_raw;
+    rv.out = c->raw_out;
+    rv.n = (uint64_t)n;
+    rv.fastq = fastq ? 1u : 0u;
+    /* '>' lines at sequence positions seen in earlier batches of this text moved every later sequence
+     * line on by one (qm2_raw.hip.h): the caller's skip follows the line count only */
+    rv.skip = fastq ? (skip + (continues ? c->raw_shift : 0u)) & 3u : 0u;
+    rv.n_desync = 0;
     TimedLaunch t;
     if (time_begin(c, &t, QM2_K_LINES)) return 1;
     hipLaunchKernelGGL(raw_tile_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, tile);
     hipLaunchKernelGGL(raw_group_kernel, dim3((uint32_t)n_groups), dim3(kRawThreads), 0, s, tile, n_tiles, group);
     hipLaunchKernelGGL(raw_scan_kernel, dim3(1), dim3(1024), 0, s, group, n_groups);
-    hipLaunchKernelGGL(raw_apply_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, tile, group, c->raw_flags,
-                       c->raw_wraps, c->raw_flags + 1);
-    HIP_OK(hipGetLastError());
+    /* raw_flags: [0] refusal bits, [1] number of wrap positions, [2..3] u64 first unlisted desync line */
+    struct { unsigned int bits, n_wraps; unsigned long long next_desync; } fl;
+    for (;;) {
+        fl.bits = 0; fl.n_wraps = 0; fl.next_desync = ~0ull;
+        HIP_OK(hipMemcpyAsync(c->raw_flags, &fl, sizeof fl, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(raw_apply_kernel, dim3((uint32_t)n_tiles), dim3(kRawThreads), 0, s, rv, tile, group, c->raw_flags,
+                           c->raw_wraps, c->raw_flags + 1, (unsigned long long *)(c->raw_flags + 2));
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync(&fl, c->raw_flags, sizeof fl, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (fl.bits || fl.next_desync == ~0ull) break;
+        if (rv.n_desync == kRawMaxDesync) { fl.bits |= kRawDesync; break; }
+        rv.desync[rv.n_desync++] = fl.next_desync;           /* found in ascending order: the list stays sorted */
+    }
     if (time_end(c, &t)) return 1;
-    unsigned int fl[2] = {0, 0};
-    HIP_OK(hipMemcpyAsync(fl, c->raw_flags, sizeof fl, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
-    if (fl[0]) { *verdict = fl[0]; return 0; }               /* not counted: the caller takes the host path */
-    if (fl[1] > 1) {                                         /* the kernels want the wrap list ascending; it is short */
-        std::vector<uint64_t> w(fl[1]);
+    if (fl.bits) { *verdict = fl.bits; return 0; }           /* not counted: the caller takes the host path */
+    if (continues) c->raw_shift = (c->raw_shift + rv.n_desync) & 3u;
+    const unsigned int n_wraps = fl.n_wraps;
+    if (n_wraps > 1) {                                       /* the kernels want the wrap list ascending; it is short */
+        std::vector<uint64_t> w(n_wraps);
         HIP_OK(hipMemcpy(w.data(), c->raw_wraps, w.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
         std::sort(w.begin(), w.end());
         HIP_OK(hipMemcpy(c->raw_wraps, w.data(), w.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
     /* + the terminator raw_apply_kernel wrote at [n]; the wrap list plays the part of qm2_plan.h's */
-    return launch_batch(c, c->raw_out, n + 1, 0, fl[1] ? c->raw_wraps : nullptr, fl[1]);
+    return launch_batch(c, c->raw_out, n + 1, 0, n_wraps ? c->raw_wraps : nullptr, n_wraps);
 }
 
 extern "C" int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
@@ -818,7 +835,7 @@ extern "C" int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, ui
     if ((uintptr_t)d_raw & 15u) return fail("qm2_submit_raw_device: the buffer must be 16-byte aligned");
     if (fastq && skip > 3) return fail("qm2_submit_raw_device: skip is 0..3");
     if (use_device(c)) return 1;
-    return raw_classify_and_count(c, d_raw, n, fastq, skip, verdict);
+    return raw_classify_and_count(c, d_raw, n, fastq, skip, verdict, false);
 }
 
 extern "C" int qm2_staging_commit_raw(qm2_ctx *c, char *buf, size_t offset, size_t n, uint32_t fastq, uint32_t skip)
@@ -914,6 +931,7 @@ extern "C" int qm2_reset(qm2_ctx *c)
     c->bytes_launched = 0;
     c->peek_pending = false;
     c->raw_verdict = 0;
+    c->raw_shift = 0;
     HIP_OK(hipStreamSynchronize(c->stream));
     memset(&c->prof, 0, sizeof c->prof);
     return 0;

@@ -11,9 +11,13 @@
  *   FASTQ  line L is a sequence line  iff  L >= skip and (L - skip) % 4 == 0
  *   FASTA  line L is a sequence line  iff  its first byte is not '>'.
  * A FASTQ sequence-position line that starts with '>' is skipped WITHOUT the three
- * drops (:398 comes before :451): from there on the phase is no longer a function
- * of the line number.  That is reported in a flag word instead of being counted
- * wrongly; the caller takes the host path for such a block.
+ * drops (:398 comes before :451): the line after it is at a sequence position again,
+ * i.e. every later sequence line comes one line later than the line number says.
+ * Such lines are rare (malformed input), so they are found one at a time: a pass
+ * that knows the first d of them (a sorted list of line numbers; line L then counts as
+ * L minus the number of listed lines before it) reports the first sequence-position
+ * '>' line that is not on the list; the host adds it and runs the pass again, until
+ * none is found.  A batch with more than kRawMaxDesync of them is refused.
  *
  * The uint16 run counter of :402 wraps after 65535 bases without an 'N' or a line
  * end, and the k-1 windows behind the wrap are lost (:418).  The count kernels take
@@ -41,7 +45,8 @@ namespace qm2 {
 constexpr int      kRawThreads = 256;
 constexpr uint32_t kRawTile = kRawThreads * 16;
 constexpr int      kRawGroup = kRawThreads;  /* tiles per group: one per thread of raw_apply_kernel */
-constexpr uint32_t kRawDesync = 1u;          /* flag bits */
+constexpr uint32_t kRawDesync = 1u;          /* flag bits: too many '>' lines at FASTQ sequence positions */
+constexpr uint32_t kRawMaxDesync = 64;
 constexpr uint32_t kRawTooManyWraps = 2u;
 constexpr uint32_t kRawWrapCap = 1u << 20;   /* wrap positions per batch (one per 65536 bases of an N-free run: a 6 GiB batch
                                                 of nothing but such runs has < 100 k) */
@@ -51,6 +56,8 @@ struct RawView {
     uint8_t       *out;     /* 16-byte aligned, n + 1 bytes */
     uint64_t       n;
     uint32_t       fastq, skip;
+    uint32_t       n_desync;                 /* known '>' lines at sequence positions, ascending line numbers */
+    uint64_t       desync[kRawMaxDesync];
 };
 
 /* what the scans carry: newlines so far, position of the last newline, of the last reset ('N' or newline) */
@@ -175,7 +182,8 @@ __global__ __launch_bounds__(1024) void raw_scan_kernel(RawArrays group, uint64_
 }
 
 __global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, RawArrays tile, RawArrays group_before,
-                                                                unsigned int *flags, uint64_t *wraps, unsigned int *n_wraps)
+                                                                unsigned int *flags, uint64_t *wraps, unsigned int *n_wraps,
+                                                                unsigned long long *next_desync)
 {
     __shared__ RawAgg s[kRawThreads / kWave];
     /* the tiles of this group in front of this one: thread t looks at tile t of the group */
@@ -215,8 +223,16 @@ __global__ __launch_bounds__(kRawThreads) void raw_apply_kernel(RawView rv, RawA
     const uint8_t first = start == at ? b[0] : rv.in[start];
     auto keep_line = [&](uint64_t l, uint8_t fc) {
         if (rv.fastq) {
-            const bool seq = l >= rv.skip && ((l - rv.skip) & 3u) == 0;
-            if (seq && fc == '>') atomicOr(flags, kRawDesync);
+            uint64_t shift = 0;                               /* known desync lines in front of l; l itself on the list: dropped */
+            for (uint32_t d = 0; d < rv.n_desync; d++) {
+                if (rv.desync[d] == l) return false;
+                shift += rv.desync[d] < l ? 1u : 0u;
+            }
+            const bool seq = l >= rv.skip + shift && ((l - rv.skip - shift) & 3u) == 0;
+            if (seq && fc == '>') {                           /* a new one: the host takes the first and runs again */
+                atomicMin(next_desync, (unsigned long long)l);
+                return false;
+            }
             return seq;
         }
         return fc != '>';

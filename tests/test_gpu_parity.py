@@ -124,21 +124,25 @@ def test_cli_raw_and_host_line_discipline(raw, tmp_path):
         if "raw input refused" in txt:
             refused.append(name)
     assert not refused, refused             # long lines included: the device keeps its own wrap list
-    # the one thing the device path refuses: a '>' at a FASTQ sequence position (QuicKmer.c:398 skips that
-    # line without the three discards).  The CLI must then go round again through the host path.
+    # a '>' at a FASTQ sequence position (QuicKmer.c:398 skips that line without the three discards) is followed
+    # on the device; 70 of them in one batch are refused, and the CLI must go round again through the host path
     ref = synth.kat_reference().tobytes()
-    recs = [b"@r%d\n" % i + (b">oops" if i == 700 else ref[i:i + 120]) + b"\n+\n" + b"I" * 120 + b"\n" for i in range(2000)]
-    p = tmp_path / "desync.fq"
-    p.write_bytes(b"".join(recs))
-    out = str(tmp_path / "desync")
-    r = subprocess.run([CLI, "count", "-t", "3", os.path.join(GOLD, "kat", "ref.fa"), str(p), out], env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-    assert r.returncode == 0
-    assert (b"raw input refused" in r.stdout) == (raw == "1")
-    exp_depth, exp_st = ol.count_lines(kat_qm()["keys"], 30, ol.strip_reads(str(p)))
-    assert ("total %d kmers" % exp_st["n_kmers"]).encode() in r.stdout
-    order = ol.chain_order(kat_qm())                                  # .bin = depth in chain order (QuicKmer.c:494-516)
-    assert open(out + ".bin", "rb").read() == exp_depth[order].astype("<u2").tobytes()
+    for tag, n_gt, expect_refusal in (("few", 3, False), ("many", 70, raw == "1")):
+        # n_gt consecutive '>' lines where record 700's sequence should be: each is at a sequence position (the line
+        # after a skipped one is), then the records go on normally
+        recs = [b"@r%d\n" % i + (b">oops\n" * n_gt if i == 700 else b"") + ref[i:i + 120] + b"\n+\n" + b"I" * 120 + b"\n"
+                for i in range(2000)]
+        p = tmp_path / ("desync_%s.fq" % tag)
+        p.write_bytes(b"".join(recs))
+        out = str(tmp_path / ("desync_" + tag))
+        r = subprocess.run([CLI, "count", "-t", "3", os.path.join(GOLD, "kat", "ref.fa"), str(p), out], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0
+        assert (b"raw input refused" in r.stdout) == expect_refusal, tag
+        exp_depth, exp_st = ol.count_lines(kat_qm()["keys"], 30, ol.strip_reads(str(p)))
+        assert ("total %d kmers" % exp_st["n_kmers"]).encode() in r.stdout
+        order = ol.chain_order(kat_qm())                              # .bin = depth in chain order (QuicKmer.c:494-516)
+        assert open(out + ".bin", "rb").read() == exp_depth[order].astype("<u2").tobytes(), tag
     # several device batches of raw FASTQ (1 MiB batches would need the API; the CLI's are >= 1 GiB): mini set
     m = MAN["sets"]["mini"]
     fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
@@ -462,8 +466,8 @@ def test_line_discipline_on_the_device(qm2, torch_cuda, tmp_path):
     """qm2_submit_raw_device: raw FASTA / FASTQ bytes, headers / '+' / qualities
     blanked by the device — against the oracle's line discipline + count on every reference edge
     case, on inputs that span many 4 KiB tiles (headers longer than a tile, lines cut at every
-    tile phase, lines that wrap the uint16 run counter), and the two things it must refuse rather than
-    count wrongly."""
+    tile phase, lines that wrap the uint16 run counter, '>' lines at FASTQ sequence positions), and the
+    amounts of the last two it refuses rather than count wrongly."""
     torch = torch_cuda
     qm = kat_qm()
     keys = qm["keys"]
@@ -536,17 +540,41 @@ def test_line_discipline_on_the_device(qm2, torch_cuda, tmp_path):
         assert st == {a: 8200 * v for a, v in one.items()}
         assert int(depth.astype(np.uint64).sum()) == (8200 * one["n_hits"]) % 65536
         del big
-    # and the '>' at a FASTQ sequence position
-    fq = b"@a\n" + ref[:100] + b"\n+\n" + b"I" * 100 + b"\n@b\n>oops\n+\nIIIII\n@c\n" + ref[:50] + b"\n+\n" + b"I" * 50 + b"\n"
+    # '>' at FASTQ sequence positions (QuicKmer.c:398 skips such a line without the three discards): found one
+    # at a time on the device, each shifting every later record by a line; more than 64 in a block are refused
+    def fq_with_gt(n_rec, bad):
+        # bad: record -> how many '>' lines stand in front of its sequence (each at a sequence position); a '>' INSTEAD
+        # of the sequence (count -1) shifts the rest of the file against the record structure, as in the reference
+        out = []
+        for i in range(n_rec):
+            g = bad.get(i, 0)
+            seq = b">oops%d" % i if g < 0 else ref[i % 3000:i % 3000 + 100]
+            out.append(b"@r%d\n" % i + b">x\n" * max(g, 0) + seq + b"\n+\n" + b"I" * 100 + b"\n")
+        return b"".join(out)
     with qm2.Counter(keys, k=30) as c:
-        d = torch.frombuffer(bytearray(fq), dtype=torch.uint8).cuda()
+        for bad in ({7: 1}, {0: 1}, {3: 2, 4: 1, 2000: 5}, {10: -1}, {10: -1, 11: -1, 400: 3}, {100: 64}, {100: 40, 2500: 24}):
+            data = fq_with_gt(3000, bad)
+            p = tmp_path / "gt.fq"
+            p.write_bytes(data)
+            exp_depth, exp_st = ol.count_lines(keys, 30, ol.strip_reads(str(p)))
+            d = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+            torch.cuda.synchronize()
+            c.reset()
+            assert c.submit_raw_device(d.data_ptr(), d.numel(), True, skip=1) == 0, sorted(bad)[:4]
+            depth, st = c.finish()
+            assert st == exp_st and np.array_equal(depth, exp_depth), sorted(bad)[:4]
+        data = fq_with_gt(3000, {100: 65})                               # 65 of them
+        d = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
         torch.cuda.synchronize()
+        c.reset()
         assert c.submit_raw_device(d.data_ptr(), d.numel(), True, skip=1) == 1
+        depth, st = c.finish()
+        assert st["n_bases"] == 0 and not depth.any()
         with pytest.raises(qm2.Qm2Error, match="aligned"):
             c.submit_raw_device(d.data_ptr() + 1, d.numel() - 1, True, skip=1)
 
 
-def test_raw_blocks_through_staging_cross_device_batches(qm2):
+def test_raw_blocks_through_staging_cross_device_batches(qm2, tmp_path):
     """qm2_staging_commit_raw the way the CLI's reader drives it — line-aligned raw blocks with the
     line state at their first byte — but with device batches of 256 KiB, so that one FASTQ file
     becomes dozens of raw batches whose state comes from whichever block happens to open them."""
@@ -556,10 +584,13 @@ def test_raw_blocks_through_staging_cross_device_batches(qm2):
     ref = synth.kat_reference().tobytes()
     rng = np.random.default_rng(12)
     recs = [ref[int(p):int(p) + int(l)] for p, l in zip(rng.integers(0, 4000, 30000), rng.integers(30, 300, 30000))]
-    fq = b"".join(b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(recs))
+    gt = {5000, 5001, 17000}                 # '>' at sequence positions: the shift they cause is carried from batch to batch
+    fq = b"".join(b"@r%d\n" % i + (b">x" if i in gt else r) + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(recs))
     fa = b"".join(b">r%d\n" % i + r + b"\n" for i, r in enumerate(recs))
-    want = b"".join(r + b"\n" for r in recs)
-    exp_depth, exp_st = ol.count_lines(keys, 30, want)
+    want = {True: None, False: b"".join(r + b"\n" for r in recs)}
+    (tmp_path / "gt.fq").write_bytes(fq)
+    want[True] = ol.strip_reads(str(tmp_path / "gt.fq"))
+    exp = {f: ol.count_lines(keys, 30, w) for f, w in want.items()}
     L = qm2.lib()
     for data, fastq in ((fq, True), (fa, False)):
         with qm2.Counter(keys, k=30, staging_bytes=48 << 10, batch_bytes=256 << 10, n_staging=4) as c:
@@ -583,6 +614,7 @@ def test_raw_blocks_through_staging_cross_device_batches(qm2):
             assert L.qm2_raw_verdict(c._h) == 0
             prof = c.profile()
             assert prof["direct_batches"] + prof["partitioned_batches"] >= 8      # really many batches
+        exp_depth, exp_st = exp[fastq]
         assert st == exp_st, fastq
         assert np.array_equal(depth, exp_depth), fastq
 
