@@ -148,7 +148,9 @@ static void part_init(qm2_ctx *c, int max_bits)
     if (p.levels > kMaxLevels) { p.levels = 0; return; }             /* cannot happen for H <= 2^32 */
     int left = nb, cum = 0;
     for (int l = 0; l < p.levels; l++) {
-        const int b = (left + (p.levels - l) - 1) / (p.levels - l);
+        /* the smaller shares go first (hg38: 6 + 7 + 7): the text level is VALU-bound and a smaller fan-out
+         * means fewer, longer runs to copy out there (measured 15.4 -> 14.1 ms, against + 0.6 ms in the k-mer levels) */
+        const int b = left / (p.levels - l);
         p.bits[l] = (uint32_t)b;
         cum += b;
         left -= b;

@@ -934,7 +934,7 @@ def test_c3_scale_partitioned_equals_direct(qm2, torch_cuda):
                      flags=qm2.FLAG_PARTITION | qm2.FLAG_TIMING) as cp:
         cp.submit_device(reads.data_ptr(), reads.numel())
         _, sp = cp.finish(want_depth=False)
-        assert cp.profile()["class_launches"]["split_kmer"] == 2      # 7 + 7 + 6 bits
+        assert cp.profile()["class_launches"]["split_kmer"] == 2      # 6 + 7 + 7 bits
         assert sp == sd and sd["n_bases"] == n_reads * rl and sd["n_hits"] > 0.7 * sd["n_kmers"]
         assert torch.equal(a, b)
         assert int(b.sum(dtype=torch.int64)) == sp["n_hits"]
