@@ -903,14 +903,17 @@ def test_c2_scale_properties(qm2, torch_cuda):
     assert np.array_equal(depth, exp_depth)
 
 
-def test_c3_scale_partitioned_equals_direct(qm2, torch_cuda):
-    """hg38-scale table (H = 2^32, 3.1 Gb synthetic reference, ~2.27 G dictionary k-mers, 53 % fill;
-    3 partition levels): the partitioned pipeline and the direct kernel must produce the same
-    4 G counters and the same statistics; the same stream twice doubles every counter."""
+# ---- 7. hg38-scale table (configs C3, C4, C5): H = 2^32, built once per module ---------------
+
+@pytest.fixture(scope="module")
+def hg38_scale(qm2, torch_cuda):
+    """H = 2^32 dictionary of a 3.1 Gb synthetic reference (~2.27 G unique 30-mers, 53 % fill): device
+    genome + keys, the direct kernel's counters for 5 M x 150 bp reads (the truth the other tests
+    compare against), and the host copy of the keys for the oracle."""
     torch = torch_cuda
     free, total = torch.cuda.mem_get_info()
     if free < 150 * (1 << 30):
-        pytest.skip("needs ~120 GiB of free HBM")
+        pytest.skip("needs ~150 GiB of free HBM")
     n, H, k = 3_100_000_000, 1 << 32, 30
     genome = torch.empty(n, dtype=torch.uint8, device="cuda")
     qm2.tools.genome_generate(genome.data_ptr(), n, seed=38, n_blocks=[(0, 10_000_000), (1_500_000_000, 30_000_000)])
@@ -924,21 +927,144 @@ def test_c3_scale_partitioned_equals_direct(qm2, torch_cuda):
     reads = torch.empty(n_reads * (rl + 1), dtype=torch.uint8, device="cuda")
     qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, n_reads, 0, rl, rl, 38)
     a = torch.zeros(H, dtype=torch.int32, device="cuda")
-    b = torch.zeros(H, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=a.data_ptr(),
                      flags=qm2.FLAG_DIRECT) as cd:
         cd.submit_device(reads.data_ptr(), reads.numel())
         _, sd = cd.finish(want_depth=False)
+    hk = keys.cpu().numpy().view(np.uint64)          # 32 GiB on the host: the oracle's table
+    env = dict(n=n, H=H, k=k, genome=genome, keys=keys, hk=hk, reads=reads, n_reads=n_reads, rl=rl,
+               direct=a, direct_stats=sd, n_unique=n_unique)
+    yield env
+    env.clear()
+
+
+def _oracle_sample_equal(qm2, env, sample: bytes, flags):
+    """Exact equality with the oracle on `sample` (whole lines), all 2^32 counters and the statistics."""
+    hk, k, H = env["hk"], env["k"], env["H"]
+    exp_depth, exp_st = ol.count_lines(hk, k, sample, threads=8)
+    exp_depth = ol.remove_drain_padding(exp_depth, hk, exp_st["n_kmers"])
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=env["keys"].data_ptr(), flags=flags) as c:
+        c.submit(sample)
+        depth, st = c.finish()
+    assert st["n_kmers"] == exp_st["n_kmers"] and st["n_bases"] == exp_st["n_bases"]
+    assert np.array_equal(depth, exp_depth)
+    return st
+
+
+def test_c3_scale_partitioned_equals_direct(qm2, torch_cuda, hg38_scale):
+    """C3: the partitioned pipeline and the direct kernel must produce the same 4 G counters and the
+    same statistics; the same stream twice doubles every counter; and both equal the ORACLE on a
+    100 k-read sample of the stream (the only CPU-checkable size at H = 2^32)."""
+    torch, env = torch_cuda, hg38_scale
+    H, k, keys, reads, a, sd = env["H"], env["k"], env["keys"], env["reads"], env["direct"], env["direct_stats"]
+    b = torch.zeros(H, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=b.data_ptr(),
                      flags=qm2.FLAG_PARTITION | qm2.FLAG_TIMING) as cp:
         cp.submit_device(reads.data_ptr(), reads.numel())
         _, sp = cp.finish(want_depth=False)
-        assert cp.profile()["class_launches"]["split_kmer"] == 2      # 6 + 7 + 7 bits
-        assert sp == sd and sd["n_bases"] == n_reads * rl and sd["n_hits"] > 0.7 * sd["n_kmers"]
+        assert cp.profile()["partitioned_batches"] == 1 and cp.profile()["fallback_batches"] == 0
+        assert sp == sd and sd["n_bases"] == env["n_reads"] * env["rl"] and sd["n_hits"] > 0.7 * sd["n_kmers"]
         assert torch.equal(a, b)
         assert int(b.sum(dtype=torch.int64)) == sp["n_hits"]
         cp.submit_device(reads.data_ptr(), reads.numel())
         _, s2 = cp.finish(want_depth=False)
         assert s2 == {x: 2 * y for x, y in sp.items()}
         assert torch.equal(b, 2 * a)
+    del b
+    torch.cuda.empty_cache()
+    sample = reads[:100_000 * (env["rl"] + 1)].cpu().numpy().tobytes()
+    for flags in (qm2.FLAG_PARTITION, qm2.FLAG_DIRECT):
+        _oracle_sample_equal(qm2, env, sample, flags)
+
+
+def test_c5_hifi_reads_at_hg38_scale(qm2, torch_cuda, hg38_scale):
+    """C5 at its stated shape: 50 k HiFi-like reads U(15 000, 20 000) bp (0.87 G bases, one line per
+    read, QuicKmer.c:388) against the H = 2^32 dictionary: both pipelines equal, conservation,
+    linearity, and exact oracle equality on the first 200 reads."""
+    torch, env = torch_cuda, hg38_scale
+    H, k, keys, genome, n = env["H"], env["k"], env["keys"], env["genome"], env["n"]
+    n_reads, lo, hi = 50_000, 15_000, 20_000
+    off = qm2.tools.read_offsets(n_reads, 500, lo, hi, 55)
+    d_off = torch.from_numpy(off.view(np.int64)).cuda()
+    nbytes = int(off[-1])
+    reads = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), d_off.data_ptr(), n_reads, 500, lo, hi, 55,
+                             sub_rate=0.001)
+    a = torch.zeros(H, dtype=torch.int32, device="cuda")
+    b = torch.zeros(H, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=a.data_ptr(),
+                     flags=qm2.FLAG_DIRECT) as cd:
+        cd.submit_device(reads.data_ptr(), nbytes)
+        _, sd = cd.finish(want_depth=False)
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=b.data_ptr(),
+                     flags=qm2.FLAG_PARTITION | qm2.FLAG_TIMING) as cp:
+        cp.submit_device(reads.data_ptr(), nbytes)
+        _, sp = cp.finish(want_depth=False)
+        assert cp.profile()["partitioned_batches"] == 1 and cp.profile()["fallback_batches"] == 0
+        assert sp == sd and sd["n_bases"] == nbytes - n_reads
+        # kappa ~ 0.998 for 17.5 kb reads, minus the windows with a substitution-made N: the long-read path
+        assert sd["n_kmers"] > 0.97 * sd["n_bases"] and sd["n_hits"] > 0.7 * sd["n_kmers"]
+        assert torch.equal(a, b)
+        assert int(b.sum(dtype=torch.int64)) == sp["n_hits"]
+        cp.submit_device(reads.data_ptr(), nbytes)
+        _, s2 = cp.finish(want_depth=False)
+        assert s2 == {x: 2 * y for x, y in sp.items()}
+        assert torch.equal(b, 2 * a)
+    del a, b
+    torch.cuda.empty_cache()
+    sample = reads[:int(off[200])].cpu().numpy().tobytes()
+    assert sample.count(b"\n") == 200 and min(len(x) for x in sample.split(b"\n")[:-1]) >= lo
+    for flags in (qm2.FLAG_PARTITION, qm2.FLAG_DIRECT):
+        st = _oracle_sample_equal(qm2, env, sample, flags)
+        assert st["n_kmers"] > 0.97 * st["n_bases"]
+
+
+def test_c4_eight_logical_shards_at_hg38_scale(qm2, torch_cuda, hg38_scale):
+    """C4's shape without 8 GPUs: the H = 2^32 table cut into 8 hash-range
+    shards; qm2_encode_device buckets the k-mers of the C3 stream by owner, every shard probes its
+    bucket against its own span (qm2_shard_span: owned range + the run of occupied slots past the
+    middle-facing edge, QuicKmer.c:90-99) in its own context, overhang counts are folded into the
+    neighbour that owns those slots — and all 4 G counters equal the single-context result."""
+    torch, env = torch_cuda, hg38_scale
+    H, k, keys, reads, truth, sd = env["H"], env["k"], env["keys"], env["reads"], env["direct"], env["direct_stats"]
+    G, per = 8, H // 8
+    # qm2_shard_span only looks at the slots around the shard edges: give it a sparse host image
+    W = 1 << 16
+    sparse = np.zeros(H, dtype=np.uint64)            # untouched pages stay unmapped
+    for g in range(1, G):
+        e = g * per
+        sparse[e - W:e + W] = keys[e - W:e + W].cpu().numpy().view(np.uint64)
+    spans = [qm2.shard_span(sparse, G, g) for g in range(G)]
+    for own_lo, own_hi, lo, hi in spans:
+        assert own_lo - lo < W - 1 and hi - own_hi < W - 1      # every walk ended inside the copied window
+    del sparse
+    n_km = sd["n_kmers"]
+    cap = int(n_km / G * 1.05) + 65536
+    out = torch.empty(G * cap, dtype=torch.int64, device="cuda")
+    fills = torch.zeros(G, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr()) as enc:
+        enc.encode_device(reads.data_ptr(), reads.numel(), out.data_ptr(), cap, G, fills.data_ptr())
+        _, se = enc.finish(want_depth=False)
+    assert se["n_kmers"] == n_km and se["n_bases"] == sd["n_bases"]
+    fl = [int(x) for x in fills.cpu()]
+    assert sum(fl) == n_km and max(fl) < cap
+    full = torch.zeros(H, dtype=torch.int32, device="cuda")
+    hits = probes = 0
+    for g, (own_lo, own_hi, lo, hi) in enumerate(spans):
+        cnt = torch.zeros(hi - lo, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr() + 8 * lo, ext_counters=cnt.data_ptr(),
+                         span=(lo, hi)) as pc:
+            pc.probe_device(out.data_ptr() + 8 * g * cap, fl[g], fills.data_ptr() + 8 * g)
+            _, s = pc.finish(want_depth=False)
+        hits += s["n_hits"]
+        probes += s["n_probes"]
+        # owned slots and overhang alike: slot lo + i of the table (the fold of ShardedJob.finish)
+        full[lo:hi] += cnt
+        del cnt
+    assert hits == sd["n_hits"] and probes == sd["n_probes"]
+    assert torch.equal(full, truth)
