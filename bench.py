@@ -185,6 +185,21 @@ def main():
         barrier()
         reduce_ms = 1e3 * (time.perf_counter() - tr0)
 
+    try:                                     # diagnostic builds only (-DQM2_STAMPS): phase stamps of bucket_count
+        import ctypes as _C
+        fn = pyqm2.lib().qm2_debug_stamps
+        acc = (_C.c_uint64 * 16)()
+        fn(acc)
+        nw = max(1, acc[8])
+        names = ["other", "wait_slice", "stage", "bar_stage", "phase_a", "phase_b", "bar_flush", "flush", None,
+                 "issue_slice", "rotate_nq", "wait_kmers"]
+        idx = [i for i in range(12) if names[i]]
+        tot = sum(acc[i] for i in idx)
+        sys.stderr.write("STAMPS waves=%d total_cycles_per_wave=%.0f " % (nw, tot / nw) +
+                         " ".join("%s=%.1f%%" % (names[i], 100.0 * acc[i] / max(1, tot)) for i in idx) + "\n")
+    except AttributeError:
+        pass
+
     elapsed = t1 - t0
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)

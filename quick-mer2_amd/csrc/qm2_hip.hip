@@ -143,7 +143,8 @@ static int harvest_timing(qm2_ctx *c)
 static void part_init(qm2_ctx *c, int max_bits)
 {
     PartPlan &p = c->part;
-    const int nb = (int)c->lgH > kLgS ? (int)c->lgH - kLgS : 0;     /* bits of the finest bucket id */
+    const int nb = (int)c->lgH - kLgS;                               /* bits of the finest bucket id */
+    if (nb < 1) { p.levels = 0; return; }     /* fewer than two buckets: such a table is counted by the direct kernel */
     p.levels = nb <= max_bits ? 1 : (nb + max_bits - 1) / max_bits;
     if (p.levels > kMaxLevels) { p.levels = 0; return; }             /* cannot happen for H <= 2^32 */
     int left = nb, cum = 0;
@@ -304,27 +305,28 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
         }
         const uint64_t per_bucket = (uint64_t)((double)sv.n_total * c->kmers_per_byte) / n_buckets;
         const bool pipe = QM2_COUNT_PIPE == 2 ? per_bucket < (2u << kLgS) : QM2_COUNT_PIPE != 0;
-        int g = 6;
+        int g = 4;
         if (pipe) {
             const double fill = (double)per_bucket + 3.0 * std::sqrt((double)per_bucket + 1.0);
-            const int rows = std::max(1, (int)std::ceil(fill / kCountThreads));
+            const int rows = std::max(1, (int)std::ceil(fill / (2.0 * kCountThreads)));   /* rows of 2 k-mers per thread */
             int best_rows = 1 << 30;
-            for (int cand = 4; cand <= 8; cand++) {
+            for (int cand = 2; cand <= 6; cand++) {
                 const int run = (rows + cand - 1) / cand * cand;               /* rows executed */
                 if (run <= best_rows) { best_rows = run; g = cand; }           /* ties: the larger group */
             }
         }
+        const CountGeo cg = {0, 0, c->H, c->H >> 1};
 #define QM2_LAUNCH_COUNT(PIPE_, G_)                                                                             \
         hipLaunchKernelGGL((bucket_count_kernel<kLgS, PIPE_, G_>), dim3(grid), dim3(kCountThreads), 0, s,      \
-                           p.buf[L & 1], p.cursors + p.cursor_off[L], p.cap[L], table_view(c), c->H, n_buckets, \
+                           p.buf[L & 1], p.cursors + p.cursor_off[L], p.cap[L], table_view(c), cg, n_buckets,   \
                            p.shared, c->stats)
-        if (!pipe) QM2_LAUNCH_COUNT(false, 6);
+        if (!pipe) QM2_LAUNCH_COUNT(false, 4);
         else switch (g) {
+            case 2: QM2_LAUNCH_COUNT(true, 2); break;
+            case 3: QM2_LAUNCH_COUNT(true, 3); break;
             case 4: QM2_LAUNCH_COUNT(true, 4); break;
             case 5: QM2_LAUNCH_COUNT(true, 5); break;
-            case 6: QM2_LAUNCH_COUNT(true, 6); break;
-            case 7: QM2_LAUNCH_COUNT(true, 7); break;
-            default: QM2_LAUNCH_COUNT(true, 8); break;
+            default: QM2_LAUNCH_COUNT(true, 6); break;
         }
 #undef QM2_LAUNCH_COUNT
         HIP_OK(hipGetLastError());
@@ -949,6 +951,18 @@ extern "C" int qm2_get_profile(qm2_ctx *c, qm2_profile *p)
     *p = c->prof;
     return 0;
 }
+
+#ifdef QM2_STAMPS
+/* diagnostic build only: read and clear the phase stamps of bucket_count_kernel */
+extern "C" int qm2_debug_stamps(unsigned long long *out16)
+{
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(qm2::qm2_stamp_acc), 16 * sizeof(unsigned long long)));
+    unsigned long long z[16] = {0};
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(qm2::qm2_stamp_acc), z, sizeof z));
+    return 0;
+}
+#endif
 
 /* ---- split path ------------------------------------------------------------ */
 

@@ -62,6 +62,24 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+/* Diagnostic build only (-DQM2_STAMPS, tools/stamps.sh): s_memtime brackets around the phases of
+ * bucket_count_kernel, summed per wave into qm2_stamp_acc (cdna_hip_programming.md section 7, In-kernel
+ * stamps).  Compiled out of the product. */
+#ifdef QM2_STAMPS
+__device__ unsigned long long qm2_stamp_acc[16];
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define QM2_STAMP(I) do { const unsigned long long now_ = stamp_now(); st_acc[I] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define QM2_STAMP(I) do { } while (0)
+#endif
+
 struct SplitDst {
     uint64_t           *kmers;      /* child c occupies [c*cap, (c+1)*cap)                      */
     uint32_t           *cursors;    /* per child: k-mers reserved so far (may exceed cap)        */
@@ -294,85 +312,113 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
 
 /* Finest level: one workgroup per bucket of S = 2^LG_S table slots.
  *
- * Probing in LDS is cheap per step but DIVERGENT: at 53 % fill (hg38) a k-mer needs 1.75
- * slots on average while the slowest of a wave's 64 lanes needs ~12, and a plain per-lane loop
- * makes every lane pay for the slowest.  So each group of k-mers is probed in two phases:
- *   A  straight-line: the home slot and the one after it are inspected for every k-mer
- *      (resolves ~75 % at 53 % fill, ~99 % at 14 %);
- *   B  the unresolved ones are COMPACTED into a small per-wave LDS queue and probed on in
- *      dense rows, so the long tails of few k-mers no longer idle the other lanes.
+ * The slice of a bucket (its S slots + kHalo slots on the side probe walks leave through, i.e.
+ * towards the middle of the table, :94-95) is staged in LDS MIRRORED for the upper half of the
+ * table, so that in LDS every walk is p, p+1, p+2, ... whatever its direction in the table.  Next to
+ * the keys and the counter tile sits one FINGERPRINT byte per slot: 0 = empty, 1..253 = a function
+ * of the key, 0xFF = beyond the staged slice.
+ *
+ * Probing in LDS is cheap per step but DIVERGENT as a per-lane loop (at 53 % fill a k-mer needs
+ * 1.75 slots on average, the slowest of a wave's 64 lanes ~12).  So:
+ *   A  straight-line, every k-mer: the fingerprints of the 4 slots from its home slot on (two
+ *      aligned dwords + v_alignbyte) are compared SWAR-wise with the k-mer's own fingerprint; the
+ *      first match at or before the first empty slot is verified against the full key (exact: equal
+ *      keys have equal fingerprints; k-mer 0 has fingerprint 0 and so "matches" the first empty
+ *      slot exactly like :96-98).  ~90 % of the k-mers end here at 53 % fill.
+ *   B  the rest (no match and no empty slot among the 4, or a false fingerprint match) are
+ *      compacted into a per-wave LDS queue and walked slot by slot once per bucket, in dense rows.
+ * (Measured with in-kernel stamps on the round-1 kernel, which looked at 2 keys per k-mer and
+ * queued 22 %: 31 % of its time was that queue walk, 12 % the barrier imbalance behind it, 22 %
+ * phase A, 24 % ISSUING its 8-byte-per-lane global loads.  All global traffic is 16 bytes per
+ * lane here.)
  *
  * Template parameters (chosen per launch by launch_partitioned):
  *   PIPE  few k-mers per bucket (hg38-scale tables): the counter tile is prefetched with the
  *         key slice a bucket ahead and stored back plainly; otherwise the tile starts at zero
  *         and only the sectors that got counts are read and written at flush time;
- *   G     rows of kCountThreads k-mers per group (each thread holds G k-mers in registers).
+ *   G2    16-byte k-mer loads per thread per group (2 k-mers each).
  * Two workgroups per CU (LDS), 4 waves per SIMD: the register budget is 128 VGPRs. */
-template <int LG_S, bool PIPE, int G>
+struct CountGeo {
+    uint64_t range_lo;      /* first slot of bucket 0 (0, or a shard's own_lo)                   */
+    uint64_t lim_lo, lim_hi;/* the slots that are resident: [0, H) or the shard's span          */
+    uint64_t half;          /* H >> 1: buckets at or above walk down                            */
+};
+
+/* fingerprint of a key: 1..253; of an empty slot and of k-mer 0: 0 */
+__device__ __forceinline__ uint32_t fp8(uint64_t key)
+{
+    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    const uint32_t b = (lo ^ hi ^ (lo >> 13)) & 0xFFu;
+    return key == 0 ? 0u : (b * 253u + 256u) >> 8;
+}
+
+template <int LG_S, bool PIPE, int G2>
 __global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_t cap, TableView tv, uint64_t H,
+void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_t cap, TableView tv, CountGeo cg,
                          uint32_t n_buckets, const uint32_t *shared, DevStats *stats)
 {
     if (stats->part_lost != 0) return;       /* this batch is recounted by the direct kernel */
     constexpr int S = 1 << LG_S;
     constexpr int kWaves = kCountThreads / kWave;
-    __shared__ uint64_t skey[S + kHalo];
-    __shared__ uint32_t scnt[S + kHalo];
-    constexpr int kGroup = G;                         /* k-mers per thread per group */
-    constexpr int kQueueCap = 32 * G;                 /* per wave; what does not fit is finished in place */
+    constexpr int kSeg = S + kHalo;
+    constexpr int kQueueCap = 128;                    /* per wave and bucket; what does not fit is finished in place */
+    __shared__ uint64_t skey[kSeg];
+    __shared__ uint32_t scnt[kSeg];
+    __shared__ uint32_t sfp[kSeg / 4 + 4];            /* one byte per slot + 16 bytes of 0xFF */
     __shared__ uint64_t qk[kWaves][kQueueCap];
     __shared__ uint16_t qa[kWaves][kQueueCap];
+    uint8_t *const sfpb = reinterpret_cast<uint8_t *>(sfp);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     uint32_t n_probes = 0, n_hits = 0;      /* per lane: < 2^32 for any batch that fits the plan */
+#ifdef QM2_STAMPS
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now();
+#endif
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int kKeySteps = (kSeg / 2 + kCountThreads - 1) / kCountThreads;   /* 2 keys per lane and step     */
+    constexpr int kCntSteps = (kSeg / 4 + kCountThreads - 1) / kCountThreads;   /* 4 counters per lane and step */
+    constexpr uint32_t kGroupKmers = 2u * G2 * kCountThreads;
 
-    constexpr int kSteps = (S + kHalo + kCountThreads - 1) / kCountThreads;
-
-    /* geometry of bucket b: own range, staged slice (own + kHalo slots on the side its probe
-     * walks leave through, i.e. towards the middle of the table, :94-95), walk direction */
-    /* int_lo / int_len: the private interior in slice coordinates (i - int_lo < int_len, unsigned) */
-    struct Geo { uint64_t own_lo, own_hi, seg_lo; uint32_t seg, int_lo, int_len; bool down, shared; };
+    /* geometry of bucket b: own range, staged slice, walk direction.  Everything is a multiple of
+     * 4 slots (buckets, halo and spans are), so 16-byte accesses never straddle an edge.
+     * int_lo / int_len: the private interior in slice coordinates (i - int_lo < int_len, unsigned) */
+    struct Geo { uint64_t seg_lo; uint32_t seg, int_lo, int_len; bool down; };
     auto geo = [&](uint32_t b) {
         Geo g;
-        g.own_lo = (uint64_t)b << LG_S;
-        g.own_hi = g.own_lo + S < H ? g.own_lo + S : H;
-        g.down = (g.own_lo & (H >> 1)) != 0;                    /* upper half walks down */
-        uint64_t lo = g.own_lo, hi = g.own_hi;
-        if (H > (uint64_t)S) {
-            if (g.down) lo = g.own_lo >= (uint64_t)kHalo ? g.own_lo - kHalo : 0;
-            else        hi = g.own_hi + kHalo <= H ? g.own_hi + kHalo : H;
-        }
+        const uint64_t own_lo = cg.range_lo + ((uint64_t)b << LG_S), own_hi = own_lo + S;
+        g.down = (own_lo & cg.half) != 0;                         /* upper half walks down */
+        uint64_t lo = own_lo, hi = own_hi;
+        if (g.down) lo = own_lo >= cg.lim_lo + kHalo ? own_lo - kHalo : cg.lim_lo;
+        else        hi = own_hi + kHalo <= cg.lim_hi ? own_hi + kHalo : cg.lim_hi;
         g.seg_lo = lo;
         g.seg = (uint32_t)(hi - lo);
         /* a long run of occupied slots reaches into this bucket: nothing in it is private */
-        g.shared = shared != nullptr && ((shared[b >> 5] >> (b & 31)) & 1u) != 0;
-        const uint32_t own_len = (uint32_t)(g.own_hi - g.own_lo);
-        g.int_lo = (uint32_t)(g.own_lo - lo) + kHalo;
-        g.int_len = !g.shared && own_len > 2u * kHalo ? own_len - 2u * kHalo : 0u;
+        const bool sh = shared != nullptr && ((shared[b >> 5] >> (b & 31)) & 1u) != 0;
+        g.int_lo = (uint32_t)(own_lo - lo) + kHalo;
+        g.int_len = sh ? 0u : (uint32_t)S - 2u * kHalo;
         return g;
     };
     /* Software pipeline over the buckets of this workgroup (stride gridDim.x): everything bucket
      * b+stride needs from HBM — its table slice, the old values of its counters, its fill and its
      * first group of k-mers — is loaded into registers while bucket b is probed, and later groups
-     * of b while the current group is probed.  Nothing in the steady state waits for a load that
-     * was issued less than one bucket ago. */
+     * of b while the current group is probed. */
     const uint32_t stride = gridDim.x;
-    uint64_t kv[kSteps];
-    uint32_t ov[kSteps];
+    u32x4 kv[kKeySteps];
+    u32x4 ov[kCntSteps];
     auto fetch_slice = [&](uint32_t b) {
         if (b >= n_buckets) return;
         const Geo g = geo(b);
-        const uint64_t *kp = tv.keys + g.seg_lo;
+        const u32x4 *kp = reinterpret_cast<const u32x4 *>(tv.keys + (g.seg_lo - tv.span_lo));
 #pragma unroll
-        for (int st = 0; st < kSteps; st++) {
-            const uint32_t i = tid + st * kCountThreads;
-            kv[st] = i < g.seg ? kp[i] : 0;
+        for (int st = 0; st < kKeySteps; st++) {
+            const uint32_t i2 = tid + st * kCountThreads;
+            kv[st] = 2 * i2 < g.seg ? kp[i2] : u32x4{0, 0, 0, 0};
         }
         if constexpr (PIPE) {
-            const uint32_t *cp = tv.counters + (g.seg_lo - tv.span_lo);
+            const u32x4 *cp4 = reinterpret_cast<const u32x4 *>(tv.counters + (g.seg_lo - tv.span_lo));
 #pragma unroll
-            for (int st = 0; st < kSteps; st++) {
-                const uint32_t i = tid + st * kCountThreads;
-                ov[st] = i - g.int_lo < g.int_len ? cp[i] : 0;
+            for (int st = 0; st < kCntSteps; st++) {
+                const uint32_t i4 = tid + st * kCountThreads;
+                ov[st] = 4 * i4 - g.int_lo < g.int_len ? cp4[i4] : u32x4{0, 0, 0, 0};
             }
         }
     };
@@ -380,17 +426,20 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         uint32_t n = b < n_buckets ? cursors[b] : 0;
         return n > cap ? cap : n;
     };
-    uint64_t nq[kGroup];
+    /* 16 bytes = k-mers e, e+1 of the bucket at `src` (cap is a multiple of 64: 16-byte aligned) */
+    u32x4 nq[G2];
+    auto load_group = [&](const uint64_t *src, uint32_t first, uint32_t n_src) {
+#pragma unroll
+        for (int q = 0; q < G2; q++) {
+            const uint32_t e = first + 2u * (q * kCountThreads + tid);
+            nq[q] = e < n_src ? *reinterpret_cast<const u32x4 *>(src + e) : u32x4{~0u, ~0u, ~0u, ~0u};
+        }
+    };
     uint32_t n_next = 0, n_after = 0;
     fetch_slice(blockIdx.x);
     if constexpr (PIPE) {
         n_next = fill_of(blockIdx.x);                         /* fill of the bucket about to start */
-        const uint64_t *in0 = kmers + (uint64_t)blockIdx.x * cap;
-#pragma unroll
-        for (int q = 0; q < kGroup; q++) {
-            const uint32_t i = q * kCountThreads + tid;
-            nq[q] = i < n_next ? in0[i] : kPad;
-        }
+        load_group(kmers + (uint64_t)blockIdx.x * cap, 0, n_next);
         n_after = fill_of(blockIdx.x + stride);               /* ... and of the one after it */
     }
 
@@ -401,161 +450,184 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         const uint32_t seg = g.seg;
         const bool down = g.down;
         const uint32_t int_lo = g.int_lo, int_len = g.int_len;
+        /* LDS position of slice index i: mirrored for the upper half, so every walk goes up in LDS */
+        auto mir = [&](uint32_t i) { return down ? seg - 1u - i : i; };
+        /* position of home slot h: (h ^ xm) + ad  (up: h - seg_lo; down: seg_lo + seg - 1 - h) */
+        const uint32_t xm = down ? ~0u : 0u;
+        const uint32_t ad = down ? (uint32_t)(seg_lo + seg) : (uint32_t)(0u - (uint32_t)seg_lo);
         uint32_t *const cp = tv.counters + (seg_lo - tv.span_lo);
-        /* the counter tile starts from the old values of the interior (0 elsewhere), so the LDS
-         * atomics accumulate straight onto them */
+        QM2_STAMP(0);
+#ifdef QM2_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        QM2_STAMP(1);                      /* waiting for the prefetched slice (stamp builds only) */
+#endif
+        /* stage: keys, fingerprints, and the counter tile — which starts from the old values of the
+         * interior (0 elsewhere), so the LDS atomics accumulate straight onto them */
 #pragma unroll
-        for (int st = 0; st < kSteps; st++) {
-            const uint32_t i = tid + st * kCountThreads;
-            if (i < seg) { skey[i] = kv[st]; scnt[i] = PIPE ? ov[st] : 0u; }
+        for (int st = 0; st < kKeySteps; st++) {
+            const uint32_t i = 2u * (tid + st * kCountThreads);
+            if (i < (uint32_t)kSeg + 16u) {
+                const uint64_t k0 = ((uint64_t)kv[st].y << 32) | kv[st].x, k1 = ((uint64_t)kv[st].w << 32) | kv[st].z;
+                if (i < seg) {
+                    const uint32_t m0 = mir(i), m1 = mir(i + 1);
+                    skey[m0] = k0; skey[m1] = k1;
+                    sfpb[m0] = (uint8_t)fp8(k0); sfpb[m1] = (uint8_t)fp8(k1);
+                } else {
+                    sfpb[i] = 0xFF; sfpb[i + 1] = 0xFF;         /* beyond the slice (positions, not mirrored) */
+                }
+            }
         }
+#pragma unroll
+        for (int st = 0; st < kCntSteps; st++) {
+            const uint32_t i = 4u * (tid + st * kCountThreads);
+            if (i < seg) {
+                const u32x4 o = PIPE ? ov[st] : u32x4{0, 0, 0, 0};
+                scnt[mir(i)] = o.x; scnt[mir(i + 1)] = o.y; scnt[mir(i + 2)] = o.z; scnt[mir(i + 3)] = o.w;
+            }
+        }
+        QM2_STAMP(2);                      /* staging the slice in LDS */
         lds_barrier();
+        QM2_STAMP(3);                      /* barrier after staging */
         const uint32_t bn = b + stride;
         fetch_slice(bn);
         if constexpr (PIPE) {
             n_next = n_after;
             n_after = fill_of(bn + stride);
         }
+        QM2_STAMP(9);                      /* issuing the next slice's loads */
 
-        /* continue a walk from staged position `at` (may be outside the slice: then, and when it
-         * leaves the slice later, it finishes in global memory like the direct kernel) */
-        auto walk = [&](uint64_t km, int32_t at, bool dn, uint32_t seen) {
+        /* continue a walk at staged position p (may be beyond the slice: then, and when it leaves the
+         * slice later, it finishes in global memory like the direct kernel) */
+        auto walk = [&](uint64_t km, uint32_t p, uint32_t seen) {
             for (;;) {
-                if (at < 0 || at >= (int32_t)seg) {
-                    uint64_t slot = seg_lo + (int64_t)at;
+                if (p >= seg) {
+                    uint64_t slot = down ? seg_lo + seg - 1u - (uint64_t)p : seg_lo + p;
                     for (;;) {
-                        const uint64_t gk = tv.keys[slot];
+                        const uint64_t gk = tv.keys[slot - tv.span_lo];
                         seen++;
-                        if (gk == km) { atomicAdd(&tv.counters[slot], 1u); n_hits++; break; }
+                        if (gk == km) { atomicAdd(&tv.counters[slot - tv.span_lo], 1u); n_hits++; break; }
                         if (gk == 0) break;
-                        slot += dn ? (uint64_t)-1 : 1;
+                        slot += down ? (uint64_t)-1 : 1;
                     }
                     break;
                 }
-                const uint64_t v = skey[at];
+                const uint64_t v = skey[p];
                 seen++;
-                if (v == km) { atomicAdd(&scnt[at], 1u); n_hits++; break; }   /* :98, :291 */
+                if (v == km) { atomicAdd(&scnt[p], 1u); n_hits++; break; }   /* :98, :291 */
                 if (v == 0) break;
-                at += dn ? -1 : 1;                                         /* :97 */
+                p++;                                                        /* :97 */
             }
             n_probes += seen;
         };
 
         const uint64_t *in = kmers + (uint64_t)b * cap;
         const uint64_t *in_next = kmers + (uint64_t)bn * cap;
-        if constexpr (!PIPE) {
-#pragma unroll
-            for (int q = 0; q < kGroup; q++) {
-                const uint32_t i = q * kCountThreads + tid;
-                nq[q] = i < n ? in[i] : kPad;
+        if constexpr (!PIPE) load_group(in, 0, n);
+        uint32_t queued = 0;                                                /* wave-uniform */
+        /* ---- phase A: one k-mer, four slots, no loop ---- */
+        auto probe1 = [&](uint64_t km, bool live) {
+            const uint32_t h = djb32(km) & tv.hmask;                        /* :92 */
+            const uint32_t p = live ? (h ^ xm) + ad : 0u;
+            const uint32_t d0 = sfp[p >> 2], d1 = sfp[(p >> 2) + 1];
+            const uint32_t w = __builtin_amdgcn_alignbyte(d1, d0, p & 3u);  /* fingerprints of p .. p+3 */
+            const uint32_t x = w ^ (fp8(km) * 0x01010101u);
+            /* lowest flagged byte is exact (a borrow only ever flags bytes ABOVE a zero byte) */
+            const uint32_t zm = (x - 0x01010101u) & ~x & 0x80808080u;       /* fingerprint matches */
+            const uint32_t ze = (w - 0x01010101u) & ~w & 0x80808080u;       /* empty slots         */
+            const uint32_t lm = (uint32_t)__ffs((int)zm) - 1u, le = (uint32_t)__ffs((int)ze) - 1u;   /* 0xFFFFFFFF: none */
+            const bool cand = lm <= le && lm < 32u;                         /* a match at or before the first empty slot */
+            const bool miss = !cand && le < 32u;                            /* an empty slot first: not in the dictionary */
+            const uint32_t c = cand ? lm >> 3 : 0u;
+            const uint64_t v = skey[p + c];
+            const bool hit = live && cand && v == km;                       /* :98 (k-mer 0: the empty slot itself) */
+            if (hit) atomicAdd(&scnt[p + c], 1u);                           /* :291 */
+            n_hits += hit ? 1u : 0u;
+            n_probes += !live ? 0u : hit ? c + 1u : miss ? (le >> 3) + 1u : 0u;   /* unresolved: walk() adds the total */
+            const bool more = live && !hit && !miss;     /* nothing decisive in 4 slots, or a false fingerprint match */
+            const unsigned long long m = __ballot(more);
+            if (m) {
+                const uint32_t slot = queued + __popcll(m & ((1ull << lane) - 1));
+                const uint32_t seen = cand ? c + 1u : 4u;                   /* slots the reference walk has passed */
+                if (more) {
+                    if (slot < (uint32_t)kQueueCap) {
+                        qk[wave][slot] = km;
+                        qa[wave][slot] = (uint16_t)((p + seen) | ((seen - 1u) << 13));
+                    } else {
+                        walk(km, p + seen, seen);                           /* queue full: finish in place */
+                    }
+                }
+                queued += __popcll(m);
             }
-        }
+        };
         uint32_t base = 0;
         /* PIPE runs the body once even for an empty bucket: it carries the next bucket's prefetch */
         while (PIPE ? (base == 0 || base < n) : base < n) {
-            uint64_t kq[kGroup];
-            const bool last = PIPE && base + kGroup * kCountThreads >= n;   /* workgroup-uniform */
+            u32x4 kq[G2];
 #pragma unroll
-            for (int q = 0; q < kGroup; q++) {
-                kq[q] = nq[q];
-                /* next group of this bucket, or (PIPE) behind the last one the first of the next bucket */
-                const uint32_t j = q * kCountThreads + tid;
-                const uint32_t i = base + kGroup * kCountThreads + j;
-                nq[q] = last ? (j < n_next ? in_next[j] : kPad) : (i < n ? in[i] : kPad);
+            for (int q = 0; q < G2; q++) kq[q] = nq[q];
+            /* next group of this bucket, or (PIPE) behind the last one the first of the next bucket */
+            if (PIPE && base + kGroupKmers >= n) load_group(in_next, 0, n_next);   /* workgroup-uniform */
+            else load_group(in, base + kGroupKmers, n);
+            QM2_STAMP(10);                 /* rotating nq -> kq, issuing the next group's loads */
+            /* All G2 rows run as one straight-line block even when the last ones hold no k-mer
+             * (skipping rows was measured slower in round 1): the host picks G2 to fit the fill. */
+#pragma unroll
+            for (int q = 0; q < G2; q++) {
+                const uint32_t e = base + 2u * (q * kCountThreads + tid);
+                probe1(((uint64_t)kq[q].y << 32) | kq[q].x, e < n);
+                probe1(((uint64_t)kq[q].w << 32) | kq[q].z, e + 1u < n);
             }
-            /* ---- phase A: two slots per k-mer, no loop.  All kGroup rows run as one straight-line
-             * block even when the last ones hold no k-mer: skipping rows (a branch per row, or one
-             * block per row count) was measured 12 % SLOWER, so the host picks kGroup to fit the
-             * bucket fill instead. ---- */
-            uint32_t queued = 0;                                            /* wave-uniform */
-            auto phase_a = [&]() {
-#pragma unroll
-                for (int q = 0; q < kGroup; q++) {
-                    const uint64_t km = kq[q];
-                    const bool live = km != kPad;
-                    const uint32_t home = djb32(km) & tv.hmask;                    /* :92 */
-                    /* H <= S: the single bucket holds both halves, direction per k-mer */
-                    const bool dn = H > (uint64_t)S ? down : (home & tv.hhalf) != 0;
-                    const int32_t at0 = live ? (int32_t)((uint64_t)home - seg_lo) : 0;
-                    const int32_t at1 = at0 + (dn ? -1 : 1);
-                    const bool in1 = at1 >= 0 && at1 < (int32_t)seg;
-                    const uint64_t v0 = skey[at0];
-                    const uint64_t v1 = skey[in1 ? at1 : at0];
-                    const bool hit0 = live && v0 == km;                          /* :98 */
-                    const bool end0 = hit0 || v0 == 0;
-                    const bool hit1 = live && !end0 && in1 && v1 == km;
-                    const bool end1 = end0 || (in1 && (hit1 || v1 == 0));
-                    if (hit0) atomicAdd(&scnt[at0], 1u);                          /* :291 */
-                    if (hit1) atomicAdd(&scnt[at1], 1u);
-                    n_hits += (hit0 || hit1) ? 1 : 0;
-                    const bool more = live && !end1;       /* both occupied by other keys, or at1 outside */
-                    n_probes += live ? (end0 ? 1u : (end1 ? 2u : 0u)) : 0u;   /* unresolved: walk() adds the total */
-                    /* unresolved: compact into this wave's queue; entry = position to look at next,
-                     * direction, and how many slots were counted so far */
-                    const unsigned long long m = __ballot(more);
-                    if (m) {
-                        const uint32_t slot = queued + __popcll(m & ((1ull << lane) - 1));
-                        const int32_t nxt = in1 ? at1 + (dn ? -1 : 1) : at1;
-                        const uint32_t seen = in1 ? 2u : 1u;
-                        if (more) {
-                            if (slot < (uint32_t)kQueueCap) {
-                                qk[wave][slot] = km;
-                                qa[wave][slot] = (uint16_t)((uint32_t)(nxt + 1) | (dn ? 0x2000u : 0u) | ((seen - 1) << 14));
-                            } else {
-                                walk(km, nxt, dn, seen);             /* queue full: finish in place */
-                            }
-                        }
-                        queued += __popcll(m);
-                    }
-                }
-            };
-            phase_a();
-            /* ---- phase B: dense rows over the compacted queue ---- */
+            QM2_STAMP(4);                  /* phase A */
+            base += kGroupKmers;
+        }
+        /* ---- phase B: this wave's unresolved k-mers, dense rows, once per bucket ---- */
+        {
             const uint32_t qn = queued < (uint32_t)kQueueCap ? queued : (uint32_t)kQueueCap;
             for (uint32_t e = lane; e < qn; e += kWave) {
-                const uint64_t km = qk[wave][e];
                 const uint32_t a = qa[wave][e];
-                walk(km, (int32_t)(a & 0x1FFFu) - 1, (a & 0x2000u) != 0, (a >> 14) + 1);
+                walk(qk[wave][e], a & 0x1FFFu, (a >> 13) + 1u);
             }
-            base += kGroup * kCountThreads;
         }
+        QM2_STAMP(5);                      /* phase B */
         lds_barrier();
+        QM2_STAMP(6);                      /* barrier before the flush */
         /* flush: the interior of the owned range is touched by this workgroup only, so the tile
          * (old values, fetched a bucket ago, plus this bucket's counts) is stored back plainly; the
          * kHalo slots at either end of it and the staged halo can also receive a neighbour's
          * counts, so there the tile holds deltas and they are added atomically. */
         if (n) {
-            if constexpr (PIPE) {
 #pragma unroll
-                for (int st = 0; st < kSteps; st++) {
-                    const uint32_t i = tid + st * kCountThreads;
-                    if (i < seg) {
-                        const uint32_t cv = scnt[i];
-                        if (i - int_lo < int_len) cp[i] = cv;
-                        else if (cv) atomicAdd(cp + i, cv);
+            for (int st = 0; st < kCntSteps; st++) {
+                const uint32_t i = 4u * (tid + st * kCountThreads);
+                if (i < seg) {
+                    u32x4 cv = {scnt[mir(i)], scnt[mir(i + 1)], scnt[mir(i + 2)], scnt[mir(i + 3)]};
+                    u32x4 *const dst = reinterpret_cast<u32x4 *>(cp + i);
+                    if (i - int_lo < int_len) {
+                        if constexpr (PIPE) *dst = cv;
+                        else if (cv.x | cv.y | cv.z | cv.w) {
+                            /* sparse table: only the sectors that got counts are read and written */
+                            const u32x4 old = *dst;
+                            *dst = old + cv;
+                        }
+                    } else {
+                        if (cv.x) atomicAdd(cp + i, cv.x);
+                        if (cv.y) atomicAdd(cp + i + 1, cv.y);
+                        if (cv.z) atomicAdd(cp + i + 2, cv.z);
+                        if (cv.w) atomicAdd(cp + i + 3, cv.w);
                     }
                 }
-            } else {
-                /* sparse table: only the sectors that got counts are read and written (all reads
-                 * issued before the writes) */
-                uint32_t cv[kSteps], old[kSteps];
-#pragma unroll
-                for (int st = 0; st < kSteps; st++) {
-                    const uint32_t i = tid + st * kCountThreads;
-                    cv[st] = i < seg ? scnt[i] : 0;
-                    old[st] = 0;
-                    if (cv[st]) {
-                        if (i - int_lo < int_len) old[st] = cp[i];
-                        else { atomicAdd(cp + i, cv[st]); cv[st] = 0; }
-                    }
-                }
-#pragma unroll
-                for (int st = 0; st < kSteps; st++)
-                    if (cv[st]) cp[tid + st * kCountThreads] = old[st] + cv[st];
             }
         }
         lds_barrier();
+        QM2_STAMP(7);                      /* flush + barrier */
     }
+#ifdef QM2_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 8; i++) atomicAdd(&qm2_stamp_acc[i], st_acc[i]);
+        for (int i = 9; i < 12; i++) atomicAdd(&qm2_stamp_acc[i], st_acc[i]);
+        atomicAdd(&qm2_stamp_acc[8], 1ull);
+    }
+#endif
     const unsigned long long w_probes = wave_sum((unsigned long long)n_probes), w_hits = wave_sum((unsigned long long)n_hits);
     if (lane == 0) {
         atomicAdd(&stats->n_probes, w_probes);
