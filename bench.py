@@ -190,13 +190,15 @@ def main():
         fn = pyqm2.lib().qm2_debug_stamps
         acc = (_C.c_uint64 * 16)()
         fn(acc)
-        nw = max(1, acc[8])
-        names = ["other", "wait_slice", "stage", "bar_stage", "phase_a", "phase_b", "bar_flush", "flush", None,
-                 "issue_slice", "rotate_nq", "wait_kmers"]
-        idx = [i for i in range(12) if names[i]]
-        tot = sum(acc[i] for i in idx)
-        sys.stderr.write("STAMPS waves=%d total_cycles_per_wave=%.0f " % (nw, tot / nw) +
-                         " ".join("%s=%.1f%%" % (names[i], 100.0 * acc[i] / max(1, tot)) for i in idx) + "\n")
+        nl, npw = max(1, acc[8]), max(1, acc[9])
+        lt = sum(acc[i] for i in (0, 1, 2, 3, 10))
+        ptot = sum(acc[i] for i in (4, 5, 6, 7))
+        sys.stderr.write("STAMPS loaders=%d cycles/wave=%.0f flush=%.1f%% wait_regs=%.1f%% stage=%.1f%% fetch_issue=%.1f%% barrier=%.1f%% | "
+                         "probers=%d cycles/wave=%.0f kmer_loads=%.1f%% phase_a=%.1f%% phase_b=%.1f%% barrier=%.1f%%\n"
+                         % (nl, lt / nl, 100.0 * acc[0] / max(1, lt), 100.0 * acc[10] / max(1, lt), 100.0 * acc[1] / max(1, lt),
+                            100.0 * acc[2] / max(1, lt), 100.0 * acc[3] / max(1, lt),
+                            npw, ptot / npw, 100.0 * acc[4] / max(1, ptot), 100.0 * acc[5] / max(1, ptot),
+                            100.0 * acc[6] / max(1, ptot), 100.0 * acc[7] / max(1, ptot)))
     except AttributeError:
         pass
 

@@ -138,7 +138,12 @@ __host__ __device__ __forceinline__ uint32_t djb_s4(uint32_t w)
 __host__ __device__ __forceinline__ uint32_t djb32(uint64_t kmer)
 {
     uint32_t x = djb_s4((uint32_t)kmer);
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __umul24(x, 1185921u);       /* * 33^4: both factors < 2^24 (S < 2^24), one full-rate v_mul_u32_u24; hipcc turns
+                                        four shift-adds into a quarter-rate v_mul_lo_u32 */
+#else
     x = (x << 5) + x; x = (x << 5) + x; x = (x << 5) + x; x = (x << 5) + x;      /* * 33^4 */
+#endif
     return x + djb_s4((uint32_t)(kmer >> 32)) + 0x7BB34A05u;                     /* + 5381 * 33^8 mod 2^32 */
 }
 

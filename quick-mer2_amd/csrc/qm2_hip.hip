@@ -53,11 +53,8 @@ constexpr size_t kDevPad = 64;
 #ifndef QM2_LG_S
 #define QM2_LG_S 12
 #endif
-#ifndef QM2_COUNT_PIPE
-#define QM2_COUNT_PIPE 2          /* 0 never, 1 always, 2 by k-mers per bucket */
-#endif
 #ifndef QM2_COUNT_GRID_MULT
-#define QM2_COUNT_GRID_MULT 8        /* bucket_count workgroups = 2 per CU (what is resident) x this */
+#define QM2_COUNT_GRID_MULT 4        /* bucket_count workgroups = 1 per CU (what is resident) x this */
 #endif
 constexpr int    kLgS = QM2_LG_S;          /* finest bucket = 2^kLgS table slots: 12 B of LDS per slot */
 }  // namespace
@@ -293,22 +290,20 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
     {
         const int L = p.levels - 1;
         const uint32_t n_buckets = (uint32_t)p.buckets[L];
-        const int grid = (int)std::min<uint64_t>(n_buckets, (uint64_t)c->n_cu * 2 * QM2_COUNT_GRID_MULT);
+        const int grid = (int)std::min<uint64_t>(n_buckets, (uint64_t)c->n_cu * QM2_COUNT_GRID_MULT);
         if (time_begin(c, &t, QM2_K_BUCKET_COUNT)) return 1;
-        /* few k-mers per bucket (hg38-scale tables): the counter tile is fetched a bucket ahead with
-         * the key slice (PIPE), and the group size is picked so that a bucket's fill (mean + 3 sigma
-         * of uniform hashing) wastes the fewest 512-k-mer rows; many k-mers per bucket: the flush
-         * touches only the sectors that got counts, and the group size hardly matters */
+        /* the group size (16-byte k-mer loads per prober thread) is picked so that a bucket's fill (mean
+         * + 3 sigma of uniform hashing; k-mers per byte measured on earlier batches through an asynchronous
+         * copy of the stats block) wastes the fewest rows */
         if (c->peek_pending && hipEventQuery(c->peek_evt) == hipSuccess) {
             c->peek_pending = false;
             if (c->peek_bytes) c->kmers_per_byte = std::min(1.0, (double)c->stats_peek->n_kmers / (double)c->peek_bytes);
         }
         const uint64_t per_bucket = (uint64_t)((double)sv.n_total * c->kmers_per_byte) / n_buckets;
-        const bool pipe = QM2_COUNT_PIPE == 2 ? per_bucket < (2u << kLgS) : QM2_COUNT_PIPE != 0;
         int g = 4;
-        if (pipe) {
+        {
             const double fill = (double)per_bucket + 3.0 * std::sqrt((double)per_bucket + 1.0);
-            const int rows = std::max(1, (int)std::ceil(fill / (2.0 * kCountThreads)));   /* rows of 2 k-mers per thread */
+            const int rows = std::max(1, (int)std::ceil(fill / (2.0 * kProberThreads)));   /* rows of 2 k-mers per thread */
             int best_rows = 1 << 30;
             for (int cand = 2; cand <= 6; cand++) {
                 const int run = (rows + cand - 1) / cand * cand;               /* rows executed */
@@ -316,17 +311,16 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
             }
         }
         const CountGeo cg = {0, 0, c->H, c->H >> 1};
-#define QM2_LAUNCH_COUNT(PIPE_, G_)                                                                             \
-        hipLaunchKernelGGL((bucket_count_kernel<kLgS, PIPE_, G_>), dim3(grid), dim3(kCountThreads), 0, s,      \
+#define QM2_LAUNCH_COUNT(G_)                                                                                    \
+        hipLaunchKernelGGL((bucket_count_kernel<kLgS, G_>), dim3(grid), dim3(kCountThreads), 0, s,             \
                            p.buf[L & 1], p.cursors + p.cursor_off[L], p.cap[L], table_view(c), cg, n_buckets,   \
                            p.shared, c->stats)
-        if (!pipe) QM2_LAUNCH_COUNT(false, 4);
-        else switch (g) {
-            case 2: QM2_LAUNCH_COUNT(true, 2); break;
-            case 3: QM2_LAUNCH_COUNT(true, 3); break;
-            case 4: QM2_LAUNCH_COUNT(true, 4); break;
-            case 5: QM2_LAUNCH_COUNT(true, 5); break;
-            default: QM2_LAUNCH_COUNT(true, 6); break;
+        switch (g) {
+            case 2: QM2_LAUNCH_COUNT(2); break;
+            case 3: QM2_LAUNCH_COUNT(3); break;
+            case 4: QM2_LAUNCH_COUNT(4); break;
+            case 5: QM2_LAUNCH_COUNT(5); break;
+            default: QM2_LAUNCH_COUNT(6); break;
         }
 #undef QM2_LAUNCH_COUNT
         HIP_OK(hipGetLastError());

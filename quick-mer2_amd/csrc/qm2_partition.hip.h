@@ -36,7 +36,7 @@ namespace qm2 {
 #define QM2_SPLIT_THREADS 1024
 #endif
 #ifndef QM2_COUNT_THREADS
-#define QM2_COUNT_THREADS 512
+#define QM2_COUNT_THREADS 1024
 #endif
 constexpr int kSplitThreads  = QM2_SPLIT_THREADS;    /* 1024 threads x 16 k-mers: long runs per child beat
                                                         occupancy (512 x 16 and 1024 x 8, two workgroups
@@ -51,6 +51,9 @@ constexpr uint64_t kPad      = ~0ull;                /* never a k-mer (k <= 31 u
 constexpr int kHalo          = 256;                  /* table slots staged past a bucket's
                                                         middle-facing edge                      */
 constexpr int kCountThreads  = QM2_COUNT_THREADS;
+#ifndef QM2_COUNT_SET
+#define QM2_COUNT_SET 4
+#endif
 
 /* Workgroup barrier for LDS hand-offs.  hipcc's __syncthreads() also drains every outstanding
  * global load / store / atomic of the wave (s_waitcnt vmcnt(0)); these kernels keep a prefetch,
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
     if (lane == 0 && lost) atomicAdd(&stats->part_lost, lost);
 }
 
-/* Finest level: one workgroup per bucket of S = 2^LG_S table slots.
+/* Finest level: one bucket of S = 2^LG_S table slots at a time per workgroup, one workgroup per CU.
  *
  * The slice of a bucket (its S slots + kHalo slots on the side probe walks leave through, i.e.
  * towards the middle of the table, :94-95) is staged in LDS MIRRORED for the upper half of the
@@ -318,69 +321,79 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
  * the keys and the counter tile sits one FINGERPRINT byte per slot: 0 = empty, 1..253 = a function
  * of the key, 0xFF = beyond the staged slice.
  *
- * Probing in LDS is cheap per step but DIVERGENT as a per-lane loop (at 53 % fill a k-mer needs
- * 1.75 slots on average, the slowest of a wave's 64 lanes ~12).  So:
- *   A  straight-line, every k-mer: the fingerprints of the 4 slots from its home slot on (two
- *      aligned dwords + v_alignbyte) are compared SWAR-wise with the k-mer's own fingerprint; the
- *      first match at or before the first empty slot is verified against the full key (exact: equal
- *      keys have equal fingerprints; k-mer 0 has fingerprint 0 and so "matches" the first empty
- *      slot exactly like :96-98).  ~90 % of the k-mers end here at 53 % fill.
- *   B  the rest (no match and no empty slot among the 4, or a false fingerprint match) are
- *      compacted into a per-wave LDS queue and walked slot by slot once per bucket, in dense rows.
- * (Measured with in-kernel stamps on the round-1 kernel, which looked at 2 keys per k-mer and
- * queued 22 %: 31 % of its time was that queue walk, 12 % the barrier imbalance behind it, 22 %
- * phase A, 24 % ISSUING its 8-byte-per-lane global loads.  All global traffic is 16 bytes per
- * lane here.)
+ * Roles (measured with in-kernel stamps on the one-role kernels of round 1 / early round 2: 18-25 %
+ * of a wave's time went into ISSUING the slice loads — the per-CU fetch path takes ~10 B/clk, the
+ * issuing wave stalls — and the prefetch registers left the probe code no room to overlap its LDS
+ * round trips):
+ *   waves 0..3   LOADERS: stream the table slice of the bucket after next into registers, stage the
+ *                next bucket's slice (keys, fingerprints, old counter values) into the OTHER LDS
+ *                buffer, and flush the counter tile of the previous bucket;
+ *   waves 4..15  PROBERS: probe the current bucket's k-mers against the current buffer.
+ * One workgroup barrier per bucket: behind barrier k the probers are done with bucket k-1 and the
+ * loaders have staged bucket k.  A loader thread flushes exactly the counter slots it later stages,
+ * so flush (k-1) -> stage (k+1) into the same buffer needs no second barrier.
  *
- * Template parameters (chosen per launch by launch_partitioned):
- *   PIPE  few k-mers per bucket (hg38-scale tables): the counter tile is prefetched with the
- *         key slice a bucket ahead and stored back plainly; otherwise the tile starts at zero
- *         and only the sectors that got counts are read and written at flush time;
- *   G2    16-byte k-mer loads per thread per group (2 k-mers each).
- * Two workgroups per CU (LDS), 4 waves per SIMD: the register budget is 128 VGPRs. */
+ * Probing is cheap per step but DIVERGENT as a per-lane loop (at 53 % fill a k-mer needs 1.75 slots
+ * on average, the slowest of a wave's 64 lanes ~12).  So:
+ *   A  straight-line, kSet k-mers at a time: the fingerprints of the 4 slots from the home slot on
+ *      (two aligned dwords + v_alignbyte) are compared SWAR-wise with the k-mer's own fingerprint;
+ *      the first match at or before the first empty slot is verified against the full key (exact:
+ *      equal keys have equal fingerprints; k-mer 0 has fingerprint 0 and so "matches" the first
+ *      empty slot exactly like :96-98).  ~90 % of the k-mers end here at 53 % fill.
+ *   B  the rest (no match and no empty slot among the 4, or a false fingerprint match) are
+ *      compacted into a per-wave LDS queue and finished once per bucket in dense rows, again four
+ *      fingerprints per step.
+ *
+ * Counter tile: starts from the old values of the bucket's private interior (0 elsewhere), so the
+ * LDS atomics accumulate straight onto them and the interior is stored back plainly; the kHalo slots
+ * at either end of the owned range and the staged halo can also receive a neighbour's counts, so
+ * there the tile holds deltas that are added atomically.
+ *
+ * G2 = 16-byte k-mer loads per prober thread per group (2 k-mers each), chosen per launch. */
 struct CountGeo {
     uint64_t range_lo;      /* first slot of bucket 0 (0, or a shard's own_lo)                   */
     uint64_t lim_lo, lim_hi;/* the slots that are resident: [0, H) or the shard's span          */
     uint64_t half;          /* H >> 1: buckets at or above walk down                            */
 };
 
-/* fingerprint of a key: 1..253; of an empty slot and of k-mer 0: 0 */
+/* fingerprint of a stored key: odd, 1..255; of an empty slot: 0; beyond the staged slice: 0xFE */
 __device__ __forceinline__ uint32_t fp8(uint64_t key)
 {
     const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-    const uint32_t b = (lo ^ hi ^ (lo >> 13)) & 0xFFu;
-    return key == 0 ? 0u : (b * 253u + 256u) >> 8;
+    return ((lo ^ hi ^ (lo >> 13)) & 0xFFu) | 1u;
 }
+constexpr uint32_t kFpPad = 0xFEu;
 
-template <int LG_S, bool PIPE, int G2>
-__global__ __launch_bounds__(kCountThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef QM2_LOADER_WAVES
+#define QM2_LOADER_WAVES 3
+#endif
+constexpr int kLoaderWaves = QM2_LOADER_WAVES;
+
+constexpr int kLoaderThreads = kLoaderWaves * kWave;
+constexpr int kProberThreads = kCountThreads - kLoaderThreads;
+constexpr int kProberWaves = kProberThreads / kWave;
+
+template <int LG_S, int G2>
+__global__ __launch_bounds__(kCountThreads)
 void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_t cap, TableView tv, CountGeo cg,
                          uint32_t n_buckets, const uint32_t *shared, DevStats *stats)
 {
     if (stats->part_lost != 0) return;       /* this batch is recounted by the direct kernel */
     constexpr int S = 1 << LG_S;
-    constexpr int kWaves = kCountThreads / kWave;
     constexpr int kSeg = S + kHalo;
     constexpr int kQueueCap = 128;                    /* per wave and bucket; what does not fit is finished in place */
-    __shared__ uint64_t skey[kSeg];
-    __shared__ uint32_t scnt[kSeg];
-    __shared__ uint32_t sfp[kSeg / 4 + 4];            /* one byte per slot + 16 bytes of 0xFF */
-    __shared__ uint64_t qk[kWaves][kQueueCap];
-    __shared__ uint16_t qa[kWaves][kQueueCap];
-    uint8_t *const sfpb = reinterpret_cast<uint8_t *>(sfp);
+    __shared__ uint64_t skey[2][kSeg];
+    __shared__ uint32_t scnt[2][kSeg];
+    __shared__ uint32_t sfp[2][kSeg / 4 + 4];         /* one byte per slot + 16 bytes of kFpPad */
+    __shared__ uint64_t qk[kProberWaves][kQueueCap];
+    __shared__ uint16_t qa[kProberWaves][kQueueCap];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    uint32_t n_probes = 0, n_hits = 0;      /* per lane: < 2^32 for any batch that fits the plan */
-#ifdef QM2_STAMPS
-    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now();
-#endif
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int kKeySteps = (kSeg / 2 + kCountThreads - 1) / kCountThreads;   /* 2 keys per lane and step     */
-    constexpr int kCntSteps = (kSeg / 4 + kCountThreads - 1) / kCountThreads;   /* 4 counters per lane and step */
-    constexpr uint32_t kGroupKmers = 2u * G2 * kCountThreads;
+    const uint32_t stride = gridDim.x;
 
-    /* geometry of bucket b: own range, staged slice, walk direction.  Everything is a multiple of
-     * 4 slots (buckets, halo and spans are), so 16-byte accesses never straddle an edge.
-     * int_lo / int_len: the private interior in slice coordinates (i - int_lo < int_len, unsigned) */
+    /* geometry of bucket b: staged slice, walk direction, private interior.  Everything is a
+     * multiple of 4 slots (buckets, halo and spans are), so 16-byte accesses never straddle an edge.
+     * int_lo / int_len: the interior in slice coordinates (i - int_lo < int_len, unsigned) */
     struct Geo { uint64_t seg_lo; uint32_t seg, int_lo, int_len; bool down; };
     auto geo = [&](uint32_t b) {
         Geo g;
@@ -397,218 +410,84 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         g.int_len = sh ? 0u : (uint32_t)S - 2u * kHalo;
         return g;
     };
-    /* Software pipeline over the buckets of this workgroup (stride gridDim.x): everything bucket
-     * b+stride needs from HBM — its table slice, the old values of its counters, its fill and its
-     * first group of k-mers — is loaded into registers while bucket b is probed, and later groups
-     * of b while the current group is probed. */
-    const uint32_t stride = gridDim.x;
-    u32x4 kv[kKeySteps];
-    u32x4 ov[kCntSteps];
-    auto fetch_slice = [&](uint32_t b) {
-        if (b >= n_buckets) return;
-        const Geo g = geo(b);
-        const u32x4 *kp = reinterpret_cast<const u32x4 *>(tv.keys + (g.seg_lo - tv.span_lo));
-#pragma unroll
-        for (int st = 0; st < kKeySteps; st++) {
-            const uint32_t i2 = tid + st * kCountThreads;
-            kv[st] = 2 * i2 < g.seg ? kp[i2] : u32x4{0, 0, 0, 0};
-        }
-        if constexpr (PIPE) {
-            const u32x4 *cp4 = reinterpret_cast<const u32x4 *>(tv.counters + (g.seg_lo - tv.span_lo));
-#pragma unroll
-            for (int st = 0; st < kCntSteps; st++) {
-                const uint32_t i4 = tid + st * kCountThreads;
-                ov[st] = 4 * i4 - g.int_lo < g.int_len ? cp4[i4] : u32x4{0, 0, 0, 0};
-            }
-        }
-    };
     auto fill_of = [&](uint32_t b) {
         uint32_t n = b < n_buckets ? cursors[b] : 0;
         return n > cap ? cap : n;
     };
-    /* 16 bytes = k-mers e, e+1 of the bucket at `src` (cap is a multiple of 64: 16-byte aligned) */
-    u32x4 nq[G2];
-    auto load_group = [&](const uint64_t *src, uint32_t first, uint32_t n_src) {
-#pragma unroll
-        for (int q = 0; q < G2; q++) {
-            const uint32_t e = first + 2u * (q * kCountThreads + tid);
-            nq[q] = e < n_src ? *reinterpret_cast<const u32x4 *>(src + e) : u32x4{~0u, ~0u, ~0u, ~0u};
-        }
-    };
-    uint32_t n_next = 0, n_after = 0;
-    fetch_slice(blockIdx.x);
-    if constexpr (PIPE) {
-        n_next = fill_of(blockIdx.x);                         /* fill of the bucket about to start */
-        load_group(kmers + (uint64_t)blockIdx.x * cap, 0, n_next);
-        n_after = fill_of(blockIdx.x + stride);               /* ... and of the one after it */
-    }
 
-    for (uint32_t b = blockIdx.x; b < n_buckets; b += stride) {
-        const uint32_t n = PIPE ? n_next : fill_of(b);
-        const Geo g = geo(b);
-        const uint64_t seg_lo = g.seg_lo;
-        const uint32_t seg = g.seg;
-        const bool down = g.down;
-        const uint32_t int_lo = g.int_lo, int_len = g.int_len;
-        /* LDS position of slice index i: mirrored for the upper half, so every walk goes up in LDS */
-        auto mir = [&](uint32_t i) { return down ? seg - 1u - i : i; };
-        /* position of home slot h: (h ^ xm) + ad  (up: h - seg_lo; down: seg_lo + seg - 1 - h) */
-        const uint32_t xm = down ? ~0u : 0u;
-        const uint32_t ad = down ? (uint32_t)(seg_lo + seg) : (uint32_t)(0u - (uint32_t)seg_lo);
-        uint32_t *const cp = tv.counters + (seg_lo - tv.span_lo);
-        QM2_STAMP(0);
-#ifdef QM2_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        QM2_STAMP(1);                      /* waiting for the prefetched slice (stamp builds only) */
-#endif
-        /* stage: keys, fingerprints, and the counter tile — which starts from the old values of the
-         * interior (0 elsewhere), so the LDS atomics accumulate straight onto them */
+    if (wave < kLoaderWaves) {
+        /* ============================ LOADERS ============================ */
+        __builtin_amdgcn_s_setprio(2);
+        constexpr int kKeySteps = (kSeg / 2 + 8 + kLoaderThreads - 1) / kLoaderThreads;   /* 2 keys per lane and step (+ the 0xFF pad) */
+        constexpr int kCntSteps = (kSeg / 4 + kLoaderThreads - 1) / kLoaderThreads;       /* 4 counters per lane and step */
+        u32x4 kv[kKeySteps];
+        u32x4 ov[kCntSteps];
+        auto fetch = [&](uint32_t b) {
+            if (b >= n_buckets) return;
+            const Geo g = geo(b);
+            const u32x4 *kp = reinterpret_cast<const u32x4 *>(tv.keys + (g.seg_lo - tv.span_lo));
 #pragma unroll
-        for (int st = 0; st < kKeySteps; st++) {
-            const uint32_t i = 2u * (tid + st * kCountThreads);
-            if (i < (uint32_t)kSeg + 16u) {
-                const uint64_t k0 = ((uint64_t)kv[st].y << 32) | kv[st].x, k1 = ((uint64_t)kv[st].w << 32) | kv[st].z;
-                if (i < seg) {
-                    const uint32_t m0 = mir(i), m1 = mir(i + 1);
-                    skey[m0] = k0; skey[m1] = k1;
-                    sfpb[m0] = (uint8_t)fp8(k0); sfpb[m1] = (uint8_t)fp8(k1);
-                } else {
-                    sfpb[i] = 0xFF; sfpb[i + 1] = 0xFF;         /* beyond the slice (positions, not mirrored) */
-                }
+            for (int st = 0; st < kKeySteps; st++) {
+                const uint32_t i2 = tid + st * kLoaderThreads;
+                kv[st] = 2 * i2 < g.seg ? kp[i2] : u32x4{0, 0, 0, 0};
             }
-        }
-#pragma unroll
-        for (int st = 0; st < kCntSteps; st++) {
-            const uint32_t i = 4u * (tid + st * kCountThreads);
-            if (i < seg) {
-                const u32x4 o = PIPE ? ov[st] : u32x4{0, 0, 0, 0};
-                scnt[mir(i)] = o.x; scnt[mir(i + 1)] = o.y; scnt[mir(i + 2)] = o.z; scnt[mir(i + 3)] = o.w;
-            }
-        }
-        QM2_STAMP(2);                      /* staging the slice in LDS */
-        lds_barrier();
-        QM2_STAMP(3);                      /* barrier after staging */
-        const uint32_t bn = b + stride;
-        fetch_slice(bn);
-        if constexpr (PIPE) {
-            n_next = n_after;
-            n_after = fill_of(bn + stride);
-        }
-        QM2_STAMP(9);                      /* issuing the next slice's loads */
-
-        /* continue a walk at staged position p (may be beyond the slice: then, and when it leaves the
-         * slice later, it finishes in global memory like the direct kernel) */
-        auto walk = [&](uint64_t km, uint32_t p, uint32_t seen) {
-            for (;;) {
-                if (p >= seg) {
-                    uint64_t slot = down ? seg_lo + seg - 1u - (uint64_t)p : seg_lo + p;
-                    for (;;) {
-                        const uint64_t gk = tv.keys[slot - tv.span_lo];
-                        seen++;
-                        if (gk == km) { atomicAdd(&tv.counters[slot - tv.span_lo], 1u); n_hits++; break; }
-                        if (gk == 0) break;
-                        slot += down ? (uint64_t)-1 : 1;
-                    }
-                    break;
-                }
-                const uint64_t v = skey[p];
-                seen++;
-                if (v == km) { atomicAdd(&scnt[p], 1u); n_hits++; break; }   /* :98, :291 */
-                if (v == 0) break;
-                p++;                                                        /* :97 */
-            }
-            n_probes += seen;
-        };
-
-        const uint64_t *in = kmers + (uint64_t)b * cap;
-        const uint64_t *in_next = kmers + (uint64_t)bn * cap;
-        if constexpr (!PIPE) load_group(in, 0, n);
-        uint32_t queued = 0;                                                /* wave-uniform */
-        /* ---- phase A: one k-mer, four slots, no loop ---- */
-        auto probe1 = [&](uint64_t km, bool live) {
-            const uint32_t h = djb32(km) & tv.hmask;                        /* :92 */
-            const uint32_t p = live ? (h ^ xm) + ad : 0u;
-            const uint32_t d0 = sfp[p >> 2], d1 = sfp[(p >> 2) + 1];
-            const uint32_t w = __builtin_amdgcn_alignbyte(d1, d0, p & 3u);  /* fingerprints of p .. p+3 */
-            const uint32_t x = w ^ (fp8(km) * 0x01010101u);
-            /* lowest flagged byte is exact (a borrow only ever flags bytes ABOVE a zero byte) */
-            const uint32_t zm = (x - 0x01010101u) & ~x & 0x80808080u;       /* fingerprint matches */
-            const uint32_t ze = (w - 0x01010101u) & ~w & 0x80808080u;       /* empty slots         */
-            const uint32_t lm = (uint32_t)__ffs((int)zm) - 1u, le = (uint32_t)__ffs((int)ze) - 1u;   /* 0xFFFFFFFF: none */
-            const bool cand = lm <= le && lm < 32u;                         /* a match at or before the first empty slot */
-            const bool miss = !cand && le < 32u;                            /* an empty slot first: not in the dictionary */
-            const uint32_t c = cand ? lm >> 3 : 0u;
-            const uint64_t v = skey[p + c];
-            const bool hit = live && cand && v == km;                       /* :98 (k-mer 0: the empty slot itself) */
-            if (hit) atomicAdd(&scnt[p + c], 1u);                           /* :291 */
-            n_hits += hit ? 1u : 0u;
-            n_probes += !live ? 0u : hit ? c + 1u : miss ? (le >> 3) + 1u : 0u;   /* unresolved: walk() adds the total */
-            const bool more = live && !hit && !miss;     /* nothing decisive in 4 slots, or a false fingerprint match */
-            const unsigned long long m = __ballot(more);
-            if (m) {
-                const uint32_t slot = queued + __popcll(m & ((1ull << lane) - 1));
-                const uint32_t seen = cand ? c + 1u : 4u;                   /* slots the reference walk has passed */
-                if (more) {
-                    if (slot < (uint32_t)kQueueCap) {
-                        qk[wave][slot] = km;
-                        qa[wave][slot] = (uint16_t)((p + seen) | ((seen - 1u) << 13));
-                    } else {
-                        walk(km, p + seen, seen);                           /* queue full: finish in place */
-                    }
-                }
-                queued += __popcll(m);
-            }
-        };
-        uint32_t base = 0;
-        /* PIPE runs the body once even for an empty bucket: it carries the next bucket's prefetch */
-        while (PIPE ? (base == 0 || base < n) : base < n) {
-            u32x4 kq[G2];
-#pragma unroll
-            for (int q = 0; q < G2; q++) kq[q] = nq[q];
-            /* next group of this bucket, or (PIPE) behind the last one the first of the next bucket */
-            if (PIPE && base + kGroupKmers >= n) load_group(in_next, 0, n_next);   /* workgroup-uniform */
-            else load_group(in, base + kGroupKmers, n);
-            QM2_STAMP(10);                 /* rotating nq -> kq, issuing the next group's loads */
-            /* All G2 rows run as one straight-line block even when the last ones hold no k-mer
-             * (skipping rows was measured slower in round 1): the host picks G2 to fit the fill. */
-#pragma unroll
-            for (int q = 0; q < G2; q++) {
-                const uint32_t e = base + 2u * (q * kCountThreads + tid);
-                probe1(((uint64_t)kq[q].y << 32) | kq[q].x, e < n);
-                probe1(((uint64_t)kq[q].w << 32) | kq[q].z, e + 1u < n);
-            }
-            QM2_STAMP(4);                  /* phase A */
-            base += kGroupKmers;
-        }
-        /* ---- phase B: this wave's unresolved k-mers, dense rows, once per bucket ---- */
-        {
-            const uint32_t qn = queued < (uint32_t)kQueueCap ? queued : (uint32_t)kQueueCap;
-            for (uint32_t e = lane; e < qn; e += kWave) {
-                const uint32_t a = qa[wave][e];
-                walk(qk[wave][e], a & 0x1FFFu, (a >> 13) + 1u);
-            }
-        }
-        QM2_STAMP(5);                      /* phase B */
-        lds_barrier();
-        QM2_STAMP(6);                      /* barrier before the flush */
-        /* flush: the interior of the owned range is touched by this workgroup only, so the tile
-         * (old values, fetched a bucket ago, plus this bucket's counts) is stored back plainly; the
-         * kHalo slots at either end of it and the staged halo can also receive a neighbour's
-         * counts, so there the tile holds deltas and they are added atomically. */
-        if (n) {
+            const u32x4 *cp4 = reinterpret_cast<const u32x4 *>(tv.counters + (g.seg_lo - tv.span_lo));
 #pragma unroll
             for (int st = 0; st < kCntSteps; st++) {
-                const uint32_t i = 4u * (tid + st * kCountThreads);
-                if (i < seg) {
-                    u32x4 cv = {scnt[mir(i)], scnt[mir(i + 1)], scnt[mir(i + 2)], scnt[mir(i + 3)]};
-                    u32x4 *const dst = reinterpret_cast<u32x4 *>(cp + i);
-                    if (i - int_lo < int_len) {
-                        if constexpr (PIPE) *dst = cv;
-                        else if (cv.x | cv.y | cv.z | cv.w) {
-                            /* sparse table: only the sectors that got counts are read and written */
-                            const u32x4 old = *dst;
-                            *dst = old + cv;
-                        }
+                const uint32_t i4 = tid + st * kLoaderThreads;
+                ov[st] = 4 * i4 - g.int_lo < g.int_len ? cp4[i4] : u32x4{0, 0, 0, 0};
+            }
+        };
+        /* registers -> LDS buffer `bf`: keys, fingerprints, counter tile; mirrored when the bucket walks down */
+        auto stage = [&](uint32_t b, int bf) {
+            const Geo g = geo(b);
+            uint8_t *const fpb = reinterpret_cast<uint8_t *>(sfp[bf]);
+#pragma unroll
+            for (int st = 0; st < kKeySteps; st++) {
+                const uint32_t i = 2u * (tid + st * kLoaderThreads);
+                if (i < g.seg) {
+                    const uint64_t k0 = ((uint64_t)kv[st].y << 32) | kv[st].x, k1 = ((uint64_t)kv[st].w << 32) | kv[st].z;
+                    const uint32_t f0 = k0 ? fp8(k0) : 0u, f1 = k1 ? fp8(k1) : 0u;
+                    if (g.down) {
+                        const uint32_t m = g.seg - 2u - i;                 /* slots i+1, i land at m, m+1 */
+                        *reinterpret_cast<u32x4 *>(&skey[bf][m]) = u32x4{kv[st].z, kv[st].w, kv[st].x, kv[st].y};
+                        *reinterpret_cast<uint16_t *>(fpb + m) = (uint16_t)(f1 | (f0 << 8));
+                    } else {
+                        *reinterpret_cast<u32x4 *>(&skey[bf][i]) = kv[st];
+                        *reinterpret_cast<uint16_t *>(fpb + i) = (uint16_t)(f0 | (f1 << 8));
+                    }
+                } else if (i < (uint32_t)kSeg + 16u) {
+                    *reinterpret_cast<uint16_t *>(fpb + i) = (uint16_t)(kFpPad | (kFpPad << 8));   /* beyond the slice (positions, not mirrored) */
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < kCntSteps; st++) {
+                const uint32_t i = 4u * (tid + st * kLoaderThreads);
+                if (i < g.seg) {
+                    const u32x4 o = ov[st];
+                    if (g.down) *reinterpret_cast<u32x4 *>(&scnt[bf][g.seg - 4u - i]) = u32x4{o.w, o.z, o.y, o.x};
+                    else        *reinterpret_cast<u32x4 *>(&scnt[bf][i]) = o;
+                }
+            }
+        };
+        /* counter tile of LDS buffer `bf` -> table */
+        auto flush = [&](uint32_t b, int bf) {
+            if (fill_of(b) == 0) return;                 /* nothing was counted: the tile is what was loaded */
+            const Geo g = geo(b);
+            uint32_t *const cp = tv.counters + (g.seg_lo - tv.span_lo);
+#pragma unroll
+            for (int st = 0; st < kCntSteps; st++) {
+                const uint32_t i = 4u * (tid + st * kLoaderThreads);
+                if (i < g.seg) {
+                    u32x4 cv;
+                    if (g.down) {
+                        const u32x4 r = *reinterpret_cast<const u32x4 *>(&scnt[bf][g.seg - 4u - i]);
+                        cv = u32x4{r.w, r.z, r.y, r.x};
+                    } else {
+                        cv = *reinterpret_cast<const u32x4 *>(&scnt[bf][i]);
+                    }
+                    if (i - g.int_lo < g.int_len) {
+                        *reinterpret_cast<u32x4 *>(cp + i) = cv;
                     } else {
                         if (cv.x) atomicAdd(cp + i, cv.x);
                         if (cv.y) atomicAdd(cp + i + 1, cv.y);
@@ -617,18 +496,275 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                     }
                 }
             }
+        };
+        uint32_t b = blockIdx.x;
+        if (b < n_buckets) { fetch(b); stage(b, 0); }
+        fetch(b + stride);
+        lds_barrier();                                            /* barrier 0: bucket 0 is staged */
+#ifdef QM2_STAMPS
+        unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now();
+#endif
+        uint32_t k = 0;
+        for (; b < n_buckets; b += stride, k++) {
+            if (k) flush(b - stride, (int)((k + 1u) & 1u));       /* bucket k-1: the probers left it at barrier k */
+            QM2_STAMP(0);
+#ifdef QM2_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            QM2_STAMP(10);
+#endif
+            if (b + stride < n_buckets) stage(b + stride, (int)((k + 1u) & 1u));
+            QM2_STAMP(1);
+            fetch(b + 2u * stride);
+            QM2_STAMP(2);
+            lds_barrier();                                        /* barrier k+1 */
+            QM2_STAMP(3);
         }
-        lds_barrier();
-        QM2_STAMP(7);                      /* flush + barrier */
+        if (k) flush(b - stride, (int)((k + 1u) & 1u));
+#ifdef QM2_STAMPS
+        if (lane == 0) {
+            for (int i = 0; i < 4; i++) atomicAdd(&qm2_stamp_acc[i], st_acc[i]);
+            atomicAdd(&qm2_stamp_acc[10], st_acc[10]);
+            atomicAdd(&qm2_stamp_acc[8], 1ull);
+        }
+#endif
+        return;
+    }
+
+    /* ============================ PROBERS ============================ */
+    const int pt = tid - kLoaderThreads, pw = wave - kLoaderWaves;
+    uint32_t n_probes = 0;                  /* per lane: < 2^32 for any batch that fits the plan */
+    uint32_t n_hits = 0;                    /* phase A: per WAVE (scalar popcounts); lane 0 .. 63 add their own walk() hits */
+    uint32_t w_hits_a = 0;
+    constexpr uint32_t kGroupKmers = 2u * G2 * kProberThreads;
+    constexpr int kSet = QM2_COUNT_SET;               /* k-mers probed together in phase A (even) */
+    /* 16 bytes = k-mers e, e+1 of the bucket at `src` (cap is a multiple of 64: 16-byte aligned).
+     * UNCONDITIONAL loads: lanes beyond the fill re-read the bucket's first 16 bytes (a hot line; what
+     * they get is ignored, `live` is decided from e < n at use).  Conditional loads make hipcc wait
+     * with vmcnt(0) at the first use of a k-mer — i.e. for the NEXT group's prefetch as well. */
+    u32x4 nq[G2];
+    auto load_group = [&](const uint64_t *src, uint32_t first, uint32_t n_src) {
+#pragma unroll
+        for (int q = 0; q < G2; q++) {
+            const uint32_t e = first + 2u * (q * kProberThreads + pt);
+            nq[q] = *reinterpret_cast<const u32x4 *>(src + (e < n_src ? e : 0u));
+        }
+    };
+    uint32_t n_next = fill_of(blockIdx.x);                    /* fill of the bucket about to start */
+    if (blockIdx.x < n_buckets) load_group(kmers + (uint64_t)blockIdx.x * cap, 0, n_next);
+    uint32_t n_after = fill_of(blockIdx.x + stride);          /* ... and of the one after it */
+    lds_barrier();                                            /* barrier 0 */
+#ifdef QM2_STAMPS
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now();
+#endif
+
+    uint32_t k = 0;
+    for (uint32_t b = blockIdx.x; b < n_buckets; b += stride, k++) {
+        const uint32_t n = n_next;
+        const Geo g = geo(b);
+        const uint64_t seg_lo = g.seg_lo;
+        const uint32_t seg = g.seg;
+        const bool down = g.down;
+        const int bf = (int)(k & 1u);
+        const uint64_t *const bkey = skey[bf];
+        uint32_t *const bcnt = scnt[bf];
+        const uint32_t *const bfp = sfp[bf];
+        /* LDS position of home slot h: (h ^ xm) + ad  (up: h - seg_lo; down: seg_lo + seg - 1 - h) */
+        const uint32_t xm = down ? ~0u : 0u;
+        const uint32_t ad = down ? (uint32_t)(seg_lo + seg) : (uint32_t)(0u - (uint32_t)seg_lo);
+        const uint32_t bn = b + stride;
+        n_next = n_after;
+        n_after = fill_of(bn + stride);
+        /* (a scalar load in flight makes every LDS wait of the probe code an lgkmcnt(0): drain it here) */
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        /* Decision on the 4 slots from position p on, from their fingerprint word w (slot p in the low
+         * byte).  lm / le: bit index of the first fingerprint match / first empty slot, 0xFFFFFFFF if
+         * none (the LOWEST flagged byte of the borrow trick is exact).
+         *   lm <= le: a candidate at slot c = lm >> 3 — to be verified against the key; this also covers
+         *             "neither" (lm = le = none): c reads as 3, the key there cannot be equal (its
+         *             fingerprint is not), and the walk goes on behind slot 3, as it should;
+         *   lm >  le: an empty slot comes first: not in the dictionary (:96-98) — except for k-mer 0,
+         *             which the reference counts ON that empty slot; k-mer 0 is left to walk().
+         * Slots the reference has inspected by then: min(c, e, 3) + 1. */
+#define QM2_WINDOW(W, KM, LM, LE)                                                            \
+        {                                                                                    \
+            const uint32_t x_ = (W) ^ __builtin_amdgcn_perm(0u, fp8(KM), 0u);                \
+            const uint32_t zm_ = (x_ - 0x01010101u) & ~x_ & 0x80808080u;                     \
+            const uint32_t ze_ = ((W) - 0x01010101u) & ~(W) & 0x80808080u;                   \
+            LM = (uint32_t)__ffs((int)zm_) - 1u;                                             \
+            LE = (uint32_t)__ffs((int)ze_) - 1u;                                             \
+        }
+        /* finish a walk that stands at staged position p; adds the slots it inspects from there on.
+         * Beyond the slice — only behind a run of >= kHalo occupied slots — it goes on in global
+         * memory like the direct kernel. */
+        auto walk = [&](uint64_t km, uint32_t p) {
+            uint32_t seen = 0;
+            for (;;) {
+                if (p + 4u > seg || km == 0) {
+                    for (;;) {
+                        uint64_t v;
+                        uint32_t *ctr;
+                        if (p < seg) { v = bkey[p]; ctr = nullptr; }
+                        else {
+                            const uint64_t slot = (down ? seg_lo + seg - 1u - (uint64_t)p : seg_lo + p) - tv.span_lo;
+                            v = tv.keys[slot];
+                            ctr = tv.counters + slot;
+                        }
+                        seen++;
+                        if (v == km) {                                      /* :98, :291 */
+                            if (ctr) atomicAdd(ctr, 1u); else atomicAdd(&bcnt[p], 1u);
+                            n_hits++;
+                            break;
+                        }
+                        if (v == 0) break;
+                        p++;                                                /* :97 */
+                    }
+                    break;
+                }
+                uint32_t lm, le;
+                const uint32_t w = __builtin_amdgcn_alignbyte(bfp[(p >> 2) + 1], bfp[p >> 2], p);
+                QM2_WINDOW(w, km, lm, le)
+                const uint32_t c = __builtin_amdgcn_ubfe(lm, 3, 2);
+                seen += (min(min(lm, le), 31u) >> 3) + 1u;
+                if (lm > le) break;                                         /* an empty slot first */
+                if (bkey[p + c] == km) { atomicAdd(&bcnt[p + c], 1u); n_hits++; break; }
+                p += c + 1u;
+            }
+            n_probes += seen;
+        };
+
+        const uint64_t *in = kmers + (uint64_t)b * cap;
+        const uint64_t *in_next = kmers + (uint64_t)bn * cap;
+        uint32_t queued = 0;                                                /* wave-uniform */
+        /* ---- phase A: K k-mers at a time, four slots each, no loop and no branch until the queue
+         * pushes: all fingerprint reads are issued before the first is used, then all key reads,
+         * then the compares and the (unconditional: + 0 or + 1) counter adds, so the LDS round trips
+         * of the K k-mers overlap instead of adding up.  Idle lanes (beyond the bucket's fill) hold
+         * a real k-mer of the bucket (load_group) and run along; only their effects are masked. ---- */
+        auto probe_set = [&](const auto &km, const auto &live) {
+            constexpr int K = (int)(sizeof(km) / sizeof(km[0]));
+            uint32_t pp[K], d0[K], d1[K], lm[K], le[K];
+            uint64_t vv[K];
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                pp[j] = ((djb32(km[j]) & tv.hmask) ^ xm) + ad;              /* :92 */
+                d0[j] = bfp[pp[j] >> 2];
+                d1[j] = bfp[(pp[j] >> 2) + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const uint32_t w = __builtin_amdgcn_alignbyte(d1[j], d0[j], pp[j]);   /* fingerprints of p .. p+3 */
+                QM2_WINDOW(w, km[j], lm[j], le[j])
+                vv[j] = bkey[pp[j] + __builtin_amdgcn_ubfe(lm[j], 3, 2)];
+            }
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const uint32_t c = __builtin_amdgcn_ubfe(lm[j], 3, 2);
+                const bool on = live[j] && km[j] != 0;                      /* k-mer 0: everything is left to walk() */
+                const bool cand = lm[j] <= le[j];
+                const bool hit = on && cand && vv[j] == km[j];              /* :98 */
+                atomicAdd(&bcnt[pp[j] + c], hit ? 1u : 0u);                 /* :291 */
+                w_hits_a += __popcll(__ballot(hit));
+                n_probes += on ? (min(min(lm[j], le[j]), 31u) >> 3) + 1u : 0u;
+                /* a false fingerprint match, or nothing decisive in 4 slots: this wave's queue */
+                const bool more = live[j] && (km[j] == 0 || (cand && !hit));
+                const unsigned long long m = __ballot(more);
+                if (m) {
+                    const uint32_t slot = queued + __popcll(m & ((1ull << lane) - 1));
+                    if (more && slot < (uint32_t)kQueueCap) {               /* (beyond the capacity: the redo pass below) */
+                        qk[pw][slot] = km[j];
+                        qa[pw][slot] = (uint16_t)(km[j] ? pp[j] + c + 1u : pp[j]);
+                    }
+                    queued += __popcll(m);
+                }
+            }
+        };
+        uint32_t base = 0;
+        /* runs once even for an empty bucket: it carries the next bucket's prefetch */
+        while (base == 0 || base < n) {
+            u32x4 kq[G2];
+#pragma unroll
+            for (int q = 0; q < G2; q++) kq[q] = nq[q];
+            /* next group of this bucket, or behind the last one the first group of the next bucket */
+            if (base + kGroupKmers >= n) load_group(bn < n_buckets ? in_next : in, 0, n_next);   /* workgroup-uniform */
+            else load_group(in, base + kGroupKmers, n);
+            QM2_STAMP(4);
+            /* All G2 rows run as straight-line blocks even when the last ones hold no k-mer
+             * (skipping rows was measured slower in round 1): the host picks G2 to fit the fill. */
+            auto probe_rows = [&](auto first_c, auto count_c) {
+                constexpr int Q0 = decltype(first_c)::value, R = decltype(count_c)::value;
+                uint64_t km[2 * R];
+                bool live[2 * R];
+#pragma unroll
+                for (int t = 0; t < R; t++) {
+                    const uint32_t e = base + 2u * ((Q0 + t) * kProberThreads + pt);
+                    km[2 * t] = ((uint64_t)kq[Q0 + t].y << 32) | kq[Q0 + t].x;
+                    km[2 * t + 1] = ((uint64_t)kq[Q0 + t].w << 32) | kq[Q0 + t].z;
+                    live[2 * t] = e < n;
+                    live[2 * t + 1] = e + 1u < n;
+                }
+                probe_set(km, live);
+            };
+            constexpr int kR = kSet / 2;               /* 16-byte rows per set */
+#define QM2_SET(I)                                                                                     \
+            if constexpr (G2 > (I) * kR)                                                                   \
+                probe_rows(std::integral_constant<int, (I) * kR>{},                                        \
+                           std::integral_constant<int, (G2 - (I) * kR < kR ? G2 - (I) * kR : kR)>{});
+            QM2_SET(0) QM2_SET(1) QM2_SET(2) QM2_SET(3) QM2_SET(4) QM2_SET(5)
+#undef QM2_SET
+            static_assert(G2 <= 6 * kR, "at most six sets per group");
+            QM2_STAMP(5);
+            base += kGroupKmers;
+        }
+        /* ---- phase B: this wave's unresolved k-mers, dense rows, once per bucket ---- */
+        {
+            const uint32_t qn = queued < (uint32_t)kQueueCap ? queued : (uint32_t)kQueueCap;
+            for (uint32_t e = lane; e < qn; e += kWave) walk(qk[pw][e], qa[pw][e]);
+        }
+        /* More unresolved k-mers than the queue holds (skewed input: many copies of a k-mer that sits
+         * far from its home slot): go over this wave's k-mers of the bucket again, in the same order,
+         * repeat phase A's decision WITHOUT its side effects, and finish in place those that would have
+         * got a queue slot beyond the capacity.  Rare, exact, and keeps every walk out of phase A. */
+        if (queued > (uint32_t)kQueueCap) {
+            uint32_t q2 = 0;
+#pragma unroll 1
+            for (uint32_t base2 = 0; base2 < n; base2 += kGroupKmers) {
+#pragma unroll 1
+                for (uint32_t q = 0; q < 2u * G2; q++) {
+                    const uint32_t e = base2 + 2u * ((q >> 1) * kProberThreads + pt) + (q & 1u);
+                    const bool live = e < n;
+                    const uint64_t km = live ? in[e] : 0;
+                    uint32_t at = 0;
+                    bool more = false;
+                    if (live) {
+                        const uint32_t p = ((djb32(km) & tv.hmask) ^ xm) + ad;
+                        uint32_t lm, le;
+                        const uint32_t w = __builtin_amdgcn_alignbyte(bfp[(p >> 2) + 1], bfp[p >> 2], p);
+                        QM2_WINDOW(w, km, lm, le)
+                        const uint32_t c = __builtin_amdgcn_ubfe(lm, 3, 2);
+                        more = km == 0 || (lm <= le && bkey[p + c] != km);
+                        at = km ? p + c + 1u : p;
+                    }
+                    const unsigned long long m = __ballot(more);           /* every lane: the same count as phase A's */
+                    const uint32_t slot = q2 + __popcll(m & ((1ull << lane) - 1));
+                    if (more && slot >= (uint32_t)kQueueCap) walk(km, at);
+                    q2 += __popcll(m);
+                }
+            }
+        }
+#undef QM2_WINDOW
+        QM2_STAMP(6);
+        lds_barrier();                                                      /* barrier k+1 */
+        QM2_STAMP(7);
     }
 #ifdef QM2_STAMPS
     if (lane == 0) {
-        for (int i = 0; i < 8; i++) atomicAdd(&qm2_stamp_acc[i], st_acc[i]);
-        for (int i = 9; i < 12; i++) atomicAdd(&qm2_stamp_acc[i], st_acc[i]);
-        atomicAdd(&qm2_stamp_acc[8], 1ull);
+        for (int i = 4; i < 8; i++) atomicAdd(&qm2_stamp_acc[i], st_acc[i]);
+        atomicAdd(&qm2_stamp_acc[9], 1ull);
     }
 #endif
-    const unsigned long long w_probes = wave_sum((unsigned long long)n_probes), w_hits = wave_sum((unsigned long long)n_hits);
+    const unsigned long long w_probes = wave_sum((unsigned long long)n_probes),
+                             w_hits = wave_sum((unsigned long long)n_hits) + w_hits_a;
     if (lane == 0) {
         atomicAdd(&stats->n_probes, w_probes);
         atomicAdd(&stats->n_hits, w_hits);
