@@ -22,6 +22,7 @@
  *     counter increment, :291 / :443
  *   drain + join, :458-479                              qm2_finish
  *   "total %lu kmers" bookkeeping, :445, :481           qm2_stats
+ *   progress line every 2^30 k-mers, :446               qm2_stats_peek
  *   chain read + walk -> depth in genome order, :483-516  qm2_chain_gather(_fd) / qm2_chain_fetch
  *   free, :519-520                                      qm2_close
  *
@@ -50,7 +51,7 @@
 extern "C" {
 #endif
 
-#define QM2_ABI_VERSION 1
+#define QM2_ABI_VERSION 2
 
 typedef struct qm2_ctx qm2_ctx;
 
@@ -127,6 +128,9 @@ typedef struct {
     uint64_t fallback_batches; /* partitioned batches whose spill list overflowed: recounted by the
                                   direct kernel (decided on the device; read at qm2_get_profile,
                                   which therefore waits for the work submitted so far) */
+    uint64_t allocations;      /* device / pinned-host allocations the counting pipeline made since
+                                  qm2_open or the last qm2_reset (0 between the first submit and
+                                  qm2_finish once qm2_prepare has run)                          */
 } qm2_profile;
 
 /* Create a counting context for a dictionary of `hash_size` slots (power of
@@ -172,6 +176,21 @@ int qm2_sync(qm2_ctx *c);
  * exact) into depth_out (may be NULL) and the totals into st (may be NULL).
  * The context stays usable; counts keep accumulating until qm2_reset. */
 int qm2_finish(qm2_ctx *c, uint16_t *depth_out, qm2_stats *st);
+
+/* The totals as of the last batch whose kernels have finished — never blocks, may lag the stream
+ * (the snapshot is copied out by the stream itself behind every batch).  The CLI prints the
+ * reference's progress line `Read %liG kmers` (QuicKmer.c:446) from it, at batch granularity. */
+int qm2_stats_peek(qm2_ctx *c, qm2_stats *st);
+
+/* Allocate ahead of time what the counting phase needs for device batches of `batch_bytes` (0 = the
+ * context's batch size): QM2_PREPARE_HOST the pinned staging buffers and the two device batches of
+ * the qm2_submit / qm2_staging_* pipeline, QM2_PREPARE_RAW the scratch of the device line discipline;
+ * always the partition buffers and (once the key table is there) the one-off look at its runs of
+ * occupied slots.  Optional: without it all of that happens inside the first batches (the reference
+ * does its allocations up front too, QuicKmer.c:353-384). */
+#define QM2_PREPARE_HOST 1u
+#define QM2_PREPARE_RAW  2u
+int qm2_prepare(qm2_ctx *c, uint64_t batch_bytes, uint32_t what);
 
 /* Zero counters and statistics (a fresh calloc, :360). */
 int qm2_reset(qm2_ctx *c);

@@ -19,11 +19,35 @@ static void help_count(void)
     puts("-t [num]\tNumber of threads");
 }
 
+/* The reference prints `Read %liG kmers` whenever its k-mer count reaches a multiple of 2^30 (:446).
+ * Here the count advances a device batch at a time: every multiple crossed since the last look is
+ * printed (same lines, same order, in front of "Counting elapse"), from the backend's non-blocking
+ * snapshot while the stream runs and from the final totals at the end. */
+static uint64_t progress_printed_g;
+static void progress_upto(uint64_t n_kmers)
+{
+    while (progress_printed_g < (n_kmers >> 30)) printf("Read %liG kmers\n", (long)++progress_printed_g);
+}
+static void progress_peek(qm2_ctx *ctx)
+{
+    qm2_stats st;
+    if (qm2_stats_peek(ctx, &st) == 0) progress_upto(st.n_kmers);
+}
+
 static int out_acquire(void *user, char **buf, size_t *cap) { return qm2_staging_acquire((qm2_ctx *)user, buf, cap); }
-static int out_commit(void *user, char *buf, size_t n) { return qm2_staging_commit((qm2_ctx *)user, buf, n); }
-static int out_submit(void *user, const char *lines, size_t n) { return qm2_submit((qm2_ctx *)user, lines, n); }
+static int out_commit(void *user, char *buf, size_t n)
+{
+    progress_peek((qm2_ctx *)user);
+    return qm2_staging_commit((qm2_ctx *)user, buf, n);
+}
+static int out_submit(void *user, const char *lines, size_t n)
+{
+    progress_peek((qm2_ctx *)user);
+    return qm2_submit((qm2_ctx *)user, lines, n);
+}
 static int out_commit_raw(void *user, char *buf, size_t offset, size_t n, int fastq, unsigned skip)
 {
+    progress_peek((qm2_ctx *)user);
     if (qm2_staging_commit_raw((qm2_ctx *)user, buf, offset, n, (uint32_t)fastq, skip)) return 1;
     return qm2_raw_verdict((qm2_ctx *)user) ? 2 : 0;       /* refused: no point in reading on */
 }
@@ -78,11 +102,23 @@ int qm2_main_count(int argc, char **argv)
     o.flags = QM2_FLAG_KEYS_LATER;
     o.n_staging = (uint32_t)n_strip + 3;
     clock_gettime(CLOCK_MONOTONIC, &ta);
+    const char *raw_env = getenv("QM2_READER_RAW");
+    const int want_raw = !(raw_env && strcmp(raw_env, "0") == 0);
     if (qm2_open(&ctx, NULL, d.hash_size, d.k, &o)) { qm2_dict_close(&d); return 1; }
+    /* every buffer of the counting phase is allocated here, like the reference's mallocs and thread start-up
+     * ahead of its timed loop (:353-384): nothing but copies and kernels between the first block and the drain */
+    if (qm2_prepare(ctx, 0, QM2_PREPARE_HOST | (want_raw ? QM2_PREPARE_RAW : 0u))) { qm2_close(ctx); qm2_dict_close(&d); return 1; }
     if (qm2_dict_load_keys(&d, ctx)) { qm2_close(ctx); qm2_dict_close(&d); return 1; }
     clock_gettime(CLOCK_MONOTONIC, &tb);
     if (timing) printf("QM2 phase load-dictionary %.3f s (file -> device)\n", (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec));
 
+    uint64_t allocs_before = 0;
+    if (timing) {
+        qm2_profile pr;
+        memset(&pr, 0, sizeof pr);
+        (void)qm2_get_profile(ctx, &pr);
+        allocs_before = pr.allocations;
+    }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);                      /* :386-387 */
     /* Regular files are not stripped on the host: the workers only pread and the device does the line
@@ -91,8 +127,7 @@ int qm2_main_count(int argc, char **argv)
      * absurd amounts of those are refused (known at the end of the device batch that holds them):
      * the whole input then goes through the host path again, from zeroed counters — exact either
      * way, nothing extra on stdout.  QM2_READER_RAW=0 goes straight to the host path. */
-    const char *raw_env = getenv("QM2_READER_RAW");
-    const int want_raw = !(raw_env && strcmp(raw_env, "0") == 0);
+    progress_printed_g = 0;
     qm2_lines_out out = {out_acquire, out_commit, out_submit, ctx, want_raw ? out_commit_raw : NULL};
     int rc = qm2_stream_reads(reads, &out, n_strip);
     qm2_stats st;
@@ -101,6 +136,7 @@ int qm2_main_count(int argc, char **argv)
     if (want_raw && (rc == 2 || (rc == 0 && qm2_raw_verdict(ctx) != 0))) {
         if (timing) printf("QM2 raw input refused (verdict %u): host line discipline\n", qm2_raw_verdict(ctx));
         out.commit_raw = NULL;
+        /* (progress lines already printed stay printed: the host pass prints only what lies beyond them) */
         rc = qm2_reset(ctx);
         if (!rc) rc = qm2_stream_reads(reads, &out, n_strip);
         memset(&st, 0, sizeof st);
@@ -108,11 +144,19 @@ int qm2_main_count(int argc, char **argv)
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (rc) { qm2_close(ctx); qm2_dict_close(&d); return 1; }
+    progress_upto(st.n_kmers);
     printf("Counting elapse %u sec, total %lu kmers\n",       /* :481 */
            (unsigned)(t1.tv_sec - t0.tv_sec), (unsigned long)st.n_kmers);
 
-    if (timing) printf("QM2 phase count %.3f s (%.2f G bases/s)\n", (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec),
-                       st.n_bases / ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / 1e9);
+    if (timing) {
+        qm2_profile pr;
+        memset(&pr, 0, sizeof pr);
+        (void)qm2_get_profile(ctx, &pr);
+        printf("QM2 phase count %.3f s (%.2f G bases/s); allocations inside it: %llu\n",
+               (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec),
+               st.n_bases / ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / 1e9,
+               (unsigned long long)(pr.allocations - allocs_before));
+    }
     clock_gettime(CLOCK_MONOTONIC, &ta);
     rc = qm2_write_outputs(&d, ctx, ref_prefix, out_prefix);
     clock_gettime(CLOCK_MONOTONIC, &tb);

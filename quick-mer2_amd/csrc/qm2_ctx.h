@@ -31,6 +31,7 @@ struct Batch {                              /* one device batch being filled by 
     uint64_t   *dev_wraps = nullptr;
     size_t      wraps_cap = 0;
     hipEvent_t  done = nullptr;             /* its kernels have finished */
+    hipEvent_t  copied = nullptr;           /* its staged copies have landed (the kernels wait for it) */
     bool        busy = false;
     bool        raw = false;                /* holds raw FASTA/FASTQ text (qm2_staging_commit_raw) ... */
     uint32_t    raw_fastq = 0, raw_skip = 0;/* ... in this line state at dev[0] */
@@ -87,7 +88,8 @@ struct qm2_ctx {
     qm2::DevStats *stats_peek = nullptr;
     hipEvent_t  peek_evt = nullptr;
     bool        peek_pending = false;
-    uint64_t    peek_bytes = 0, bytes_launched = 0;
+    uint64_t    peek_bytes = 0, peek_bytes_pending = 0, bytes_launched = 0;
+    qm2::DevStats peek = {};                /* latest snapshot that has landed (qm2_stats_peek) */
     double      kmers_per_byte = 1.0;
     hipStream_t stream = nullptr;           /* every kernel of this context runs here, in order */
     bool        own_stream = false;

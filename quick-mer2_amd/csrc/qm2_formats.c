@@ -126,7 +126,9 @@ int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, co
                         const uint16_t v = out[i];
                         sum[b] += v;
                         cnt[b]++;
-                        sumsq[b] += (int)v * (int)v;
+                        /* the reference squares a promoted uint16 in `int` (:507): above 46340 that overflows, and
+                         * what its build does is wrap; pinned here without the undefined behaviour */
+                        sumsq[b] += (double)(int32_t)((uint32_t)v * (uint32_t)v);
                     }
                 }
             }

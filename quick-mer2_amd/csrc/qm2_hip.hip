@@ -54,7 +54,7 @@ constexpr size_t kDevPad = 64;
 #define QM2_LG_S 12
 #endif
 #ifndef QM2_COUNT_GRID_MULT
-#define QM2_COUNT_GRID_MULT 4        /* bucket_count workgroups = 1 per CU (what is resident) x this */
+#define QM2_COUNT_GRID_MULT 1        /* bucket_count workgroups = 1 per CU (what is resident) x this; 1 / 4 / 8: 22.6 / 22.9 / 23.0 ms */
 #endif
 constexpr int    kLgS = QM2_LG_S;          /* finest bucket = 2^kLgS table slots: 12 B of LDS per slot */
 }  // namespace
@@ -201,7 +201,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     p.spill_cap = want / 4 + 4096;                                     /* 2 B of HBM per input byte */
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++)
-        if (p.buf_slots[i]) e = hipMalloc((void **)&p.buf[i], p.buf_slots[i] * sizeof(uint64_t));
+        if (p.buf_slots[i]) { e = hipMalloc((void **)&p.buf[i], p.buf_slots[i] * sizeof(uint64_t)); c->prof.allocations++; }
     if (e == hipSuccess) e = hipMalloc((void **)&p.cursors, p.n_cursors * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p.spill, p.spill_cap * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p.spill_count, sizeof(unsigned long long));
@@ -218,6 +218,8 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
 }
 
 /* ---- launching one batch ----------------------------------------------------- */
+
+static void stats_peek_harvest(qm2_ctx *c);
 
 static SeqView seq_view(const uint8_t *data, size_t n, size_t carry, const uint64_t *d_sup, uint64_t n_sup)
 {
@@ -295,10 +297,7 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
         /* the group size (16-byte k-mer loads per prober thread) is picked so that a bucket's fill (mean
          * + 3 sigma of uniform hashing; k-mers per byte measured on earlier batches through an asynchronous
          * copy of the stats block) wastes the fewest rows */
-        if (c->peek_pending && hipEventQuery(c->peek_evt) == hipSuccess) {
-            c->peek_pending = false;
-            if (c->peek_bytes) c->kmers_per_byte = std::min(1.0, (double)c->stats_peek->n_kmers / (double)c->peek_bytes);
-        }
+        stats_peek_harvest(c);
         const uint64_t per_bucket = (uint64_t)((double)sv.n_total * c->kmers_per_byte) / n_buckets;
         int g = 4;
         {
@@ -339,12 +338,6 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
     /* exact fallback, decided on the device: only if even the spill list overflowed */
     if (launch_direct(c, sv, &c->stats->part_lost, false, true)) return 1;
     hipLaunchKernelGGL(part_end_kernel, dim3(1), dim3(64), 0, s, c->stats);
-    if (!c->peek_pending && c->stats_peek) {
-        HIP_OK(hipMemcpyAsync(c->stats_peek, c->stats, sizeof(DevStats), hipMemcpyDeviceToHost, s));
-        HIP_OK(hipEventRecord(c->peek_evt, s));
-        c->peek_pending = true;
-        c->peek_bytes = c->bytes_launched;
-    }
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -363,23 +356,53 @@ static int runs_fit(qm2_ctx *c, bool *ok)
         const size_t words = (size_t)((n_buckets + 31) / 32);
         unsigned int *d_found = nullptr, found = 0;
         uint32_t *d_shared = nullptr;
-        HIP_OK(hipMalloc((void **)&d_found, sizeof(unsigned int)));
-        HIP_OK(hipMalloc((void **)&d_shared, words * sizeof(uint32_t)));
-        HIP_OK(hipMemsetAsync(d_found, 0, sizeof(unsigned int), c->stream));
-        HIP_OK(hipMemsetAsync(d_shared, 0, words * sizeof(uint32_t), c->stream));
-        const int grid = (int)std::min<uint64_t>((c->H + 255) / 256, (uint64_t)c->n_cu * 64);
-        hipLaunchKernelGGL(long_run_kernel, dim3(grid), dim3(256), 0, c->stream, c->keys, c->H, (uint32_t)kHalo,
-                           (uint32_t)kLgS, d_shared, d_found);
-        HIP_OK(hipGetLastError());
-        HIP_OK(hipMemcpyAsync(&found, d_found, sizeof found, hipMemcpyDeviceToHost, c->stream));
-        HIP_OK(hipStreamSynchronize(c->stream));
-        HIP_OK(hipFree(d_found));
+        hipError_t e = hipMalloc((void **)&d_found, sizeof(unsigned int));
+        c->prof.allocations++;
+        if (e == hipSuccess) e = hipMalloc((void **)&d_shared, words * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(d_found, 0, sizeof(unsigned int), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_shared, 0, words * sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) {
+            const int grid = (int)std::min<uint64_t>((c->H + 255) / 256, (uint64_t)c->n_cu * 64);
+            hipLaunchKernelGGL(long_run_kernel, dim3(grid), dim3(256), 0, c->stream, c->keys, c->H, (uint32_t)kHalo,
+                               (uint32_t)kLgS, d_shared, d_found);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&found, d_found, sizeof found, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (d_found) (void)hipFree(d_found);
+        if (e != hipSuccess) {
+            if (d_shared) (void)hipFree(d_shared);
+            return fail("qm2: looking for long runs of occupied slots failed: %s", hipGetErrorString(e));
+        }
         p.runs = (found & 2u) ? 3 : (found & 1u) ? 2 : 1;
         if (p.runs == 2) p.shared = d_shared;
-        else HIP_OK(hipFree(d_shared));
+        else (void)hipFree(d_shared);
     }
     *ok = p.runs != 3;
     return 0;
+}
+
+/* Snapshot of the statistics behind the batch just launched, copied to pinned memory by the
+ * stream itself: qm2_stats_peek and the group-size choice of the next batches read it once it
+ * has landed, nobody waits for it. */
+static int stats_peek_async(qm2_ctx *c)
+{
+    if (c->peek_pending || !c->stats_peek) return 0;
+    HIP_OK(hipMemcpyAsync(c->stats_peek, c->stats, sizeof(DevStats), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipEventRecord(c->peek_evt, c->stream));
+    c->peek_pending = true;
+    c->peek_bytes_pending = c->bytes_launched;
+    return 0;
+}
+
+static void stats_peek_harvest(qm2_ctx *c)
+{
+    if (c->peek_pending && hipEventQuery(c->peek_evt) == hipSuccess) {
+        c->peek_pending = false;
+        c->peek = *c->stats_peek;
+        c->peek_bytes = c->peek_bytes_pending;
+        if (c->peek_bytes) c->kmers_per_byte = std::min(1.0, (double)c->peek.n_kmers / (double)c->peek_bytes);
+    }
 }
 
 static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry, const uint64_t *d_sup,
@@ -403,10 +426,12 @@ static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry,
     if (part && part_reserve(c, n)) part = false;                    /* no memory: direct */
     if (part) {
         c->prof.partitioned_batches++;
-        return launch_partitioned(c, sv);
+        if (launch_partitioned(c, sv)) return 1;
+    } else {
+        c->prof.direct_batches++;
+        if (launch_direct(c, sv, nullptr, true, true)) return 1;
     }
-    c->prof.direct_batches++;
-    return launch_direct(c, sv, nullptr, true, true);
+    return stats_peek_async(c);
 }
 
 /* ---- open / close ---------------------------------------------------------- */
@@ -429,6 +454,8 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
     if (k < 1 || k > 31)
         return fail("qm2_open: k-mer size %u unsupported (1..31; k=32 is undefined in the reference)", k);
     if (!keys && !o.ext_keys && !(o.flags & QM2_FLAG_KEYS_LATER)) return fail("qm2_open: no keys given");
+    if (((uintptr_t)o.ext_keys | (uintptr_t)o.ext_counters) & 15u)
+        return fail("qm2_open: ext_keys / ext_counters must be 16-byte aligned");
     if ((o.flags & QM2_FLAG_DIRECT) && (o.flags & QM2_FLAG_PARTITION))
         return fail("qm2_open: QM2_FLAG_DIRECT and QM2_FLAG_PARTITION exclude each other");
 
@@ -520,7 +547,10 @@ extern "C" void qm2_close(qm2_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
+    /* only this context's own work: a device-wide synchronize would stall the other contexts of a
+     * multi-context process (replicas, shards) */
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &s : c->slots) {
         if (s.host) (void)hipHostFree(s.host);
         if (s.done) (void)hipEventDestroy(s.done);
@@ -529,6 +559,7 @@ extern "C" void qm2_close(qm2_ctx *c)
         if (b.dev) (void)hipFree(b.dev);
         if (b.dev_wraps) (void)hipFree(b.dev_wraps);
         if (b.done) (void)hipEventDestroy(b.done);
+        if (b.copied) (void)hipEventDestroy(b.copied);
     }
     for (auto &t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto &t : c->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -561,6 +592,8 @@ static int batch_ready(qm2_ctx *c, Batch &b)
     if (!b.dev) {
         HIP_OK(hipMalloc((void **)&b.dev, c->batch_bytes + kCarry + kDevPad));
         HIP_OK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
+        c->prof.allocations++;
     }
     if (b.busy) {
         HIP_OK(hipEventSynchronize(b.done));
@@ -571,6 +604,7 @@ static int batch_ready(qm2_ctx *c, Batch &b)
 
 static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
                                   uint32_t *verdict, bool continues);
+static int raw_reserve(qm2_ctx *c, size_t n);
 
 /* Launch the kernels for the batch being filled and switch to the other one. */
 static int batch_flush(qm2_ctx *c)
@@ -578,11 +612,8 @@ static int batch_flush(qm2_ctx *c)
     Batch &b = c->batch[c->cur];
     if (b.fill <= b.carry) { b.fill = b.carry = 0; b.wraps.clear(); return 0; }
     /* the kernels must see every staged copy of this batch */
-    hipEvent_t copied;
-    HIP_OK(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
-    HIP_OK(hipEventRecord(copied, c->copy_stream));
-    HIP_OK(hipStreamWaitEvent(c->stream, copied, 0));
-    HIP_OK(hipEventDestroy(copied));
+    HIP_OK(hipEventRecord(b.copied, c->copy_stream));
+    HIP_OK(hipStreamWaitEvent(c->stream, b.copied, 0));
     if (b.raw) {                              /* raw text: line discipline on the device, then the count */
         uint32_t verdict = 0;
         if (raw_classify_and_count(c, b.dev, b.fill, b.raw_fastq, b.raw_skip, &verdict, true)) return 1;
@@ -601,6 +632,7 @@ static int batch_flush(qm2_ctx *c)
             if (b.dev_wraps) HIP_OK(hipFree(b.dev_wraps));
             b.wraps_cap = std::max<size_t>(n_sup, 1024);
             HIP_OK(hipMalloc((void **)&b.dev_wraps, b.wraps_cap * sizeof(uint64_t)));
+            c->prof.allocations++;
         }
         HIP_OK(hipMemcpy(b.dev_wraps, b.wraps.data(), n_sup * sizeof(uint64_t), hipMemcpyHostToDevice));
         d_sup = b.dev_wraps;
@@ -618,6 +650,7 @@ int qm2_slot_ready(qm2_ctx *c, Slot &s)
 {
     if (!s.host) {
         HIP_OK(hipHostMalloc((void **)&s.host, c->staging_bytes, hipHostMallocDefault));
+        c->prof.allocations++;
         HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
     if (s.busy) {
@@ -751,8 +784,8 @@ extern "C" int qm2_submit_device(qm2_ctx *c, const void *d_seq, size_t n, const 
 
 /* classify the n raw bytes at d_raw (device, 16-byte aligned) and, unless refused, count them.
  * continues: the block follows the previous raw block of this context in the same text (staged input) */
-static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
-                                  uint32_t *verdict, bool continues)
+/* scratch of the device line discipline for blocks of up to n raw bytes */
+static int raw_reserve(qm2_ctx *c, size_t n)
 {
     hipStream_t s = c->stream;
     const uint64_t n_tiles = (n + kRawTile - 1) / kRawTile;
@@ -762,6 +795,7 @@ static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint3
         c->raw_out = nullptr;
         c->raw_cap = n + n / 8 + 4096;
         HIP_OK(hipMalloc((void **)&c->raw_out, c->raw_cap));
+        c->prof.allocations++;
     }
     if (n_tiles > c->raw_tile_cap) {
         HIP_OK(hipStreamSynchronize(s));
@@ -769,11 +803,22 @@ static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint3
         c->raw_tiles = nullptr;
         c->raw_tile_cap = n_tiles + n_tiles / 8 + 16;
         HIP_OK(hipMalloc(&c->raw_tiles, c->raw_tile_cap * 40));
+        c->prof.allocations++;
     }
     if (!c->raw_flags) {
         HIP_OK(hipMalloc((void **)&c->raw_flags, 4 * sizeof(unsigned int)));
+        c->prof.allocations++;
         HIP_OK(hipMalloc((void **)&c->raw_wraps, kRawWrapCap * sizeof(uint64_t)));
     }
+    return 0;
+}
+
+static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
+                                  uint32_t *verdict, bool continues)
+{
+    hipStream_t s = c->stream;
+    const uint64_t n_tiles = (n + kRawTile - 1) / kRawTile;
+    if (raw_reserve(c, n)) return 1;
     /* scratch: three channels (i64 last newline, i64 last reset, u32 newline count) per tile and per
      * group; the group arrays use the first n_groups entries of their cap-sized slices */
     const uint64_t n_groups = (n_tiles + kRawGroup - 1) / kRawGroup, cap = c->raw_tile_cap;
@@ -875,6 +920,10 @@ extern "C" int qm2_keys_from_fd(qm2_ctx *c, int fd, uint64_t file_offset)
     if (qm2_stream_fd(c, fd, file_offset + c->span_lo * sizeof(uint64_t), c->keys, n_slots * sizeof(uint64_t), "Dictionary file"))
         return 1;
     c->keys_pending = false;
+    if (c->part.reserved) {                                   /* prepared: look at the runs of occupied slots now, not in the first batch */
+        bool ok = false;
+        if (runs_fit(c, &ok)) return 1;
+    }
     return 0;
 }
 
@@ -893,7 +942,47 @@ extern "C" int qm2_sync(qm2_ctx *c)
     if (st.overflow)
         return fail("qm2: %llu k-mers did not fit their exchange bucket", st.overflow);
     c->peek_pending = false;
+    c->peek = st;
+    c->peek_bytes = c->bytes_launched;
     if (c->bytes_launched) c->kmers_per_byte = std::min(1.0, (double)st.n_kmers / (double)c->bytes_launched);
+    return 0;
+}
+
+extern "C" int qm2_stats_peek(qm2_ctx *c, qm2_stats *st)
+{
+    if (!c || !st) return fail("qm2_stats_peek: null argument");
+    stats_peek_harvest(c);
+    st->n_bases = c->peek.n_bases;
+    st->n_kmers = c->peek.n_kmers;
+    st->n_probes = c->peek.n_probes;
+    st->n_hits = c->peek.n_hits;
+    return 0;
+}
+
+/* Everything the counting phase will allocate, ahead of time (the CLI calls this while nothing is
+ * waiting for it): so no hipMalloc / hipHostMalloc sits between the first submit and qm2_finish. */
+extern "C" int qm2_prepare(qm2_ctx *c, uint64_t batch_bytes, uint32_t what)
+{
+    if (!c) return fail("qm2_prepare: null context");
+    if (use_device(c)) return 1;
+    const uint64_t bb = batch_bytes ? batch_bytes : (uint64_t)c->batch_bytes;
+    if (what & QM2_PREPARE_HOST) {
+        if (bb > c->batch_bytes) return fail("qm2_prepare: batch larger than the context's device batch");
+        for (auto &b : c->batch) if (batch_ready(c, b)) return 1;
+        for (auto &s : c->slots) if (qm2_slot_ready(c, s)) return 1;
+    }
+    if (what & QM2_PREPARE_RAW) {
+        if (raw_reserve(c, bb + 1)) return 1;
+    }
+    const bool want_part = !(c->flags & QM2_FLAG_DIRECT) && c->part.levels != 0 && c->span_lo == 0 && c->span_hi == c->H &&
+                           ((c->flags & QM2_FLAG_PARTITION) || (bb >= c->H / 8 && bb >= (1u << 20)));
+    if (want_part) {
+        (void)part_reserve(c, bb + kCarry + 64);           /* (no room: those batches take the direct kernel) */
+        if (!c->keys_pending && !c->keys_consumed) {
+            bool ok = false;
+            if (runs_fit(c, &ok)) return 1;
+        }
+    }
     return 0;
 }
 
@@ -928,6 +1017,8 @@ extern "C" int qm2_reset(qm2_ctx *c)
     HIP_OK(hipMemsetAsync(c->stats, 0, sizeof(DevStats), c->stream));
     c->bytes_launched = 0;
     c->peek_pending = false;
+    c->peek = DevStats();
+    c->peek_bytes = 0;
     c->raw_verdict = 0;
     c->raw_shift = 0;
     HIP_OK(hipStreamSynchronize(c->stream));
@@ -1025,6 +1116,9 @@ extern "C" int qm2_shard_span(const uint64_t *keys, uint64_t H, uint32_t n_shard
          * span over the occupied run past the middle-facing edge, empty slot included */
         if (lo < (H >> 1)) while (shi < H && keys[shi - 1] != 0) shi++;
         else               while (slo > 0 && keys[slo] != 0) slo--;
+        /* whole 64-slot blocks (more slots never hurt): 16-byte accesses to the span's keys and
+         * counters stay aligned and never straddle its ends */
+        if (H >= 64) { slo &= ~(uint64_t)63; shi = (shi + 63) & ~(uint64_t)63; }
     }
     if (own_lo) *own_lo = lo;
     if (own_hi) *own_hi = hi;

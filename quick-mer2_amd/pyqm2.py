@@ -40,7 +40,8 @@ class Stats(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("n_launches", C.c_uint64), ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double),
                 ("class_launches", C.c_uint64 * 8), ("class_ms", C.c_double * 8),
-                ("partitioned_batches", C.c_uint64), ("direct_batches", C.c_uint64), ("fallback_batches", C.c_uint64)]
+                ("partitioned_batches", C.c_uint64), ("direct_batches", C.c_uint64), ("fallback_batches", C.c_uint64),
+                ("allocations", C.c_uint64)]
 
 
 class Range(C.Structure):
@@ -52,7 +53,7 @@ class Dup(C.Structure):
 
 
 # every symbol include/qm2.h and include/qm2_tools.h declare
-ABI_SYMBOLS = ["qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
+ABI_SYMBOLS = ["qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
                "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_submit_raw_device", "qm2_staging_commit_raw", "qm2_raw_verdict",
                "qm2_shard_span", "qm2_last_error",
@@ -98,6 +99,10 @@ def lib():
     L.qm2_finish.argtypes = [vp, vp, C.POINTER(Stats)]
     L.qm2_reset.restype = C.c_int
     L.qm2_reset.argtypes = [vp]
+    L.qm2_prepare.restype = C.c_int
+    L.qm2_prepare.argtypes = [vp, u64, u32]
+    L.qm2_stats_peek.restype = C.c_int
+    L.qm2_stats_peek.argtypes = [vp, C.POINTER(Stats)]
     L.qm2_close.restype = None
     L.qm2_close.argtypes = [vp]
     L.qm2_counters_device.restype = vp
@@ -226,6 +231,14 @@ class Counter:
     def reset(self):
         _check(lib().qm2_reset(self._h), "qm2_reset")
 
+    def prepare(self, batch_bytes=0, host=False, raw=False):
+        _check(lib().qm2_prepare(self._h, int(batch_bytes), (1 if host else 0) | (2 if raw else 0)), "qm2_prepare")
+
+    def stats_peek(self):
+        st = Stats()
+        _check(lib().qm2_stats_peek(self._h, C.byref(st)), "qm2_stats_peek")
+        return st.as_dict()
+
     def chain_gather(self, chain, first_idx, window=None):
         """Epilogue on the device: counts in genome (chain) order, = the .bin payload."""
         chain = np.ascontiguousarray(chain, dtype=np.uint32)
@@ -266,7 +279,7 @@ class Counter:
                 "class_launches": {KERNEL_CLASSES[i]: int(p.class_launches[i]) for i in range(7)},
                 "class_ms": {KERNEL_CLASSES[i]: float(p.class_ms[i]) for i in range(7)},
                 "partitioned_batches": int(p.partitioned_batches), "direct_batches": int(p.direct_batches),
-                "fallback_batches": int(p.fallback_batches)}
+                "fallback_batches": int(p.fallback_batches), "allocations": int(p.allocations)}
 
     @property
     def counters_ptr(self):

@@ -166,8 +166,12 @@ def test_shard_spans_contain_every_walk():
                 assert own_lo == prev_hi and own_hi - own_lo == H // G and lo <= own_lo and hi >= own_hi
                 prev_hi = own_hi
                 if G > 1:
+                    # spans are whole 64-slot blocks; a walk that leaves the owned range through its
+                    # middle-facing edge meets an empty slot before it leaves the span
+                    assert lo % 64 == 0 and hi % 64 == 0
                     if own_lo < H // 2:
-                        assert lo == own_lo and keys[hi - 1] == 0 or hi == own_hi
-                        assert np.all(keys[own_hi - 1:hi - 1] != 0) if hi > own_hi else True
+                        assert lo == own_lo and np.any(keys[own_hi - 1:hi] == 0)
+                        assert hi - own_hi < 64 or np.all(keys[own_hi - 1:hi - 64] != 0)   # ... and not a block more than that
                     else:
-                        assert hi == own_hi and (keys[lo] == 0 or lo == own_lo)
+                        assert hi == own_hi and np.any(keys[lo:own_lo + 1] == 0)
+                        assert own_lo - lo < 64 or np.all(keys[lo + 64:own_lo + 1] != 0)

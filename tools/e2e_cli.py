@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
-"""End-to-end timing of the `quicKmer2 count` CLI at config-C2 scale on the GPU box:
-synthetic chr22-like dictionary written as a real .qm (chain = occupied slots in ascending
-order: a valid cycle, enough for timing), 10 M x 150 bp reads as FASTQ and as FASTA on local
-disk, then the CLI with wall-clock per phase from its own output.  This is the
-PCIe- and host-inclusive number (never bench.py's `value`)."""
+"""End-to-end timing of the `quicKmer2 count` CLI on the GPU box: a synthetic dictionary written as a
+real .qm (chain = occupied slots in ascending order: a valid cycle, enough for timing), N x 150 bp
+reads as FASTQ (and, at chr22 scale, FASTA) on local disk or /dev/shm, then the CLI with wall-clock
+per phase from its own output (QM2_TIMING=1).  This is the PCIe- and host-inclusive number (never
+bench.py's `value`).
+
+  tools/e2e_cli.py [n_reads] [workdir] [c2|c3] [reads_dir]
+
+Checks on the way: the reference's progress lines (`Read %liG kmers`, QuicKmer.c:446) number
+n_kmers >> 30, and no allocation happens inside the count phase (qm2_prepare)."""
 import os
+import re
 import subprocess
 import sys
 import time
@@ -20,15 +26,14 @@ from bench import genome_layout  # noqa: E402
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 work = sys.argv[2] if len(sys.argv) > 2 else "/tmp/qm2_e2e"
-os.makedirs(work, exist_ok=True)
 scale = sys.argv[3] if len(sys.argv) > 3 else "c2"
+reads_dir = sys.argv[4] if len(sys.argv) > 4 else work
+os.makedirs(work, exist_ok=True)
+os.makedirs(reads_dir, exist_ok=True)
 n, H, k = (3_100_000_000, 1 << 32, 30) if scale == "c3" else (50_818_468, 1 << 28, 30)
-if scale == "c3":                        # 51 GB .qm + reads + 4.5 GB .bin must fit on the scratch disk
-    import shutil
-    free = shutil.disk_usage(work).free
-    print("scratch disk free: %.0f GB" % (free / 1e9), flush=True)
-    if free < 70e9:
-        sys.exit("not enough scratch space for the hg38-scale run")
+import shutil
+print("scratch free: %.0f GB in %s, %.0f GB in %s" % (shutil.disk_usage(work).free / 1e9, work,
+                                                       shutil.disk_usage(reads_dir).free / 1e9, reads_dir), flush=True)
 genome = torch.empty(n, dtype=torch.uint8, device="cuda")
 n_blocks, dups, covered = genome_layout(n)
 pyqm2.tools.genome_generate(genome.data_ptr(), n, seed=22, n_blocks=n_blocks, dups=dups)
@@ -46,47 +51,63 @@ with open(os.path.join(work, "ref.fa.qm"), "wb") as f:
     hk.tofile(f)
     chain.tofile(f)
 print("wrote .qm %.1f GB in %.1f s" % (os.path.getsize(os.path.join(work, "ref.fa.qm")) / 1e9, time.time() - t), flush=True)
-del hk, chain
-reads = torch.empty(n_reads * 151, dtype=torch.uint8, device="cuda")
-pyqm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, n_reads, 0, 150, 150, 22, sample_from=covered)
-torch.cuda.synchronize()
-lines = reads.cpu().numpy()
-del reads, genome, keys
+del hk, chain, keys
 torch.cuda.empty_cache()
+# reads: made and framed on the device a piece at a time ("@r\n" seq "\n" "+\n" qual "\n" = 307 bytes a record)
 t = time.time()
-arr = lines.reshape(n_reads, 151)
-fq = np.empty((n_reads, 4 + 151 + 2 + 151), dtype=np.uint8)      # "@r\n" seq "\n" "+\n" qual "\n"
-fq[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
-fq[:, 3:154] = arr
-fq[:, 154:156] = np.frombuffer(b"+\n", dtype=np.uint8)
-fq[:, 156:306] = ord("I")
-fq[:, 306] = 10
-fq = fq[:, :307]
-fq.tofile(os.path.join(work, "reads.fq"))
-fa = np.empty((n_reads if scale != "c3" else 1, 2 + 151), dtype=np.uint8)      # (c3: scratch space is tight, FASTQ only)
-fa[:, 0:2] = np.frombuffer(b">\n", dtype=np.uint8)
-fa[:, 2:] = arr[:len(fa)]
-fa.tofile(os.path.join(work, "reads.fa"))
-print("wrote reads (fq %.1f GB, fa %.1f GB) in %.1f s" % (fq.nbytes / 1e9, fa.nbytes / 1e9, time.time() - t), flush=True)
-del fq, fa, arr, lines
+piece = 10_000_000
+want_fa = scale != "c3"
+head = torch.tensor(list(b"@r\n"), dtype=torch.uint8, device="cuda")
+plus = torch.tensor(list(b"+\n"), dtype=torch.uint8, device="cuda")
+with open(os.path.join(reads_dir, "reads.fq"), "wb") as fq, open(os.path.join(reads_dir, "reads.fa"), "wb") as fa:
+    for first in range(0, n_reads, piece):
+        m = min(piece, n_reads - first)
+        reads = torch.empty(m * 151, dtype=torch.uint8, device="cuda")
+        pyqm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, m, first, 150, 150, 22, sample_from=covered)
+        torch.cuda.synchronize()
+        rec = torch.empty((m, 307), dtype=torch.uint8, device="cuda")
+        rec[:, 0:3] = head
+        rec[:, 3:154] = reads.view(m, 151)
+        rec[:, 154:156] = plus
+        rec[:, 156:306] = ord("I")
+        rec[:, 306] = 10
+        rec.cpu().numpy().tofile(fq)
+        if want_fa:
+            rec = torch.empty((m, 153), dtype=torch.uint8, device="cuda")
+            rec[:, 0] = ord(">")
+            rec[:, 1] = 10
+            rec[:, 2:] = reads.view(m, 151)
+            rec.cpu().numpy().tofile(fa)
+        del reads, rec
+print("wrote %d reads (fq %.1f GB) in %.1f s" % (n_reads, os.path.getsize(os.path.join(reads_dir, "reads.fq")) / 1e9, time.time() - t), flush=True)
+del genome
+torch.cuda.empty_cache()
 cli = os.environ.get("QM2_E2E_CLI") or os.path.join(ROOT, "quick-mer2_amd", "quicKmer2")
-import re
 runs = [(f, t, e) for f in ("reads.fq", "reads.fa")
         for t, e in (("4", {}), ("8", {}), ("12", {}), ("8", {"QM2_READER_RAW": "0"}), ("4", {"QM2_READER_RAW": "0", "QM2_READER_STREAM": "1"}))]
 reps = 4
 if scale == "c3":
-    runs, reps = [("reads.fq", "8", {})], 2
+    runs, reps = [("reads.fq", "8", {}), ("reads.fq", "12", {})], 2
+ok = True
 for name, thr, extra in runs:
     best, walls = None, []
     for rep in range(reps):
         t = time.time()
-        r = subprocess.run([cli, "count", "-t", thr, os.path.join(work, "ref.fa"), os.path.join(work, name), os.path.join(work, "out")],
+        r = subprocess.run([cli, "count", "-t", thr, os.path.join(work, "ref.fa"), os.path.join(reads_dir, name), os.path.join(work, "out")],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, QM2_TIMING="1", **extra))
         walls.append(time.time() - t)
         out = r.stdout.decode(errors="replace")
         m = re.search(r"QM2 phase count ([0-9.]+) s", out)
         sec = float(m.group(1)) if m else float("nan")
         best = sec if best is None else min(best, sec)
-    print("== %s -t %s %s rc=%d  count phase best: %.3f s = %.2f G bases/s; wall best %.2f s (incl. .qm load, upload, epilogue)" %
-          (name, thr, "host strip, read(2) stream" if "QM2_READER_STREAM" in extra else "host strip, pread blocks" if extra else "device line discipline", r.returncode, best, n_reads * 150 / best / 1e9, min(walls)), flush=True)
+    nk = re.search(r"total (\d+) kmers", out)
+    prog = re.findall(r"^Read (\d+)G kmers$", out, flags=re.M)
+    al = re.search(r"allocations inside it: (\d+)", out)
+    good = r.returncode == 0 and nk and [int(x) for x in prog] == list(range(1, (int(nk.group(1)) >> 30) + 1)) and al and int(al.group(1)) == 0
+    ok = ok and bool(good)
+    print("== %s -t %s %s rc=%d  count phase best: %.3f s = %.2f G bases/s; wall best %.2f s (incl. .qm load, upload, epilogue); "
+          "progress lines %d, allocations in the count phase %s%s" %
+          (name, thr, "host strip, read(2) stream" if "QM2_READER_STREAM" in extra else "host strip, pread blocks" if extra else "device line discipline",
+           r.returncode, best, n_reads * 150 / best / 1e9, min(walls), len(prog), al.group(1) if al else "?", "" if good else "  <-- CHECK FAILED"), flush=True)
 print(out)
+sys.exit(0 if ok else 1)
