@@ -1,9 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — input bases/sec counted by the MI355X `count` hot path.
 
-One "step" = one pass of the hot path (fused encode + probe + increment kernel,
-through the C-ABI qm2_submit_device) over one batch of synthetic reads that is
-already resident in HBM.  Workloads (BASELINE.json `configs`):
+One "step" = one pass of the hot path (through the C-ABI, qm2_submit_device) over one batch of
+synthetic reads that is already resident in HBM: `value` is that rate (inputs in HBM when the
+timed region starts).  The same JSON line also carries
+  * streamed_bases_per_s — the SURVEY 8(d) wall-clock metric: the same batches fed from host memory
+    through the pinned staging buffers (qm2_staging_acquire / commit, as the CLI's reader does),
+    first commit -> return of qm2_finish, every allocation made beforehand (qm2_prepare); once as
+    stripped sequence lines and once as raw FASTQ text with the line discipline on the device;
+  * roofline — the WHOLE path: SURVEY 8(d)'s algorithmic bytes of a step / the summed kernel time of
+    a step (HIP events on the kernels' own stream) against the 8 TB/s HBM peak, with the per-kernel
+    table (and the dominant kernel's own figures) beneath it;
+  * cpu_baseline — the real reference binary (oracle/_ref/quicKmer2, `count -t 6`) timed on this
+    box's cores on the same dictionary, beside the oracle port and its thread sweep.
+
+Workloads (BASELINE.json `configs`):
 
   c3  (default; BASELINE.json's metric is quoted on the hg38 k=30 dictionary, which fits one
       GPU) hg38-like dictionary: 3.1 Gb synthetic reference, k=30, H=2^32, 2.27 G unique
@@ -69,6 +80,113 @@ def genome_layout(n):
     return n_blocks, dups, covered
 
 
+def cpu_legs(args, wl, pyqm2, torch, keys, buf0, nbytes0, H, k, local, n_unique):
+    """Everything timed on the host cores (rank 0, N = 1 only): the oracle port at the reference's
+    recommended -t 6 on a bounded sample + the same sample through the GPU (bit-exact check), the port
+    at the other worker counts of SURVEY 8(d), and the REAL reference binary on the same dictionary."""
+    import numpy as np
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    hk = keys.cpu().numpy().view(np.uint64)
+    ncpu = os.cpu_count() or 1
+
+    def sample(nb):
+        host = buf0[:min(nbytes0, int(nb))].cpu().numpy().tobytes()
+        return host[:host.rfind(b"\n") + 1]
+
+    def timed(host, thr):
+        tA = time.perf_counter()
+        dep, st = ol.count_lines(hk, k, host, threads=thr)
+        return dep, st, time.perf_counter() - tA
+
+    # calibrate on a small slice, then size the -t 6 sample for ~cpu_seconds
+    host = sample(400_000 * 151)
+    _, st, sec = timed(host, args.cpu_threads)
+    rate6 = st["n_bases"] / max(1e-6, sec)
+    host = sample(max(len(host), rate6 * 1.0067 * args.cpu_seconds))
+    cdepth, cst, cpu_s = timed(host, args.cpu_threads)
+    cdepth = ol.remove_drain_padding(cdepth, hk, cst["n_kmers"])
+    chk = pyqm2.Counter(None, hash_size=H, k=k, device=local, ext_keys=keys.data_ptr())
+    chk.submit(host)
+    gdepth, gst = chk.finish()
+    chk.close()
+    same = bool(np.array_equal(gdepth, cdepth) and gst["n_kmers"] == cst["n_kmers"])
+    del gdepth, cdepth
+    port = {"value": round(cst["n_bases"] / cpu_s, 1), "unit": "bases/s", "cores": args.cpu_threads + 1,
+            "sample": "first %d reads (%d bases) of batch 0, oracle threaded model: 1 producer + %d probe workers, %.1f s"
+                      % (host.count(b"\n"), cst["n_bases"], args.cpu_threads, cpu_s),
+            "gpu_counts_identical_on_sample": same}
+    # SURVEY 8(d): -t 0, -t 6 and the best of {12, 24, nproc-1}
+    sweep = {str(args.cpu_threads): port["value"]}
+    for thr in [int(x) for x in args.cpu_sweep.split(",") if x != ""]:
+        if thr == args.cpu_threads or thr >= ncpu:
+            continue
+        est = rate6 * (0.12 if thr == 0 else min(2.0, thr / 6.0))
+        sub = sample(max(151 * 20000, est * args.sweep_seconds))
+        _, sst, ssec = timed(sub, thr)
+        sweep[str(thr)] = round(sst["n_bases"] / ssec, 1)
+    port["sweep_bases_per_s_by_workers"] = sweep
+    port["best_workers"] = max(sweep, key=lambda t: sweep[t])
+    out = dict(port, kind="port", host_cores=ncpu)
+
+    # the reference itself: `quicKmer2 count -t 6` on a .qm of THIS dictionary (header + keys; it is
+    # stopped at its "Counting elapse" line, before it would read and walk the chain, :481-:516)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "quicKmer2")
+    import shutil
+    need = 24 + 8 * H + 2.2e9
+    roots = [r for r in (args.scratch, "/dev/shm") if os.path.isdir(r) and os.access(r, os.W_OK)]
+    root = max(roots, key=lambda r: shutil.disk_usage(r).free) if roots else args.scratch
+    work = tempfile.mkdtemp(prefix="qm2_bench_", dir=root)
+    try:
+        if args.no_reference_binary or not os.path.exists(ref_bin) or shutil.disk_usage(work).free < need * 1.1:
+            out["reference_binary"] = "skipped (%s)" % ("--no-reference-binary" if args.no_reference_binary else
+                                                         "oracle/_ref/quicKmer2 not shipped" if not os.path.exists(ref_bin)
+                                                         else "scratch space below %.0f GB" % (need * 1.1 / 1e9))
+        else:
+            with open(os.path.join(work, "ref.fa.qm"), "wb") as f:
+                f.write(b"QM11" + bytes([k, 0, 100, 100]) + int(H).to_bytes(8, "little") + (0).to_bytes(8, "little"))
+                hk.tofile(f)
+            host = sample(rate6 * 1.0067 * args.ref_seconds)
+            n_lines = host.count(b"\n")
+            with open(os.path.join(work, "reads.fa"), "wb") as f:
+                f.write(b">r\n")
+                f.write(host)
+            tA = time.perf_counter()
+            pr = subprocess.Popen([ref_bin, "count", "-t", str(args.cpu_threads), os.path.join(work, "ref.fa"),
+                                   os.path.join(work, "reads.fa"), os.path.join(work, "out")],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, bufsize=1)
+            t_loaded = t_done = None
+            nk_ref = None
+            for line in pr.stdout:
+                if line.startswith("Read 0x") and t_loaded is None:
+                    t_loaded = time.perf_counter()               # keys are in (:359): the timed loop starts (:386)
+                if line.startswith("Counting elapse"):
+                    t_done = time.perf_counter()
+                    nk_ref = int(line.split("total")[1].split()[0])
+                    break
+            pr.kill()
+            pr.wait()
+            if t_loaded and t_done:
+                # the threaded drain sleeps one fixed second (:469); it is not counting time
+                sec = (t_done - t_loaded) - (1.0 if args.cpu_threads > 0 else 0.0)
+                nb = len(host) - n_lines
+                out = {"value": round(nb / sec, 1), "unit": "bases/s", "cores": args.cpu_threads + 1, "kind": "reference",
+                       "sample": "the reference binary itself (oracle/_ref/quicKmer2 count -t %d, gcc -O3 of QuicKmer.c) on a .qm of this "
+                                 "dictionary: first %d reads (%d bases) of batch 0 as FASTA, %.1f s between its 'Read 0x.. hash' and "
+                                 "'Counting elapse' lines minus the fixed sleep(1) of its drain; %d k-mers (port on the same reads: %s)"
+                                 % (args.cpu_threads, n_lines, nb, sec, nk_ref,
+                                    "identical" if nk_ref == ol.count_lines(hk[:1], k, b"", threads=0)[1]["n_kmers"] + ol.extract(host, k)[0].size else "DIFFERENT"),
+                       "host_cores": ncpu, "dict_load_s": round(t_loaded - tA, 1), "port": port}
+            else:
+                out["reference_binary"] = "did not reach its 'Counting elapse' line"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    del hk
+    return out
+
+
 def main():
     # native libraries (RCCL prints a version banner) write to fd 1: keep stdout for the ONE JSON line
     json_out = os.fdopen(os.dup(1), "w")
@@ -81,10 +199,17 @@ def main():
                     help="c3 (default) = the configuration the metric is quoted on: full hg38-scale dictionary on one GPU")
     ap.add_argument("--batches", type=int, default=4, help="distinct read batches kept resident and cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--no-reference-binary", action="store_true", help="CPU leg: the oracle port only")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the host-fed (PCIe-inclusive) regions")
+    ap.add_argument("--streamed-steps", type=int, default=4)
+    ap.add_argument("--feed-threads", type=int, default=8, help="host threads that fill the staging buffers in the streamed regions")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the -t 6 port sample")
+    ap.add_argument("--ref-seconds", type=float, default=15.0, help="target counting time of the reference binary")
+    ap.add_argument("--sweep-seconds", type=float, default=6.0, help="target CPU time of each other worker count")
     ap.add_argument("--cpu-threads", type=int, default=6, help="probe workers (reference recommends 6)")
-    ap.add_argument("--cpu-sweep", default="", help="comma list of extra worker counts to time on a smaller "
-                    "sample (e.g. 0,12,24; 0 = the reference's serial mode); results go to cpu_baseline.sweep")
+    ap.add_argument("--cpu-sweep", default="0,12,24", help="other worker counts timed on smaller samples "
+                    "(0 = the reference's serial mode); results in cpu_baseline.sweep_bases_per_s_by_workers")
+    ap.add_argument("--scratch", default=os.environ.get("TMPDIR", "/tmp"), help="where the reference binary's .qm goes")
     ap.add_argument("--reads-per-step", type=int, default=0, help="override the workload's reads per step")
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "partition"],
                     help="count pipeline: auto = chosen per batch from its size vs. H")
@@ -143,11 +268,14 @@ def main():
                                    sample_from=covered)
         batches.append((buf, nbytes, nbytes - wl["reads"]))
     torch.cuda.synchronize()
+    del genome
+    torch.cuda.empty_cache()
     t_setup = time.time() - t_setup
 
     mode_flag = {"auto": 0, "direct": pyqm2.FLAG_DIRECT, "partition": pyqm2.FLAG_PARTITION}[args.mode]
     ctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=pyqm2.FLAG_TIMING | mode_flag,
                         ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr())
+    ctx.prepare(max(b[1] for b in batches))
 
     def barrier():
         if use_dist:
@@ -229,97 +357,131 @@ def main():
         counts_conserved = bool(int(counters.sum(dtype=torch.int64)) == hits_all)
 
     # ---- roofline: per-kernel HIP-event times (recorded on the stream the kernels run on) -----
-    batches_timed = prof1["n_launches"] - prof0["n_launches"]
     kern_ms = prof1["kernel_ms"] - prof0["kernel_ms"]
     cls_ms = {c: prof1["class_ms"][c] - prof0["class_ms"][c] for c in prof1["class_ms"]}
     cls_n = {c: prof1["class_launches"][c] - prof0["class_launches"][c] for c in prof1["class_launches"]}
     part_batches = prof1["partitioned_batches"] - prof0["partitioned_batches"]
     b_survey = d["n_bases"] + 8 * d["n_probes"] + 4 * d["n_hits"]        # SURVEY 8(d), whole timed region
     levels_kmer = (cls_n["split_kmer"] // max(1, part_batches)) if part_batches else 0
-    # algorithmic bytes each kernel class must move over the timed region
+    # bytes each kernel class must move over the timed region by ITS OWN model
     alg = {
         "count_direct": b_survey if part_batches == 0 else 0,
         "split_text": d["n_bases"] + 8 * d["n_kmers"],                     # text in, k-mers out
         "split_kmer": 16 * d["n_kmers"] * levels_kmer,                     # k-mers in + out, per level
         "bucket_count": (8 * d["n_kmers"] + args.steps * (8 * H + 8 * n_unique)) if part_batches else 0,
-        "probe": 0, "encode": 0,
+        "probe": 0, "encode": 0, "lines": 0,
     }
-    dom = max(cls_ms, key=lambda c: cls_ms[c])
-    dom_ms = cls_ms[dom]
-    dom_n = max(1, cls_n[dom])
-    achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic = None
+    # HBM bytes per launch measured by PMC counters: written by tools/summarize_profile.py from the rocprofv3
+    # passes named in the file (profiles/<round>_<workload>/); absent = null
+    traffic_step, traffic_src, traffic_k = None, None, {}
     tr_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tr_file):
         try:
             tj = json.load(open(tr_file))
-            traffic = tj.get("per_kernel", {}).get(dom, {}).get("hbm_bytes_per_launch")
+            traffic_k = {c: v.get("hbm_bytes_per_launch") for c, v in tj.get("per_kernel", {}).items()}
+            traffic_step = tj.get("hbm_bytes_per_step")
+            traffic_src = tj.get("source")
         except Exception:
-            traffic = None
+            pass
+    dom = max(cls_ms, key=lambda c: cls_ms[c])
+    per_kernel = {}
+    for c in cls_ms:
+        if not cls_n[c]:
+            continue
+        ms = cls_ms[c] / cls_n[c]
+        per_kernel[c] = {"launches": cls_n[c], "avg_launch_ms": round(ms, 4), "ms_per_step": round(cls_ms[c] / args.steps, 4),
+                         "kernel_model_bytes_per_launch": alg[c] // cls_n[c],
+                         "kernel_model_GBs": round(alg[c] / cls_n[c] / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                         "traffic": traffic_k.get(c)}
     pipe_gbs = b_survey / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "qm2::%s_kernel" % dom, "launches": cls_n[dom],
-                "avg_launch_ms": round(dom_ms / dom_n, 4),
-                "algorithmic_bytes_per_launch": alg[dom] // dom_n,
-                "pipeline": {"mode": "partitioned" if part_batches else "direct",
-                             "kernel_ms_per_step": {c: round(cls_ms[c] / args.steps, 4) for c in cls_ms if cls_n[c]},
-                             "sum_kernel_ms_per_step": round(kern_ms / args.steps, 4),
-                             "survey_bytes_per_base": round(b_survey / max(1, d["n_bases"]), 3),
-                             "survey_algorithmic_GBs": round(pipe_gbs, 2),
-                             "survey_frac_of_peak": round(pipe_gbs / HBM_PEAK_GBS, 5),
-                             "kernel_only_bases_per_s": round(d["n_bases"] / (kern_ms * 1e-3), 1) if kern_ms > 0 else None}}
+    dom_ms = cls_ms[dom] / max(1, cls_n[dom])
+    dom_survey = b_survey / args.steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(pipe_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(pipe_gbs / HBM_PEAK_GBS, 5), "traffic": traffic_step, "traffic_source": traffic_src,
+                "what": "whole path: SURVEY 8(d) bytes (1 B/base + 8 B/slot inspected + 4 B/hit) of a step / summed kernel time of a step",
+                "algorithmic_bytes_per_step": b_survey // args.steps,
+                "bytes_per_base": round(b_survey / max(1, d["n_bases"]), 3),
+                "sum_kernel_ms_per_step": round(kern_ms / args.steps, 4),
+                "mode": "partitioned" if part_batches else "direct",
+                "dominant_kernel": {"kernel": "qm2::%s_kernel" % dom, "avg_launch_ms": round(dom_ms, 4),
+                                    "survey_bytes_over_its_time_GBs": round(dom_survey, 1),
+                                    "survey_frac": round(dom_survey / HBM_PEAK_GBS, 5),
+                                    "kernel_model_frac": round((per_kernel[dom]["kernel_model_GBs"] or 0) / HBM_PEAK_GBS, 5)},
+                "kernels": per_kernel,
+                "kernel_only_bases_per_s": round(d["n_bases"] / (kern_ms * 1e-3), 1) if kern_ms > 0 else None}
 
-    # ---- CPU baseline: the oracle's reference-model threaded counter on a bounded sample ------
-    cpu = None
-    # the measured context and everything but batch 0 are released before the CPU leg opens its own
     ctx.close()
     ctx = None
     del counters
+    torch.cuda.empty_cache()
+
+    # ---- SURVEY 8(d)'s wall-clock metric: the batches fed from HOST memory through the pinned staging
+    #      buffers, first commit -> return of qm2_finish, allocations made beforehand ---------------------
+    streamed = None
+    if rank == 0 and world == 1 and not args.no_streamed and wl["len_lo"] == wl["len_hi"]:
+        rl = wl["len_lo"]
+        nb = 2
+        hosts = [batches[i % n_batches][0].cpu().numpy() for i in range(nb)]
+        sctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=mode_flag, ext_keys=keys.data_ptr(),
+                             n_staging=14)
+        sctx.prepare(host=True, raw=True)
+
+        def run(feed, steps):
+            feed(0)                                                   # warm-up: page in, first-touch
+            sctx.finish(want_depth=False)
+            a0 = sctx.profile()["allocations"]
+            _, s0 = sctx.finish(want_depth=False)
+            tA = time.perf_counter()
+            moved = 0
+            for i in range(steps):
+                moved += feed(i)
+            _, s1 = sctx.finish(want_depth=False)
+            sec = time.perf_counter() - tA
+            return s1["n_bases"] - s0["n_bases"], moved, sec, sctx.profile()["allocations"] - a0
+
+        def feed_lines(i):
+            h = hosts[i % nb]
+            sctx.feed_host(h.ctypes.data, h.size, rl + 1, threads=args.feed_threads)
+            return h.size
+
+        nbases, moved, sec, allocs = run(feed_lines, args.streamed_steps)
+        streamed = {"streamed_bases_per_s": round(nbases / sec, 1), "h2d_GBps": round(moved / sec / 1e9, 2),
+                    "steps": args.streamed_steps, "seconds": round(sec, 3), "allocations_inside": allocs,
+                    "feed": "%d host threads copy 64 MiB pieces into the pinned staging buffers (what the CLI's reader threads do "
+                            "with pread), one thread commits them in order; timed from the first commit to the return of qm2_finish"
+                            % args.feed_threads}
+        # the same reads as raw FASTQ text ("@r" / seq / "+" / qual: 2 x 151 + 5 bytes a record), line discipline on the device
+        del hosts
+        m = min(wl["reads"], 20_000_000)
+        src = batches[0][0][:m * (rl + 1)].view(m, rl + 1)
+        rec = torch.empty((m, 2 * (rl + 1) + 5), dtype=torch.uint8, device=dev)
+        rec[:, 0:3] = torch.tensor(list(b"@r\n"), dtype=torch.uint8, device=dev)
+        rec[:, 3:3 + rl + 1] = src
+        rec[:, rl + 4:rl + 6] = torch.tensor(list(b"+\n"), dtype=torch.uint8, device=dev)
+        rec[:, rl + 6:2 * rl + 6] = ord("I")
+        rec[:, 2 * rl + 6] = 10
+        fq = rec.cpu().numpy().reshape(-1)
+        del rec, src
+        torch.cuda.empty_cache()
+
+        def feed_fastq(i):
+            sctx.feed_host(fq.ctypes.data, fq.size, 2 * (rl + 1) + 5, raw=(True, 1), threads=args.feed_threads)
+            return fq.size
+
+        nbases, moved, sec, allocs = run(feed_fastq, max(1, args.streamed_steps // 2))
+        streamed.update({"streamed_raw_fastq_bases_per_s": round(nbases / sec, 1), "raw_fastq_h2d_GBps": round(moved / sec / 1e9, 2),
+                         "raw_fastq_reads_per_step": m, "raw_fastq_allocations_inside": allocs,
+                         "raw_verdict": sctx.raw_verdict()})
+        assert nbases == max(1, args.streamed_steps // 2) * m * rl and sctx.raw_verdict() == 0
+        sctx.close()
+        del fq
     batches = batches[:1]
     torch.cuda.empty_cache()
 
+    # ---- CPU baselines (rank 0, N = 1): reference binary, oracle port, worker sweep -----------------
+    cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as ol
-        hk = keys.cpu().numpy().view(np.uint64)
-        buf, nbytes, _ = batches[0]
-        line = wl["len_lo"] + 1 if wl["len_lo"] == wl["len_hi"] else None
-        # calibrate on a small slice, then size the sample for ~cpu_seconds
-        probe_bytes = min(nbytes, 400_000 * 151)
-        host = buf[:probe_bytes].cpu().numpy().tobytes()
-        host = host[:host.rfind(b"\n") + 1]
-        tA = time.perf_counter()
-        ol.count_lines(hk, k, host, threads=args.cpu_threads)
-        rate = len(host) / max(1e-6, time.perf_counter() - tA)
-        want = int(min(nbytes, max(len(host), rate * args.cpu_seconds)))
-        host = buf[:want].cpu().numpy().tobytes()
-        host = host[:host.rfind(b"\n") + 1]
-        tA = time.perf_counter()
-        cdepth, cst = ol.count_lines(hk, k, host, threads=args.cpu_threads)
-        cpu_s = time.perf_counter() - tA
-        cdepth = ol.remove_drain_padding(cdepth, hk, cst["n_kmers"])
-        # the same sample through the GPU path must give the same counters (bit-exact)
-        chk = pyqm2.Counter(None, hash_size=H, k=k, device=local, ext_keys=keys.data_ptr())
-        chk.submit(host)
-        gdepth, gst = chk.finish()
-        chk.close()
-        same = bool(np.array_equal(gdepth, cdepth) and gst["n_kmers"] == cst["n_kmers"] and gst["n_hits"] >= 0)
-        cpu = {"value": round(cst["n_bases"] / cpu_s, 1), "unit": "bases/s", "cores": args.cpu_threads + 1,
-               "kind": "port", "host_cores": os.cpu_count(),
-               "sample": "first %d reads (%d bases) of batch 0, oracle threaded model: 1 producer + %d probe workers, %.1f s"
-                         % (host.count(b"\n"), cst["n_bases"], args.cpu_threads, cpu_s),
-               "gpu_counts_identical_on_sample": same}
-        if args.cpu_sweep:
-            sweep = {}
-            sub = host[:max(1, len(host) // 4)]
-            sub = sub[:sub.rfind(b"\n") + 1]
-            for thr in [int(x) for x in args.cpu_sweep.split(",") if x != ""]:
-                tA = time.perf_counter()
-                _, sst = ol.count_lines(hk, k, sub if thr else sub[:max(1, len(sub) // 6)][:sub[:max(1, len(sub) // 6)].rfind(b"\n") + 1], threads=thr)
-                sweep[str(thr)] = round(sst["n_bases"] / (time.perf_counter() - tA), 1)
-            cpu["sweep_bases_per_s_by_workers"] = sweep
-        del hk
+        cpu = cpu_legs(args, wl, pyqm2, torch, keys, batches[0][0], batches[0][1], H, k, local, n_unique)
 
     if rank == 0:
         out = {
@@ -337,9 +499,14 @@ def main():
                        "probes_per_kmer": round(d["n_probes"] / max(1, d["n_kmers"]), 4),
                        "hit_fraction": round(d["n_hits"] / max(1, d["n_kmers"]), 4),
                        "parallelism": "replicas x%d (dictionary replicated, reads partitioned, one RCCL reduce per job)" % world
-                       if world > 1 else "1 GPU", "inputs": "resident in HBM", "setup_s": round(t_setup, 1),
+                       if world > 1 else "1 GPU", "inputs": "resident in HBM (value); host-fed rates under `streamed`",
+                       "setup_s": round(t_setup, 1),
                        "final_reduce_ms": round(reduce_ms, 2) if reduce_ms is not None else None,
                        "counts_conserved": counts_conserved},
+            "kernel_only_bases_per_s": roofline["kernel_only_bases_per_s"],
+            "streamed_bases_per_s": streamed["streamed_bases_per_s"] if streamed else None,
+            "h2d_GBps": streamed["h2d_GBps"] if streamed else None,
+            "streamed": streamed,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

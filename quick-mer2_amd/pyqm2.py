@@ -209,6 +209,43 @@ class Counter:
             _check(L.qm2_staging_commit(self._h, buf, take), "qm2_staging_commit")
             off += take
 
+    def staging_acquire(self):
+        """-> (address of a pinned staging buffer, its capacity)"""
+        buf, cap = C.c_void_p(), C.c_size_t()
+        _check(lib().qm2_staging_acquire(self._h, C.byref(buf), C.byref(cap)), "qm2_staging_acquire")
+        return buf.value, cap.value
+
+    def staging_commit(self, addr, n):
+        _check(lib().qm2_staging_commit(self._h, addr, n), "qm2_staging_commit")
+
+    def staging_commit_raw(self, addr, offset, n, fastq, skip):
+        _check(lib().qm2_staging_commit_raw(self._h, addr, offset, n, 1 if fastq else 0, skip), "qm2_staging_commit_raw")
+
+    def raw_verdict(self):
+        return int(lib().qm2_raw_verdict(self._h))
+
+    def feed_host(self, addr, n, unit, raw=None, threads=8, depth=6):
+        """Stream n bytes of HOST memory at `addr` through the pinned staging buffers the way the CLI's
+        reader does: `threads` threads copy into acquired buffers (ctypes.memmove releases the GIL),
+        this thread commits them in order.  Pieces are whole multiples of `unit` bytes (a line, or a
+        FASTQ record).  raw = None: stripped sequence lines (qm2_staging_commit); raw = (fastq, skip):
+        raw text with the line state at the start of every piece (qm2_staging_commit_raw)."""
+        from concurrent.futures import ThreadPoolExecutor
+        pend, off = [], 0
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            while off < n or pend:
+                while off < n and len(pend) < depth:
+                    buf, cap = self.staging_acquire()
+                    take = min((cap // unit) * unit, n - off)
+                    pend.append((buf, take, pool.submit(C.memmove, buf, addr + off, take)))
+                    off += take
+                buf, take, fut = pend.pop(0)
+                fut.result()
+                if raw is None:
+                    self.staging_commit(buf, take)
+                else:
+                    self.staging_commit_raw(buf, 0, take, raw[0], raw[1])
+
     def submit_device(self, ptr, n, suppress_ptr=None, n_suppress=0):
         _check(lib().qm2_submit_device(self._h, ptr, n, suppress_ptr, n_suppress), "qm2_submit_device")
 

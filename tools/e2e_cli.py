@@ -110,4 +110,6 @@ for name, thr, extra in runs:
           (name, thr, "host strip, read(2) stream" if "QM2_READER_STREAM" in extra else "host strip, pread blocks" if extra else "device line discipline",
            r.returncode, best, n_reads * 150 / best / 1e9, min(walls), len(prog), al.group(1) if al else "?", "" if good else "  <-- CHECK FAILED"), flush=True)
 print(out)
+for d_ in {work, reads_dir}:
+    shutil.rmtree(d_, ignore_errors=True)
 sys.exit(0 if ok else 1)

@@ -8,7 +8,7 @@ tail -3 gpurun_out/${TAG}_tests.log
 [ $rc -eq 124 ] && exit 1
 timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || exit 1
 python -c "
-import json; d=json.load(open('gpurun_out/${TAG}_bench.json')); print(round(d['value']/1e9,2), 'G bases/s', d['roofline']['pipeline']['kernel_ms_per_step'])"
+import json; d=json.load(open('gpurun_out/${TAG}_bench.json')); print(round(d['value']/1e9,2), 'G bases/s', {k: v['ms_per_step'] for k, v in d['roofline']['kernels'].items()})"
 if [ -f variants_stamps.so ]; then
   QM2_LIB=$PWD/variants_stamps.so timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_stamps.json 2> gpurun_out/${TAG}_stamps.err
   grep STAMPS gpurun_out/${TAG}_stamps.err
