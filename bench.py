@@ -316,7 +316,7 @@ def main():
     try:                                     # diagnostic builds only (-DQM2_STAMPS): phase stamps of bucket_count
         import ctypes as _C
         fn = pyqm2.lib().qm2_debug_stamps
-        acc = (_C.c_uint64 * 16)()
+        acc = (_C.c_uint64 * 32)()
         fn(acc)
         nl, npw = max(1, acc[8]), max(1, acc[9])
         lt = sum(acc[i] for i in (0, 1, 2, 3, 10))
@@ -327,6 +327,10 @@ def main():
                             100.0 * acc[2] / max(1, lt), 100.0 * acc[3] / max(1, lt),
                             npw, ptot / npw, 100.0 * acc[4] / max(1, ptot), 100.0 * acc[5] / max(1, ptot),
                             100.0 * acc[6] / max(1, ptot), 100.0 * acc[7] / max(1, ptot)))
+        if acc[24]:
+            tot = sum(acc[16:20])
+            sys.stderr.write("STAMPS split_kmer waves=%d cycles/wave=%.0f zero+barrier=%.1f%% load_hash_hist_copy=%.1f%% sort=%.1f%% tail=%.1f%%\n"
+                             % (acc[24], tot / acc[24], 100.0 * acc[16] / tot, 100.0 * acc[17] / tot, 100.0 * acc[18] / tot, 100.0 * acc[19] / tot))
     except AttributeError:
         pass
 

@@ -79,8 +79,8 @@ typedef struct {
                                  clamped to 1..6 GiB; two are kept).  The
                                  partitioned pipeline streams the whole table once
                                  per batch, so batches should be large against it */
-    uint32_t part_max_bits;   /* partitioned pipeline: radix bits per level, 1..8
-                                 (default 8); smaller values only make sense in tests */
+    uint32_t part_max_bits;   /* partitioned pipeline: radix bits per level, 1..10
+                                 (default 10); smaller values only make sense in tests */
     uint32_t reserved0;
     void    *ext_keys;        /* optional: device pointer to H x u64 keys that are
                                  ALREADY resident (then `keys` may be NULL)      */

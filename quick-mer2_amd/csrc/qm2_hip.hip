@@ -146,8 +146,7 @@ static void part_init(qm2_ctx *c, int max_bits)
     if (p.levels > kMaxLevels) { p.levels = 0; return; }             /* cannot happen for H <= 2^32 */
     int left = nb, cum = 0;
     for (int l = 0; l < p.levels; l++) {
-        /* the smaller shares go first (hg38: 6 + 7 + 7): the text level is VALU-bound and a smaller fan-out
-         * means fewer, longer runs to copy out there (measured 15.4 -> 14.1 ms, against + 0.6 ms in the k-mer levels) */
+        /* the smaller shares go first (the text level is VALU-bound); hg38: 10 + 10 */
         const int b = left / (p.levels - l);
         p.bits[l] = (uint32_t)b;
         cum += b;
@@ -282,9 +281,10 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
         /* ~4 chunks per workgroup so that the prefetch has something to hide behind */
         const uint32_t chunks = std::max<uint32_t>(1u, ((p.cap[l - 1] + kSplitSlots - 1) / kSplitSlots + 3) / 4);
         if (time_begin(c, &t, QM2_K_SPLIT_KMER)) return 1;
-        hipLaunchKernelGGL(split_kmer_kernel, dim3(chunks, (uint32_t)p.buckets[l - 1]), dim3(kSplitThreads), 0, s,
-                           p.buf[(l - 1) & 1], p.cursors + p.cursor_off[l - 1], p.cap[l - 1], hmask, p.shift[l],
-                           1u << p.bits[l], d, c->stats);
+        hipLaunchKernelGGL(split_kmer_kernel<false>, dim3(chunks * (uint32_t)p.buckets[l - 1]), dim3(kSplitThreads), 0, s,
+                           p.buf[(l - 1) & 1], p.cursors + p.cursor_off[l - 1], (uint64_t)p.cap[l - 1],
+                           (const unsigned long long *)nullptr, hmask, p.shift[l], 1u << p.bits[l], chunks,
+                           (uint32_t)p.buckets[l - 1], d, c->stats);
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
     }
@@ -537,7 +537,7 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
                                    : (size_t)std::min<uint64_t>(std::max<uint64_t>(hash_size + hash_size / 2, 1ull << 30), 6ull << 30);
     if (c->batch_bytes < 64) c->batch_bytes = 64;
     c->slots.resize(o.n_staging ? std::max<uint32_t>(o.n_staging, 2) : 4);   /* allocated lazily */
-    part_init(c, o.part_max_bits >= 1 && o.part_max_bits <= 8 ? (int)o.part_max_bits : 8);
+    part_init(c, o.part_max_bits >= 1 && o.part_max_bits <= 10 ? (int)o.part_max_bits : 10);
 #undef OPEN_OK
     *out = c;
     return 0;
@@ -1039,11 +1039,11 @@ extern "C" int qm2_get_profile(qm2_ctx *c, qm2_profile *p)
 
 #ifdef QM2_STAMPS
 /* diagnostic build only: read and clear the phase stamps of bucket_count_kernel */
-extern "C" int qm2_debug_stamps(unsigned long long *out16)
+extern "C" int qm2_debug_stamps(unsigned long long *out32)
 {
     HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(qm2::qm2_stamp_acc), 16 * sizeof(unsigned long long)));
-    unsigned long long z[16] = {0};
+    HIP_OK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(qm2::qm2_stamp_acc), 32 * sizeof(unsigned long long)));
+    unsigned long long z[32] = {0};
     HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(qm2::qm2_stamp_acc), z, sizeof z));
     return 0;
 }

@@ -45,7 +45,7 @@ constexpr int kSplitWaves    = kSplitThreads / kWave;
 constexpr int kKpt           = 16;                   /* k-mers per thread per chunk = one tile per wave  */
 constexpr int kSplitSlots    = kSplitThreads * kKpt; /* k-mers staged in LDS per chunk (128 KiB)         */
 constexpr int kSplitTextBytes = kSplitWaves * kTileBytes;   /* 15872 sequence bytes per chunk   */
-constexpr int kMaxFan        = 256;                  /* children per split                      */
+constexpr int kMaxFan        = 1024;                 /* children per split: hg38-scale tables (20 bucket bits) take 2 levels */
 constexpr uint64_t kPad      = ~0ull;                /* never a k-mer (k <= 31 uses at most 62 bits);
                                                         fills unused input slots                         */
 constexpr int kHalo          = 256;                  /* table slots staged past a bucket's
@@ -69,7 +69,7 @@ __device__ __forceinline__ void lds_barrier()
  * bucket_count_kernel, summed per wave into qm2_stamp_acc (cdna_hip_programming.md section 7, In-kernel
  * stamps).  Compiled out of the product. */
 #ifdef QM2_STAMPS
-__device__ unsigned long long qm2_stamp_acc[16];
+__device__ unsigned long long qm2_stamp_acc[32];
 __device__ __forceinline__ unsigned long long stamp_now()
 {
     unsigned long long t;
@@ -97,36 +97,28 @@ struct SplitLds {
     uint32_t hist[kMaxFan + 1];             /* [kMaxFan] = trash bin of the empty slots (keeps the
                                                rank atomics and the scatter branch-free)             */
     uint32_t off[kMaxFan];                  /* exclusive prefix of hist                              */
-    uint32_t gbase[kMaxFan];                /* reserved start in the child's region                  */
-    uint32_t fit[kMaxFan];                  /* how many of this chunk's k-mers fit the child         */
+    uint2    dl[kMaxFan];                   /* copy-out of the sorted chunk: element i of child c goes
+                                               to slot i + dl.x of the child's region if i < dl.y
+                                               (dl.x = reserved start - off, dl.y = off + what fits)  */
     uint32_t wsum[kMaxFan / kWave];
-};
-
-/* What a wave needs to copy out its share of a sorted chunk: lane l holds the run of child
- * wave + l * kSplitWaves: its length, its start in L.sorted, how much of it fits the child,
- * and where that goes.  Read back with v_readlane at compile-time lane indices, so the
- * copy-out's control values live in scalar registers. */
-struct RunDesc {
-    uint32_t f, o;                  /* k-mers to copy, start in L.sorted */
-    uint32_t dst_lo, dst_hi;
-    bool live;
+    uint32_t total;                         /* real k-mers in the sorted chunk                       */
 };
 
 /* Sort one chunk by child in LDS.  Every thread holds kKpt k-mers km[j] with
  * tag[j] = (child << 16) | rank_in_child (rank from an LDS atomic on hist); empty slots carry
- * child id kMaxFan (trash bin).  On return L.sorted holds the chunk grouped by child and the
- * wave's run descriptors are in registers; the copy-out (copy_piece) is left to the caller,
- * which interleaves it with the NEXT chunk's compute so that the stores (HBM-bound, ~2 ms per
- * 10 GB) drain behind VALU work instead of stalling every wave at once. */
-__device__ __forceinline__ RunDesc sort_chunk(SplitLds &L, const uint64_t (&km)[kKpt], const uint32_t (&tag)[kKpt],
-                                              uint64_t child0, uint32_t fan, const SplitDst &d,
-                                              unsigned long long &lost)
+ * child id kMaxFan (trash bin).  On return L.sorted holds the chunk grouped by child and L.dl /
+ * L.total say where every element goes; the copy-out (copy_piece) is left to the caller, which
+ * interleaves it with the NEXT chunk's compute so that the stores (HBM-bound, ~2 ms per 10 GB)
+ * drain behind VALU work instead of stalling every wave at once. */
+__device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKpt], const uint32_t (&tag)[kKpt],
+                                           uint64_t child0, uint32_t fan, const SplitDst &d,
+                                           unsigned long long &lost)
 {
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    lds_barrier();                 /* hist complete; every wave is done reading the previous L.sorted */
-    /* exclusive scan of hist[0..fan) by the first kMaxFan threads (4 waves) */
-    uint32_t mine = 0, incl = 0;
+    lds_barrier();                 /* hist complete; every wave is done reading the previous L.sorted / L.dl */
+    /* exclusive scan of hist[0..fan): one thread per child */
     static_assert(kSplitThreads >= kMaxFan, "the scan uses one thread per child");
+    uint32_t mine = 0, incl = 0;
     if (tid < kMaxFan) {
         mine = tid < (int)fan ? L.hist[tid] : 0;
         incl = mine;
@@ -138,12 +130,21 @@ __device__ __forceinline__ RunDesc sort_chunk(SplitLds &L, const uint64_t (&km)[
         if (lane == kWave - 1) L.wsum[wave] = incl;
     }
     lds_barrier();
-    uint32_t g = 0;
+    uint32_t g = 0, off = 0;
     const bool reserve = tid < (int)fan && mine != 0;
     if (tid < kMaxFan) {
-        uint32_t before = 0;
-        for (int w = 0; w < wave; w++) before += L.wsum[w];
-        L.off[tid] = before + incl - mine;
+        /* sums of the waves before this one: every wave scans the (at most 16) wave totals itself */
+        static_assert(kMaxFan / kWave <= kWave, "one lane per wave total");
+        uint32_t ws = lane < kMaxFan / kWave ? L.wsum[lane] : 0u;
+#pragma unroll
+        for (int o = 1; o < kMaxFan / kWave; o <<= 1) {
+            const uint32_t v = __shfl_up(ws, o);
+            if (lane >= o) ws += v;
+        }
+        const uint32_t before = wave ? __shfl(ws, wave - 1) : 0u;
+        off = before + incl - mine;
+        L.off[tid] = off;
+        if (tid == kMaxFan - 1) L.total = before + incl;
         /* reserve the run in the child's region; the returned offset is only needed for the
          * copy-out, so the round trip overlaps the LDS scatter below */
         if (reserve) g = atomicAdd(&d.cursors[child0 + (uint64_t)tid], mine);
@@ -157,64 +158,53 @@ __device__ __forceinline__ RunDesc sort_chunk(SplitLds &L, const uint64_t (&km)[
         L.sorted[pos] = km[j];
     }
     uint32_t f = mine;
-    if (reserve) {
-        f = g >= d.cap ? 0u : (d.cap - g < mine ? d.cap - g : mine);
-        L.gbase[tid] = g;
-        L.fit[tid] = f;
+    if (tid < kMaxFan) {
+        if (reserve) f = g >= d.cap ? 0u : (d.cap - g < mine ? d.cap - g : mine);
+        L.dl[tid] = make_uint2(g - off, off + f);
     }
     lds_barrier();
     if (reserve && f < mine) {
         /* rare (skewed input): the child is full; this thread moves the rest of the run to the
          * spill list, which the direct kernel probes at the end of the batch */
         const unsigned long long sb = atomicAdd(d.spill_count, (unsigned long long)(mine - f));
-        const uint32_t o = L.off[tid];
         for (uint32_t i = f; i < mine; i++) {
             const unsigned long long at = sb + (i - f);
-            if (at < d.spill_cap) d.spill[at] = L.sorted[o + i];
+            if (at < d.spill_cap) d.spill[at] = L.sorted[off + i];
             else lost++;
         }
     }
-    static_assert(kMaxFan <= kSplitWaves * kWave, "one descriptor per lane");
-    RunDesc r = {0, 0, 0, 0, true};
-    const uint32_t mb = wave + lane * kSplitWaves;
-    if (mb < fan && L.hist[mb]) {
-        r.f = L.fit[mb];
-        r.o = L.off[mb];
-        const uint64_t dst = (uint64_t)(d.kmers + (child0 + mb) * (uint64_t)d.cap + L.gbase[mb]);
-        r.dst_lo = (uint32_t)dst;
-        r.dst_hi = (uint32_t)(dst >> 32);
+}
+
+/* Copy-out of elements tid + PIECE * kSplitThreads of the sorted chunk: one element per lane, its child
+ * found again from its hash (cheaper than keeping 16 K child ids in LDS), its destination from L.dl.
+ * Neighbouring lanes hold neighbours of the same run, so the 8-byte stores of a wave fall into a few
+ * contiguous pieces whatever the fan-out — a copy-out per RUN (round 1) costs instructions per run and
+ * was what kept the fan-out at 128 and hg38-scale tables at three levels. */
+template <int PIECE>
+__device__ __forceinline__ void copy_piece(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t hmask,
+                                           uint32_t shift, uint32_t fan)
+{
+    const uint32_t i = threadIdx.x + PIECE * kSplitThreads;
+    if (i < L.total) {
+        const uint64_t km = L.sorted[i];
+        const uint32_t child = ((djb32(km) & hmask) >> shift) & (fan - 1u);
+        const uint2 dl = L.dl[child];
+        /* (an address-space-1 pointer: a generic one would make this a flat_store, which also counts on
+         * lgkmcnt — and every LDS wait and lds_barrier() of these kernels would wait for the stores) */
+        typedef uint64_t __attribute__((address_space(1))) global_u64;
+        global_u64 *dst = (global_u64 *)(uintptr_t)(d.kmers + (child0 + child) * (uint64_t)d.cap);
+        if (i < dl.y) dst[i + dl.x] = km;
     }
-    lds_barrier();                 /* descriptors are in registers: hist / off may be reused */
-    return r;
 }
 
-/* Copy-out of the run with descriptor index IT (child wave + IT * kSplitWaves): one
- * full-wave contiguous store per 64 k-mers.  All 64 lanes must call. */
-template <int IT>
-__device__ __forceinline__ void copy_piece(const SplitLds &L, const RunDesc &r, const SplitDst &d)
+__device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t hmask,
+                                         uint32_t shift, uint32_t fan)
 {
-    /* (the builtin returns int: go through uint32_t, or the low half sign-extends into the pointer) */
-    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)r.f, IT);
-    if (f == 0) return;                                        /* scalar branch */
-    const int lane = threadIdx.x & (kWave - 1);
-    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)r.o, IT);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)r.dst_lo, IT);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)r.dst_hi, IT);
-    /* a GLOBAL pointer (address space 1): rebuilt from two integers the compiler would otherwise treat
-     * it as generic and emit flat_store, which also counts on lgkmcnt — and every LDS wait and
-     * lds_barrier() in these kernels would then wait for the copy-out stores as well */
-    typedef uint64_t __attribute__((address_space(1))) global_u64;
-    global_u64 *dst = (global_u64 *)(((uint64_t)hi << 32) | (uint64_t)lo);
-    for (uint32_t i = lane; i < f; i += kWave) dst[i] = L.sorted[o + i];
-}
-
-/* all pieces of a sorted chunk (kernel epilogue) */
-__device__ __forceinline__ void copy_all(const SplitLds &L, const RunDesc &r, const SplitDst &d)
-{
-    copy_piece<0>(L, r, d);  copy_piece<1>(L, r, d);  copy_piece<2>(L, r, d);  copy_piece<3>(L, r, d);
-    copy_piece<4>(L, r, d);  copy_piece<5>(L, r, d);  copy_piece<6>(L, r, d);  copy_piece<7>(L, r, d);
-    copy_piece<8>(L, r, d);  copy_piece<9>(L, r, d);  copy_piece<10>(L, r, d); copy_piece<11>(L, r, d);
-    copy_piece<12>(L, r, d); copy_piece<13>(L, r, d); copy_piece<14>(L, r, d); copy_piece<15>(L, r, d);
+#define QM2_CP(J) copy_piece<J>(L, d, child0, hmask, shift, fan);
+    QM2_CP(0) QM2_CP(1) QM2_CP(2) QM2_CP(3) QM2_CP(4) QM2_CP(5) QM2_CP(6) QM2_CP(7)
+    QM2_CP(8) QM2_CP(9) QM2_CP(10) QM2_CP(11) QM2_CP(12) QM2_CP(13) QM2_CP(14) QM2_CP(15)
+#undef QM2_CP
+    static_assert(kKpt == 16, "sixteen pieces per chunk");
 }
 
 /* Level 1: sequence text -> canonical k-mers -> 2^b1 buckets by the top bits of
@@ -227,8 +217,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
     __shared__ SplitLds L;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     unsigned long long n_bases = 0, n_kmers = 0, lost = 0;
-    static_assert(kMaxFan <= 16 * kSplitWaves, "a wave copies at most 16 runs per chunk");
-    RunDesc pend = {0, 0, 0, 0, false};
+    bool pend = false;
     /* the 16 bytes of this lane for the NEXT chunk are fetched while the current one is processed */
     uint4 bytes = load16_raw(sv, lane_offset(((uint64_t)blockIdx.x * kSplitWaves + wave) * kTileBytes, lane));
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -238,7 +227,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
         const Window W = make_window_from<K30>(sv, tile * kTileBytes, lane, k, cur);
         n_bases += W.n_bases;
         n_kmers += __builtin_popcount(W.emit);
-        if (tid <= kMaxFan) L.hist[tid] = 0;
+        for (int i = tid; i <= kMaxFan; i += kSplitThreads) L.hist[i] = 0;
         lds_barrier();
         uint64_t km[kKpt];
         uint32_t tag[kKpt];
@@ -248,14 +237,15 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
             km[J] = kmer_at<K30, J>(W, k);                                         \
             const uint32_t b = (W.emit & (0x8000u >> J)) ? (djb32(km[J]) & hmask) >> shift : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
-            if (pend.live) copy_piece<J>(L, pend, d);                              \
+            if (pend) copy_piece<J>(L, d, 0, hmask, shift, fan);                   \
         }
         QM2_T(0) QM2_T(1) QM2_T(2) QM2_T(3) QM2_T(4) QM2_T(5) QM2_T(6) QM2_T(7)
         QM2_T(8) QM2_T(9) QM2_T(10) QM2_T(11) QM2_T(12) QM2_T(13) QM2_T(14) QM2_T(15)
 #undef QM2_T
-        pend = sort_chunk(L, km, tag, 0, fan, d, lost);
+        sort_chunk(L, km, tag, 0, fan, d, lost);
+        pend = true;
     }
-    if (pend.live) copy_all(L, pend, d);
+    if (pend) copy_all(L, d, 0, hmask, shift, fan);
     n_bases = wave_sum(n_bases); n_kmers = wave_sum(n_kmers); lost = wave_sum(lost);
     if (lane == 0) {
         atomicAdd(&stats->n_bases, n_bases);
@@ -264,51 +254,74 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
     }
 }
 
-/* Level l >= 2: split every level l-1 bucket into 2^bl children.
- * grid.y = parent; workgroup x of a parent takes its chunks x, x + gridDim.x, ... */
+/* Level l >= 2 (or level 1 of a k-mer array: FLAT): split every level l-1 bucket into 2^bl children.
+ * grid.y = parent; workgroup x of a parent takes its chunks x, x + gridDim.x, ...
+ * FLAT: one parent = the n (*d_n if given) k-mers at src, children numbered from 0. */
+template <bool FLAT>
 __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_t *src, const uint32_t *src_cursors,
-                                                                   uint32_t src_cap, uint32_t hmask, uint32_t shift,
-                                                                   uint32_t fan, SplitDst d, DevStats *stats)
+                                                                   uint64_t src_cap, const unsigned long long *d_n,
+                                                                   uint32_t hmask, uint32_t shift,
+                                                                   uint32_t fan, uint32_t wgs_per_parent, uint32_t n_parents,
+                                                                   SplitDst d, DevStats *stats)
 {
     __shared__ SplitLds L;
-    const uint64_t parent = blockIdx.y;
-    uint32_t n = src_cursors[parent];
-    if (n > src_cap) n = src_cap;
+    /* Block -> (parent, x).  Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one, each
+     * with its own L2): all workgroups of a parent get the same b % 8, so the short runs (~16 k-mers)
+     * that different workgroups append to one child meet in ONE L2 and leave it as whole lines.
+     * Speed only: nothing depends on where a block really runs. */
+    uint64_t parent;
+    uint32_t bx;
+    if (FLAT) { parent = 0; bx = blockIdx.x; }
+    else if ((n_parents & 7u) == 0) {
+        const uint32_t q = blockIdx.x >> 3, r = blockIdx.x & 7u;
+        parent = (uint64_t)(q / wgs_per_parent) * 8u + r;
+        bx = q % wgs_per_parent;
+    } else { parent = blockIdx.x / wgs_per_parent; bx = blockIdx.x % wgs_per_parent; }
+    uint64_t n;
+    if constexpr (FLAT) n = d_n && *d_n < src_cap ? *d_n : src_cap;
+    else { n = src_cursors[parent]; if (n > src_cap) n = src_cap; }
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     unsigned long long lost = 0;
-    const uint64_t *in = src + parent * (uint64_t)src_cap;
-    RunDesc pend = {0, 0, 0, 0, false};
-    /* the next chunk's k-mers are loaded while the current one is sorted and copied out */
-    uint64_t nxt[kKpt];
-    {
-        const uint64_t first = (uint64_t)blockIdx.x * kSplitSlots;
+    const uint64_t *in = src + parent * src_cap;
+    const uint64_t child0 = parent * fan;
+    bool pend = false;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    /* the next chunk's k-mers are loaded (16 bytes a lane: elements 2 t, 2 t + 1 of each row of 2048) while
+     * the current one is sorted and copied out; regions start 16-byte aligned (capacities are even) */
+    u32x4 nxt[kKpt / 2];
+    auto fetch = [&](uint64_t first) {
 #pragma unroll
-        for (int j = 0; j < kKpt; j++) {
-            const uint64_t at = first + (uint64_t)j * kSplitThreads + tid;
-            nxt[j] = at < n ? in[at] : kPad;
+        for (int j = 0; j < kKpt / 2; j++) {
+            const uint64_t at = first + 2u * ((uint64_t)j * kSplitThreads + tid);
+            nxt[j] = at < n ? *reinterpret_cast<const u32x4 *>(in + at) : u32x4{~0u, ~0u, ~0u, ~0u};
         }
-    }
-    for (uint64_t first = (uint64_t)blockIdx.x * kSplitSlots; first < n; first += (uint64_t)gridDim.x * kSplitSlots) {
-        if (tid <= kMaxFan) L.hist[tid] = 0;
+    };
+    fetch((uint64_t)bx * kSplitSlots);
+    for (uint64_t first = (uint64_t)bx * kSplitSlots; first < n; first += (uint64_t)wgs_per_parent * kSplitSlots) {
+        for (int i = tid; i <= kMaxFan; i += kSplitThreads) L.hist[i] = 0;
         lds_barrier();
         uint64_t km[kKpt];
         uint32_t tag[kKpt];
-        const uint64_t ahead = first + (uint64_t)gridDim.x * kSplitSlots;
+#pragma unroll
+        for (int j = 0; j < kKpt / 2; j++) {
+            const uint64_t at = first + 2u * ((uint64_t)j * kSplitThreads + tid);
+            km[2 * j] = ((uint64_t)nxt[j].y << 32) | nxt[j].x;
+            km[2 * j + 1] = at + 1 < n ? ((uint64_t)nxt[j].w << 32) | nxt[j].z : kPad;   /* (an odd fill: the pair's second half is stale) */
+        }
+        fetch(first + (uint64_t)wgs_per_parent * kSplitSlots);
 #define QM2_K(J)                                                                   \
         {                                                                          \
-            km[J] = nxt[J];                                                        \
-            const uint64_t at = ahead + (uint64_t)(J) * kSplitThreads + tid;       \
-            nxt[J] = at < n ? in[at] : kPad;                                       \
             const uint32_t b = km[J] != kPad ? ((djb32(km[J]) & hmask) >> shift) & (fan - 1) : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
-            if (pend.live) copy_piece<J>(L, pend, d);                              \
+            if (pend) copy_piece<J>(L, d, child0, hmask, shift, fan);              \
         }
         QM2_K(0) QM2_K(1) QM2_K(2) QM2_K(3) QM2_K(4) QM2_K(5) QM2_K(6) QM2_K(7)
         QM2_K(8) QM2_K(9) QM2_K(10) QM2_K(11) QM2_K(12) QM2_K(13) QM2_K(14) QM2_K(15)
 #undef QM2_K
-        pend = sort_chunk(L, km, tag, parent * fan, fan, d, lost);
+        sort_chunk(L, km, tag, child0, fan, d, lost);
+        pend = true;
     }
-    if (pend.live) copy_all(L, pend, d);
+    if (pend) copy_all(L, d, child0, hmask, shift, fan);
     lost = wave_sum(lost);
     if (lane == 0 && lost) atomicAdd(&stats->part_lost, lost);
 }

@@ -12,7 +12,7 @@ ROOTDIR=$(pwd)
 OUT=$ROOTDIR/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-streamed $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err" || echo "trace pass failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_rd" -- python3 bench.py $ARGS > "$OUT/bench_pmc_rd.json" 2> "$OUT/pmc_rd.err" || echo "pmc_rd failed"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_wr" -- python3 bench.py $ARGS > "$OUT/bench_pmc_wr.json" 2> "$OUT/pmc_wr.err" || echo "pmc_wr failed"
@@ -21,7 +21,7 @@ if [ "${QM2_PROFILE_CAL:-0}" = "1" ]; then
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cal_rd" -- python3 tools/microbench.py 28 > "$OUT/cal_rd.jsonl" 2> "$OUT/cal_rd.err" || echo "cal_rd failed"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/cal_wr" -- python3 tools/microbench.py 28 > "$OUT/cal_wr.jsonl" 2> "$OUT/cal_wr.err" || echo "cal_wr failed"
 fi
-python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
+python3 tools/summarize_profile.py "$OUT" "${QM2_WORKLOAD:-c3}" "profiles/${TAG}" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 # keep only small files for the merge back
 find "$OUT" -name "*.db" -delete 2>/dev/null

@@ -43,3 +43,53 @@ for sub in ("pmc_rd", "pmc_wr", "pmc_ea", "cal_rd", "cal_wr"):
     for k, cs in agg.items():
         for cn, vals in cs.items():
             print("%-60s %-22s n=%d mean=%.6g last=%.6g" % (k[:60], cn, len(vals), sum(vals) / len(vals), vals[-1]))
+
+# ---- traffic_<workload>.json: HBM bytes per launch and per step from the PMC passes ------------------
+# FETCH_SIZE / WRITE_SIZE are KiB per dispatch, collected in SEPARATE passes; on gfx950 FETCH_SIZE tallies
+# a wide coalesced read at half its bytes (MI355X_MICROARCH.md, HBM), so the read side is doubled.
+import json
+import re
+
+if len(sys.argv) > 2:
+    workload, dest = sys.argv[2], sys.argv[3]
+    pk = defaultdict(dict)
+    for sub, cn in (("pmc_rd", "FETCH_SIZE"), ("pmc_wr", "WRITE_SIZE")):
+        agg = defaultdict(list)
+        for f, r in rows(sub + "/**/*counter_collection.csv"):
+            if r["Counter_Name"] == cn:
+                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        for kname, vals in agg.items():
+            m = re.search(r"qm2::(\w+)_kernel", kname)
+            if not m or m.group(1) not in ("split_text", "split_kmer", "bucket_count", "count", "probe"):
+                continue
+            cls = {"count": "count_direct"}.get(m.group(1), m.group(1))
+            e = pk[cls]
+            e.setdefault(cn + "_KiB", 0.0)
+            e.setdefault(cn + "_n", 0)
+            e[cn + "_KiB"] += sum(vals)
+            e[cn + "_n"] += len(vals)
+    steps = None
+    try:
+        bj = json.load(open(os.path.join(out, "bench_pmc_rd.json")))
+        steps = bj["steps"] + bj["warmup"]
+    except Exception:
+        pass
+    per_kernel, step_total = {}, 0.0
+    for cls, e in pk.items():
+        n = max(e.get("FETCH_SIZE_n", 0), e.get("WRITE_SIZE_n", 0), 1)
+        rd = e.get("FETCH_SIZE_KiB", 0.0) / max(1, e.get("FETCH_SIZE_n", 1))
+        wr = e.get("WRITE_SIZE_KiB", 0.0) / max(1, e.get("WRITE_SIZE_n", 1))
+        hbm = int(2 * rd * 1024 + wr * 1024)
+        per_kernel[cls] = {"FETCH_SIZE_KiB": round(rd), "WRITE_SIZE_KiB": round(wr), "hbm_bytes_per_launch": hbm,
+                           "launches_profiled": n}
+        if steps:
+            step_total += hbm * n / steps
+    tj = {"workload": workload,
+          "source": "%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py` (tools/profile.sh), "
+                    "condensed by tools/summarize_profile.py; KiB per dispatch; the read side is doubled (gfx950 tallies wide "
+                    "coalesced reads at half their bytes: MI355X_MICROARCH.md, HBM)" % os.path.relpath(dest, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")),
+          "per_kernel": per_kernel,
+          "hbm_bytes_per_step": int(step_total) if steps else None}
+    json.dump(tj, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "traffic_%s.json" % workload), "w"), indent=1)
+    print("== traffic_%s.json ==" % workload)
+    print(json.dumps(tj, indent=1))
