@@ -187,6 +187,152 @@ def cpu_legs(args, wl, pyqm2, torch, keys, buf0, nbytes0, H, k, local, n_unique)
     return out
 
 
+def shard_spans_device(pyqm2, np, keys, H, G):
+    """qm2_shard_span needs host keys but only looks at the slots around the shard edges: give it a sparse
+    host image (untouched pages stay unmapped) with windows copied from the device table."""
+    W = 1 << 18
+    sparse = np.zeros(H, dtype=np.uint64)
+    per = H // G
+    for g in range(1, G):
+        e = g * per
+        sparse[e - W:e + W] = keys[e - W:e + W].cpu().numpy().view(np.uint64)
+    spans = [pyqm2.shard_span(sparse, G, g) for g in range(G)]
+    for own_lo, own_hi, lo, hi in spans:
+        assert own_lo - lo < W - 64 and hi - own_hi < W - 64, "a run of occupied slots longer than the copied window"
+    return spans
+
+
+def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist, keys, batches, n_batches, H, k, n_unique,
+                  mode_flag, t_setup):
+    """BASELINE config 4.  N ranks: quick-mer2_amd/multi.py's ShardedJob (route -> asynchronous all-to-all of
+    fixed slabs over RCCL -> probe of the rank's span, overlapped with the next batch's encode).
+    N = 1: the same two device legs on --shards logical shards of the one GPU, the exchange a no-op —
+    what hash-range sharding costs per base against a replica, before an 8-GPU box ever sees it."""
+    import ctypes as _C
+    G = world if world > 1 else args.shards
+    spans = shard_spans_device(pyqm2, np, keys, H, G)
+    flags = pyqm2.FLAG_TIMING | mode_flag
+    max_bytes = max(b[1] for b in batches)
+    t_class = {}
+
+    def add_prof(p0, p1):
+        for c in p1["class_ms"]:
+            t_class[c] = t_class.get(c, 0.0) + p1["class_ms"][c] - p0["class_ms"][c]
+
+    if world > 1:
+        import torch.distributed as dist
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as ge
+        ge.load_package()
+        from quick_mer2_amd import multi
+        eng = multi.HipEngine(torch, dev)
+        own_lo, own_hi, lo, hi = spans[rank]
+        job = multi.ShardedJob(dist, eng, None, k, torch, batch_bytes=max_bytes, flags=flags,
+                               resident=(H, spans[rank], keys.data_ptr() + 8 * lo))
+        job.ctx.prepare(job.cap * world)
+        for i in range(args.warmup):
+            job.count_local(batches[i % n_batches][0])
+        eng.drain(job.ctx)
+        _, s0 = job.ctx.finish(want_depth=False)
+        p0, r0 = job.ctx.profile(), job.rctx.profile()
+        b0 = sum(int(c[0]) for c in job._totals)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            job.count_local(batches[(args.warmup + i) % n_batches][0])
+        eng.drain(job.ctx)
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        _, s1 = job.ctx.finish(want_depth=False)
+        add_prof(p0, job.ctx.profile())
+        add_prof(r0, job.rctx.profile())
+        tot = torch.tensor([sum(int(c[0]) for c in job._totals) - b0, sum(int(c[1]) for c in job._totals[args.warmup:]),
+                            s1["n_probes"] - s0["n_probes"], s1["n_hits"] - s0["n_hits"],
+                            int(job.counters.sum(dtype=torch.int64)), s1["n_hits"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        n_bases, n_kmers, n_probes, n_hits, csum, hsum = [int(x) for x in tot]
+        conserved = csum == hsum
+        retries = job.retries
+        par = "hash-range shards x%d: one per rank, k-mers routed by asynchronous RCCL all-to-all of fixed slabs" % world
+        job.close()
+    else:
+        cap = (int(max_bytes / G * 1.3) + 4096) & ~1
+        router = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=pyqm2.FLAG_KEYS_LATER | flags, span=(0, 64))
+        shards = []
+        for own_lo, own_hi, lo, hi in spans:
+            cnt = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
+            c = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=flags, ext_keys=keys.data_ptr() + 8 * lo,
+                              ext_counters=cnt.data_ptr(), span=(lo, hi), own=(own_lo, own_hi))
+            c.prepare(cap)
+            shards.append((c, cnt))
+        slabs = torch.empty(G * cap, dtype=torch.int64, device=dev)
+        fill = torch.zeros(G, dtype=torch.int32, device=dev)
+        call = torch.zeros(3, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+
+        def step(i):
+            buf, nbytes, _ = batches[i % n_batches]
+            fill.zero_()
+            torch.cuda.synchronize()
+            router.route_device(buf.data_ptr(), nbytes, slabs.data_ptr(), cap, G, fill.data_ptr(), call.data_ptr())
+            router.sync()
+            for g, (c, _) in enumerate(shards):
+                c.probe_slabs_device(slabs.data_ptr() + 8 * g * cap, cap, 1, fill.data_ptr() + 4 * g)
+            for c, _ in shards:
+                c.sync()
+
+        for i in range(args.warmup):
+            step(i)
+        call.zero_()
+        s0 = [c.finish(want_depth=False)[1] for c, _ in shards]
+        p0 = [c.profile() for c, _ in shards]
+        r0 = router.profile()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        s1 = [c.finish(want_depth=False)[1] for c, _ in shards]
+        for a, (c, _) in zip(p0, shards):
+            add_prof(a, c.profile())
+        add_prof(r0, router.profile())
+        n_bases, n_kmers, unfit = [int(x) for x in call]
+        assert unfit == 0
+        n_probes = sum(b["n_probes"] - a["n_probes"] for a, b in zip(s0, s1))
+        n_hits = sum(b["n_hits"] - a["n_hits"] for a, b in zip(s0, s1))
+        conserved = sum(int(cnt.sum(dtype=torch.int64)) for _, cnt in shards) == sum(b["n_hits"] for b in s1)
+        retries = 0
+        par = "hash-range shards x%d, LOGICAL on one GPU (route + one partitioned probe per shard; the exchange is a no-op)" % G
+        for c, _ in shards:
+            c.close()
+        router.close()
+    kern_ms = sum(t_class.values())
+    b_survey = n_bases + 8 * n_probes + 4 * n_hits
+    # (the shards' contexts run on their own streams and overlap: summed HIP-event times count that overlap
+    #  twice, so the path figure is taken over the wall time of the steps)
+    gbs = b_survey / max(1, world) / elapsed / 1e9
+    return {
+        "metric": "input bases/sec counted vs hg38 k=30 dict", "value": round(n_bases / elapsed, 1), "unit": "bases/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": args.workload + ": " + wl["desc"], "k": k, "hash_size": H, "dict_kmers": n_unique,
+                   "reads_per_step_per_gpu": wl["reads"], "parallelism": par, "shards": G,
+                   "inputs": "resident in HBM", "setup_s": round(t_setup, 1), "counts_conserved": bool(conserved),
+                   "batches_cut_and_rerouted": retries},
+        "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                     "traffic": None, "what": "whole path per GPU: SURVEY 8(d) bytes / wall time of the timed steps (route + exchange + partition + count)",
+                     "kernel_ms_per_step": {c: round(v / args.steps, 3) for c, v in t_class.items() if v},
+                     "sum_kernel_ms_per_step_overlapping": round(kern_ms / args.steps, 3)},
+        "cpu_baseline": None,
+    }
+
+
 def main():
     # native libraries (RCCL prints a version banner) write to fd 1: keep stdout for the ONE JSON line
     json_out = os.fdopen(os.dup(1), "w")
@@ -211,6 +357,11 @@ def main():
                     "(0 = the reference's serial mode); results in cpu_baseline.sweep_bases_per_s_by_workers")
     ap.add_argument("--scratch", default=os.environ.get("TMPDIR", "/tmp"), help="where the reference binary's .qm goes")
     ap.add_argument("--reads-per-step", type=int, default=0, help="override the workload's reads per step")
+    ap.add_argument("--parallelism", default="replicas", choices=["replicas", "sharded"],
+                    help="replicas (default; what the dictionary's size calls for: it always fits one GPU) or sharded = "
+                         "BASELINE config 4: the table range-partitioned by home slot over the ranks, k-mers routed by "
+                         "all-to-all (N = 1: --shards logical shards on the one GPU, the exchange a no-op)")
+    ap.add_argument("--shards", type=int, default=8, help="--parallelism sharded on one GPU: logical shards")
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "partition"],
                     help="count pipeline: auto = chosen per batch from its size vs. H")
     args = ap.parse_args()
@@ -273,6 +424,17 @@ def main():
     t_setup = time.time() - t_setup
 
     mode_flag = {"auto": 0, "direct": pyqm2.FLAG_DIRECT, "partition": pyqm2.FLAG_PARTITION}[args.mode]
+    if args.parallelism == "sharded":
+        del counters
+        out = sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist, keys, batches, n_batches, H, k,
+                            n_unique, mode_flag, t_setup)
+        if rank == 0:
+            json_out.write(json.dumps(out) + "\n")
+            json_out.flush()
+        if use_dist:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     ctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=pyqm2.FLAG_TIMING | mode_flag,
                         ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr())
     ctx.prepare(max(b[1] for b in batches))

@@ -97,6 +97,11 @@ typedef struct {
                                  Both 0 = the whole table.  Only k-mers whose probe
                                  walk stays inside the span may be fed (see
                                  qm2_shard_span for how the span is chosen).     */
+    uint64_t own_lo;          /* with a span: the range [own_lo, own_hi) of HOME slots this   */
+    uint64_t own_hi;          /* shard is fed (qm2_shard_span's own range: a power of two of
+                                 slots, aligned to its size).  Given, qm2_probe_slabs_device
+                                 runs the partitioned pipeline on the span; both 0: the
+                                 shard is probed directly (random gathers + atomics).           */
 } qm2_opts;
 
 typedef struct {
@@ -219,6 +224,25 @@ int qm2_encode_device(qm2_ctx *c, const void *d_seq_bytes, size_t n,
                       const uint64_t *d_suppress, uint64_t n_suppress,
                       uint64_t *d_out, uint64_t bucket_cap, uint32_t n_buckets,
                       uint64_t *d_counts);
+
+/* The same two legs in the shape the multi-GPU driver wants them (quick-mer2_amd/multi.py):
+ *
+ * qm2_route_device    encode + bucket by owner at the speed of the partitioned pipeline's text level:
+ *                     d_slabs has n_owners slabs of slab_cap u64 (slab_cap even, d_slabs 16-byte
+ *                     aligned), d_fill[n_owners] (u32, zero on entry) receives how many k-mers were
+ *                     ROUTED to each owner — min(d_fill[g], slab_cap) of them are in the slab, the
+ *                     rest did not fit and are counted in d_call[2]; d_call = {bases, k-mers, k-mers
+ *                     that did not fit} of this call (u64 x 3, zero on entry).  The context's own
+ *                     statistics are not touched: the caller adds the totals of the calls it keeps
+ *                     (a call with d_call[2] != 0 is repeated in smaller pieces, by every rank).
+ * qm2_probe_slabs_device  the k-mers of n_slabs received slabs (slab s: the first
+ *                     min(d_fill[s], slab_cap) entries at d_slabs + s * slab_cap) against this shard's
+ *                     span.  With an own range in qm2_opts: partition by home slot + probe / count in
+ *                     LDS, like a whole table; without: direct probes.  Adds to n_probes / n_hits. */
+int qm2_route_device(qm2_ctx *c, const void *d_seq_bytes, size_t n, const uint64_t *d_suppress, uint64_t n_suppress,
+                     uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t *d_fill, uint64_t *d_call);
+int qm2_probe_slabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_slabs,
+                           const uint32_t *d_fill);
 
 /* Probe + increment for an array of canonical k-mers already on this device
  * (QuicKmer.c:283-293: the worker's batch loop).  d_n (device u64, may be

@@ -45,6 +45,7 @@ struct TimedLaunch {
 
 struct PartPlan {                           /* how a batch is radix-partitioned for this table */
     int      levels = 0;
+    uint32_t lg_range = 0;                  /* log2 of the own range the finest buckets tile */
     uint32_t bits[kMaxLevels] = {0, 0, 0};
     uint32_t shift[kMaxLevels] = {0, 0, 0}; /* child id at level l = (home >> shift[l]) & (fan-1) */
     uint64_t buckets[kMaxLevels] = {0, 0, 0};
@@ -74,6 +75,7 @@ struct qm2_ctx {
     uint64_t    H = 0;
     uint32_t    lgH = 0;
     uint64_t    span_lo = 0, span_hi = 0;
+    uint64_t    own_lo = 0, own_hi = 0;     /* home slots this context is fed (= the whole table, or a shard's own range) */
     uint32_t    flags = 0;
     uint64_t   *keys = nullptr;
     bool        own_keys = false;

@@ -140,8 +140,12 @@ static int harvest_timing(qm2_ctx *c)
 static void part_init(qm2_ctx *c, int max_bits)
 {
     PartPlan &p = c->part;
-    const int nb = (int)c->lgH - kLgS;                               /* bits of the finest bucket id */
-    if (nb < 1) { p.levels = 0; return; }     /* fewer than two buckets: such a table is counted by the direct kernel */
+    p.levels = 0;
+    if (c->own_hi == 0) return;               /* a span without its own range: probed directly */
+    p.lg_range = 0;
+    while ((1ull << p.lg_range) < c->own_hi - c->own_lo) p.lg_range++;
+    const int nb = (int)p.lg_range - kLgS;                           /* bits of the finest bucket id */
+    if (nb < 1 || c->lgH <= (uint32_t)kLgS) return;   /* fewer than two buckets: counted by the direct kernel */
     p.levels = nb <= max_bits ? 1 : (nb + max_bits - 1) / max_bits;
     if (p.levels > kMaxLevels) { p.levels = 0; return; }             /* cannot happen for H <= 2^32 */
     int left = nb, cum = 0;
@@ -151,7 +155,7 @@ static void part_init(qm2_ctx *c, int max_bits)
         p.bits[l] = (uint32_t)b;
         cum += b;
         left -= b;
-        p.shift[l] = c->lgH - (uint32_t)cum;                          /* >= kLgS */
+        p.shift[l] = p.lg_range - (uint32_t)cum;                      /* >= kLgS */
         p.buckets[l] = 1ull << cum;
     }
 }
@@ -250,28 +254,46 @@ static int launch_direct(qm2_ctx *c, const SeqView &sv, const unsigned long long
     return time_end(c, &t, batch_end);
 }
 
-static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
+/* The source of a partitioned batch: sequence text (qm2_submit*), or the slabs of k-mers a shard received
+ * from its peers (qm2_probe_slabs_device). */
+struct PartSource {
+    const SeqView *sv = nullptr;
+    const uint64_t *slabs = nullptr;
+    uint64_t slab_cap = 0;
+    uint32_t n_slabs = 0;
+    const uint32_t *fill = nullptr;
+    uint64_t n_upper = 0;           /* upper bound on the k-mers (text: its bytes) */
+};
+
+static int launch_partitioned(qm2_ctx *c, const PartSource &src)
 {
     PartPlan &p = c->part;
     hipStream_t s = c->stream;
-    const uint32_t hmask = (uint32_t)(c->H - 1);
     HIP_OK(hipMemsetAsync(p.cursors, 0, p.n_cursors * sizeof(uint32_t), s));
     hipLaunchKernelGGL(part_begin_kernel, dim3(1), dim3(64), 0, s, c->stats, p.spill_count);
     HIP_OK(hipGetLastError());
 
     TimedLaunch t;
-    /* level 1: text -> buckets[0] */
+    /* level 1: text or slabs -> buckets[0] */
     {
         SplitDst d = {p.buf[0], p.cursors + p.cursor_off[0], p.cap[0], p.spill, p.spill_count, p.spill_cap};
-        const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
-        const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * (kSplitSlots * 8 <= 72 * 1024 ? 2 : 1));
-        if (time_begin(c, &t, QM2_K_SPLIT_TEXT)) return 1;
-        if (c->k == 30)
-            hipLaunchKernelGGL(split_text_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k, hmask,
-                               p.shift[0], 1u << p.bits[0], n_chunks, d, c->stats);
-        else
-            hipLaunchKernelGGL(split_text_kernel<false>, dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k, hmask,
-                               p.shift[0], 1u << p.bits[0], n_chunks, d, c->stats);
+        if (src.sv) {
+            const SeqView &sv = *src.sv;
+            const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
+            const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu);
+            if (time_begin(c, &t, QM2_K_SPLIT_TEXT)) return 1;
+            if (c->k == 30)
+                hipLaunchKernelGGL(split_text_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k,
+                                   p.shift[0], p.bits[0], n_chunks, d, c->stats, (unsigned long long *)nullptr);
+            else
+                hipLaunchKernelGGL(split_text_kernel<false>, dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k,
+                                   p.shift[0], p.bits[0], n_chunks, d, c->stats, (unsigned long long *)nullptr);
+        } else {
+            const uint32_t chunks = (uint32_t)std::max<uint64_t>(1, ((src.slab_cap + kSplitSlots - 1) / kSplitSlots + 3) / 4);
+            if (time_begin(c, &t, QM2_K_SPLIT_KMER)) return 1;
+            hipLaunchKernelGGL(split_kmer_kernel<true>, dim3(chunks * src.n_slabs), dim3(kSplitThreads), 0, s,
+                               src.slabs, src.fill, src.slab_cap, p.shift[0], p.bits[0], chunks, src.n_slabs, d, c->stats);
+        }
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
     }
@@ -283,8 +305,7 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
         if (time_begin(c, &t, QM2_K_SPLIT_KMER)) return 1;
         hipLaunchKernelGGL(split_kmer_kernel<false>, dim3(chunks * (uint32_t)p.buckets[l - 1]), dim3(kSplitThreads), 0, s,
                            p.buf[(l - 1) & 1], p.cursors + p.cursor_off[l - 1], (uint64_t)p.cap[l - 1],
-                           (const unsigned long long *)nullptr, hmask, p.shift[l], 1u << p.bits[l], chunks,
-                           (uint32_t)p.buckets[l - 1], d, c->stats);
+                           p.shift[l], p.bits[l], chunks, (uint32_t)p.buckets[l - 1], d, c->stats);
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
     }
@@ -298,7 +319,7 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
          * + 3 sigma of uniform hashing; k-mers per byte measured on earlier batches through an asynchronous
          * copy of the stats block) wastes the fewest rows */
         stats_peek_harvest(c);
-        const uint64_t per_bucket = (uint64_t)((double)sv.n_total * c->kmers_per_byte) / n_buckets;
+        const uint64_t per_bucket = (uint64_t)((double)src.n_upper * (src.sv ? c->kmers_per_byte : 1.0 / 1.3)) / n_buckets;
         int g = 4;
         {
             const double fill = (double)per_bucket + 3.0 * std::sqrt((double)per_bucket + 1.0);
@@ -309,7 +330,7 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
                 if (run <= best_rows) { best_rows = run; g = cand; }           /* ties: the larger group */
             }
         }
-        const CountGeo cg = {0, 0, c->H, c->H >> 1};
+        const CountGeo cg = {c->own_lo, c->span_lo, c->span_hi, c->H >> 1};
 #define QM2_LAUNCH_COUNT(G_)                                                                                    \
         hipLaunchKernelGGL((bucket_count_kernel<kLgS, G_>), dim3(grid), dim3(kCountThreads), 0, s,             \
                            p.buf[L & 1], p.cursors + p.cursor_off[L], p.cap[L], table_view(c), cg, n_buckets,   \
@@ -331,12 +352,25 @@ static int launch_partitioned(qm2_ctx *c, const SeqView &sv)
         const int grid = grid_for(c, std::min<uint64_t>(groups, 1u << 16));
         if (time_begin(c, &t, QM2_K_PROBE)) return 1;
         hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(kBlock), 0, s, p.spill, p.spill_cap, p.spill_count,
-                           table_view(c), c->stats, &c->stats->part_lost);
+                           (const uint32_t *)nullptr, table_view(c), c->stats, &c->stats->part_lost,
+                           (const unsigned long long *)nullptr);
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
     }
     /* exact fallback, decided on the device: only if even the spill list overflowed */
-    if (launch_direct(c, sv, &c->stats->part_lost, false, true)) return 1;
+    if (src.sv) {
+        if (launch_direct(c, *src.sv, &c->stats->part_lost, false, true)) return 1;
+    } else {
+        for (uint32_t g = 0; g < src.n_slabs; g++) {
+            const uint64_t groups = (src.slab_cap + (uint64_t)kWave * kNJ - 1) / ((uint64_t)kWave * kNJ);
+            if (time_begin(c, &t, QM2_K_PROBE)) return 1;
+            hipLaunchKernelGGL(probe_kernel, dim3(grid_for(c, groups)), dim3(kBlock), 0, s, src.slabs + g * src.slab_cap,
+                               src.slab_cap, (const unsigned long long *)nullptr, src.fill + g, table_view(c), c->stats,
+                               (const unsigned long long *)nullptr, &c->stats->part_lost);
+            HIP_OK(hipGetLastError());
+            if (time_end(c, &t, g + 1 == src.n_slabs)) return 1;
+        }
+    }
     hipLaunchKernelGGL(part_end_kernel, dim3(1), dim3(64), 0, s, c->stats);
     HIP_OK(hipGetLastError());
     return 0;
@@ -362,9 +396,10 @@ static int runs_fit(qm2_ctx *c, bool *ok)
         if (e == hipSuccess) e = hipMemsetAsync(d_found, 0, sizeof(unsigned int), c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_shared, 0, words * sizeof(uint32_t), c->stream);
         if (e == hipSuccess) {
-            const int grid = (int)std::min<uint64_t>((c->H + 255) / 256, (uint64_t)c->n_cu * 64);
-            hipLaunchKernelGGL(long_run_kernel, dim3(grid), dim3(256), 0, c->stream, c->keys, c->H, (uint32_t)kHalo,
-                               (uint32_t)kLgS, d_shared, d_found);
+            const uint64_t n_slots = c->span_hi - c->span_lo;
+            const int grid = (int)std::min<uint64_t>((n_slots + 255) / 256, (uint64_t)c->n_cu * 64);
+            hipLaunchKernelGGL(long_run_kernel, dim3(grid), dim3(256), 0, c->stream, c->keys, n_slots, c->span_lo, c->own_lo,
+                               n_buckets, (uint32_t)kHalo, (uint32_t)kLgS, d_shared, d_found);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(&found, d_found, sizeof found, hipMemcpyDeviceToHost, c->stream);
@@ -416,7 +451,7 @@ static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry,
     c->bytes_launched += n;
     bool part = (c->flags & QM2_FLAG_PARTITION) != 0 || ((uint64_t)n >= c->H / 8 && n >= (1u << 20));
     if (c->flags & QM2_FLAG_DIRECT) part = false;
-    if (c->span_lo != 0 || c->span_hi != c->H) part = false;         /* shard spans: direct only */
+    if (c->span_lo != 0 || c->span_hi != c->H) part = false;         /* (text into a shard: only what stays in its span) */
     if (part && c->part.levels == 0) part = false;
     if (part) {                                                       /* occupied runs vs the halo */
         bool ok = false;
@@ -426,7 +461,10 @@ static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry,
     if (part && part_reserve(c, n)) part = false;                    /* no memory: direct */
     if (part) {
         c->prof.partitioned_batches++;
-        if (launch_partitioned(c, sv)) return 1;
+        PartSource src;
+        src.sv = &sv;
+        src.n_upper = sv.n_total;
+        if (launch_partitioned(c, src)) return 1;
     } else {
         c->prof.direct_batches++;
         if (launch_direct(c, sv, nullptr, true, true)) return 1;
@@ -483,6 +521,18 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
         delete c;
         return fail("qm2_open: bad span [%llu, %llu)", (unsigned long long)o.span_lo,
                     (unsigned long long)o.span_hi);
+    }
+    const bool whole = c->span_lo == 0 && c->span_hi == hash_size;
+    c->own_lo = whole ? 0 : o.own_lo;
+    c->own_hi = whole ? hash_size : o.own_hi;
+    if (!whole && c->own_hi != 0) {
+        const uint64_t r = c->own_hi - c->own_lo;
+        if (c->own_lo >= c->own_hi || (r & (r - 1)) || (c->own_lo & (r - 1)) || c->own_lo < c->span_lo || c->own_hi > c->span_hi ||
+            ((c->span_lo | c->span_hi) & 63u)) {
+            delete c;
+            return fail("qm2_open: bad own range [%llu, %llu) for span [%llu, %llu) (a power of two of slots, aligned, inside a span of whole 64-slot blocks)",
+                        (unsigned long long)o.own_lo, (unsigned long long)o.own_hi, (unsigned long long)o.span_lo, (unsigned long long)o.span_hi);
+        }
     }
     const uint64_t n_slots = c->span_hi - c->span_lo;
 
@@ -974,8 +1024,8 @@ extern "C" int qm2_prepare(qm2_ctx *c, uint64_t batch_bytes, uint32_t what)
     if (what & QM2_PREPARE_RAW) {
         if (raw_reserve(c, bb + 1)) return 1;
     }
-    const bool want_part = !(c->flags & QM2_FLAG_DIRECT) && c->part.levels != 0 && c->span_lo == 0 && c->span_hi == c->H &&
-                           ((c->flags & QM2_FLAG_PARTITION) || (bb >= c->H / 8 && bb >= (1u << 20)));
+    const bool want_part = !(c->flags & QM2_FLAG_DIRECT) && c->part.levels != 0 &&
+                           ((c->flags & QM2_FLAG_PARTITION) || (bb >= (c->span_hi - c->span_lo) / 8 && bb >= (1u << 20)));
     if (want_part) {
         (void)part_reserve(c, bb + kCarry + 64);           /* (no room: those batches take the direct kernel) */
         if (!c->keys_pending && !c->keys_consumed) {
@@ -1093,10 +1143,78 @@ extern "C" int qm2_probe_device(qm2_ctx *c, const uint64_t *d_kmers, uint64_t n,
     TimedLaunch t;
     if (time_begin(c, &t, QM2_K_PROBE)) return 1;
     hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(kBlock), 0, c->stream, d_kmers, n,
-                       (const unsigned long long *)d_n, table_view(c), c->stats,
-                       (const unsigned long long *)nullptr);
+                       (const unsigned long long *)d_n, (const uint32_t *)nullptr, table_view(c), c->stats,
+                       (const unsigned long long *)nullptr, (const unsigned long long *)nullptr);
     HIP_OK(hipGetLastError());
     return time_end(c, &t, true);
+}
+
+extern "C" int qm2_route_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup, uint64_t n_sup,
+                                uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t *d_fill, uint64_t *d_call)
+{
+    if (!c) return fail("qm2_route_device: null context");
+    if (n == 0) return 0;
+    if (!d_seq || !d_slabs || !d_fill || !d_call) return fail("qm2_route_device: null buffer");
+    if (n_owners == 0 || (n_owners & (n_owners - 1)) || n_owners > (uint32_t)kMaxFan || n_owners > c->H)
+        return fail("qm2_route_device: owner count %u is not a power of two <= %d", n_owners, kMaxFan);
+    if ((slab_cap & 1u) || ((uintptr_t)d_slabs & 15u) || slab_cap > 0xFFFFFFFFull)
+        return fail("qm2_route_device: slabs must be 16-byte aligned, of an even capacity below 2^32");
+    if (use_device(c)) return 1;
+    const SeqView sv = seq_view((const uint8_t *)d_seq, n, 0, d_sup, n_sup);
+    uint32_t lgG = 0;
+    while ((1u << lgG) < n_owners) lgG++;
+    SplitDst d = {d_slabs, d_fill, (uint32_t)slab_cap, nullptr, nullptr, 0};
+    const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
+    const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu);
+    TimedLaunch t;
+    if (time_begin(c, &t, QM2_K_ENCODE)) return 1;
+    if (c->k == 30)
+        hipLaunchKernelGGL(split_text_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, c->stream, sv, c->k,
+                           c->lgH - lgG, lgG, n_chunks, d, c->stats, (unsigned long long *)d_call);
+    else
+        hipLaunchKernelGGL(split_text_kernel<false>, dim3(grid), dim3(kSplitThreads), 0, c->stream, sv, c->k,
+                           c->lgH - lgG, lgG, n_chunks, d, c->stats, (unsigned long long *)d_call);
+    HIP_OK(hipGetLastError());
+    return time_end(c, &t, true);
+}
+
+extern "C" int qm2_probe_slabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_slabs,
+                                      const uint32_t *d_fill)
+{
+    if (!c) return fail("qm2_probe_slabs_device: null context");
+    if (n_slabs == 0 || slab_cap == 0) return 0;
+    if (!d_slabs || !d_fill) return fail("qm2_probe_slabs_device: null buffer");
+    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
+    if (c->keys_consumed) return fail("qm2: the key table was overwritten by qm2_chain_gather; this context cannot count any more");
+    if (use_device(c)) return 1;
+    const uint64_t n_upper = slab_cap * n_slabs;
+    bool part = c->part.levels != 0 && !(c->flags & QM2_FLAG_DIRECT) && !(slab_cap & 1u) && !((uintptr_t)d_slabs & 15u) &&
+                ((c->flags & QM2_FLAG_PARTITION) || (n_upper >= (c->span_hi - c->span_lo) / 16 && n_upper >= (1u << 17)));
+    if (part) {
+        bool ok = false;
+        if (runs_fit(c, &ok)) return 1;
+        if (!ok) part = false;
+    }
+    if (part && part_reserve(c, n_upper)) part = false;
+    c->bytes_launched += n_upper;
+    if (part) {
+        c->prof.partitioned_batches++;
+        PartSource src;
+        src.slabs = d_slabs; src.slab_cap = slab_cap; src.n_slabs = n_slabs; src.fill = d_fill; src.n_upper = n_upper;
+        return launch_partitioned(c, src);
+    }
+    c->prof.direct_batches++;
+    for (uint32_t g = 0; g < n_slabs; g++) {
+        const uint64_t groups = (slab_cap + (uint64_t)kWave * kNJ - 1) / ((uint64_t)kWave * kNJ);
+        TimedLaunch t;
+        if (time_begin(c, &t, QM2_K_PROBE)) return 1;
+        hipLaunchKernelGGL(probe_kernel, dim3(grid_for(c, groups)), dim3(kBlock), 0, c->stream, d_slabs + g * slab_cap, slab_cap,
+                           (const unsigned long long *)nullptr, d_fill + g, table_view(c), c->stats,
+                           (const unsigned long long *)nullptr, (const unsigned long long *)nullptr);
+        HIP_OK(hipGetLastError());
+        if (time_end(c, &t, g + 1 == n_slabs)) return 1;
+    }
+    return 0;
 }
 
 /* ---- pure host helper ------------------------------------------------------ */

@@ -158,13 +158,18 @@ __global__ __launch_bounds__(kBlock) void encode_kernel(SeqView sv, uint32_t k, 
 
 /* Probe + increment of ready-made canonical k-mers: lane handles kNJ k-mers
  * strided by the wave so that the k-mer loads are coalesced. */
+/* skip_if / only_if: device-side conditions (the partitioned pipeline's "this batch lost k-mers" flag);
+ * d_n / d_n32: the count lives on the device (n is then the capacity) */
 __global__ __launch_bounds__(kBlock) void probe_kernel(const uint64_t *kmers, uint64_t n,
-                                                       const unsigned long long *d_n,
+                                                       const unsigned long long *d_n, const uint32_t *d_n32,
                                                        TableView tv, DevStats *stats,
-                                                       const unsigned long long *skip_if)
+                                                       const unsigned long long *skip_if,
+                                                       const unsigned long long *only_if)
 {
     if (skip_if && *skip_if != 0) return;
+    if (only_if && *only_if == 0) return;
     if (d_n) n = *d_n < n ? *d_n : n;
+    if (d_n32) n = *d_n32 < n ? *d_n32 : n;
     const int lane = threadIdx.x & (kWave - 1);
     const uint64_t wave_id = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) / kWave;
     const uint64_t n_waves = ((uint64_t)gridDim.x * kBlock) / kWave;

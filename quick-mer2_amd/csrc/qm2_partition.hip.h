@@ -166,11 +166,14 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
     if (reserve && f < mine) {
         /* rare (skewed input): the child is full; this thread moves the rest of the run to the
          * spill list, which the direct kernel probes at the end of the batch */
-        const unsigned long long sb = atomicAdd(d.spill_count, (unsigned long long)(mine - f));
-        for (uint32_t i = f; i < mine; i++) {
-            const unsigned long long at = sb + (i - f);
-            if (at < d.spill_cap) d.spill[at] = L.sorted[off + i];
-            else lost++;
+        if (d.spill_cap == 0) lost += mine - f;               /* (qm2_route_device: no spill list, the caller is told) */
+        else {
+            const unsigned long long sb = atomicAdd(d.spill_count, (unsigned long long)(mine - f));
+            for (uint32_t i = f; i < mine; i++) {
+                const unsigned long long at = sb + (i - f);
+                if (at < d.spill_cap) d.spill[at] = L.sorted[off + i];
+                else lost++;
+            }
         }
     }
 }
@@ -180,14 +183,20 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
  * Neighbouring lanes hold neighbours of the same run, so the 8-byte stores of a wave fall into a few
  * contiguous pieces whatever the fan-out — a copy-out per RUN (round 1) costs instructions per run and
  * was what kept the fan-out at 128 and hg38-scale tables at three levels. */
+/* child of a k-mer at a level: `bits` bits of its home slot from bit `shift` on (shift + bits <= log2 H, so
+ * the & (H - 1) of :92 is implied; bits = 0: everything is child 0) — one v_bfe_u32 */
+__device__ __forceinline__ uint32_t child_of(uint64_t km, uint32_t shift, uint32_t bits)
+{
+    return __builtin_amdgcn_ubfe(djb32(km), shift, bits);
+}
+
 template <int PIECE>
-__device__ __forceinline__ void copy_piece(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t hmask,
-                                           uint32_t shift, uint32_t fan)
+__device__ __forceinline__ void copy_piece(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
 {
     const uint32_t i = threadIdx.x + PIECE * kSplitThreads;
     if (i < L.total) {
         const uint64_t km = L.sorted[i];
-        const uint32_t child = ((djb32(km) & hmask) >> shift) & (fan - 1u);
+        const uint32_t child = child_of(km, shift, bits);
         const uint2 dl = L.dl[child];
         /* (an address-space-1 pointer: a generic one would make this a flat_store, which also counts on
          * lgkmcnt — and every LDS wait and lds_barrier() of these kernels would wait for the stores) */
@@ -197,10 +206,9 @@ __device__ __forceinline__ void copy_piece(const SplitLds &L, const SplitDst &d,
     }
 }
 
-__device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t hmask,
-                                         uint32_t shift, uint32_t fan)
+__device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
 {
-#define QM2_CP(J) copy_piece<J>(L, d, child0, hmask, shift, fan);
+#define QM2_CP(J) copy_piece<J>(L, d, child0, shift, bits);
     QM2_CP(0) QM2_CP(1) QM2_CP(2) QM2_CP(3) QM2_CP(4) QM2_CP(5) QM2_CP(6) QM2_CP(7)
     QM2_CP(8) QM2_CP(9) QM2_CP(10) QM2_CP(11) QM2_CP(12) QM2_CP(13) QM2_CP(14) QM2_CP(15)
 #undef QM2_CP
@@ -209,11 +217,14 @@ __device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, u
 
 /* Level 1: sequence text -> canonical k-mers -> 2^b1 buckets by the top bits of
  * the home slot.  One chunk = 16 tiles (one per wave). */
+/* `call` (qm2_route_device): the launch's totals {bases, k-mers, k-mers that fitted nowhere} go there
+ * instead of into the context's statistics. */
 template <bool K30>
-__global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, uint32_t k, uint32_t hmask,
-                                                                   uint32_t shift, uint32_t fan,
-                                                                   uint64_t n_chunks, SplitDst d, DevStats *stats)
+__global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, uint32_t k, uint32_t shift, uint32_t bits,
+                                                                   uint64_t n_chunks, SplitDst d, DevStats *stats,
+                                                                   unsigned long long *call)
 {
+    const uint32_t fan = 1u << bits;
     __shared__ SplitLds L;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     unsigned long long n_bases = 0, n_kmers = 0, lost = 0;
@@ -235,9 +246,9 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
 #define QM2_T(J)                                                                   \
         {                                                                          \
             km[J] = kmer_at<K30, J>(W, k);                                         \
-            const uint32_t b = (W.emit & (0x8000u >> J)) ? (djb32(km[J]) & hmask) >> shift : (uint32_t)kMaxFan; \
+            const uint32_t b = (W.emit & (0x8000u >> J)) ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
-            if (pend) copy_piece<J>(L, d, 0, hmask, shift, fan);                   \
+            if (pend) copy_piece<J>(L, d, 0, shift, bits);                         \
         }
         QM2_T(0) QM2_T(1) QM2_T(2) QM2_T(3) QM2_T(4) QM2_T(5) QM2_T(6) QM2_T(7)
         QM2_T(8) QM2_T(9) QM2_T(10) QM2_T(11) QM2_T(12) QM2_T(13) QM2_T(14) QM2_T(15)
@@ -245,25 +256,32 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
         sort_chunk(L, km, tag, 0, fan, d, lost);
         pend = true;
     }
-    if (pend) copy_all(L, d, 0, hmask, shift, fan);
+    if (pend) copy_all(L, d, 0, shift, bits);
     n_bases = wave_sum(n_bases); n_kmers = wave_sum(n_kmers); lost = wave_sum(lost);
     if (lane == 0) {
-        atomicAdd(&stats->n_bases, n_bases);
-        atomicAdd(&stats->n_kmers, n_kmers);
-        if (lost) atomicAdd(&stats->part_lost, lost);
+        if (call) {
+            atomicAdd(&call[0], n_bases);
+            atomicAdd(&call[1], n_kmers);
+            if (lost) atomicAdd(&call[2], lost);
+        } else {
+            atomicAdd(&stats->n_bases, n_bases);
+            atomicAdd(&stats->n_kmers, n_kmers);
+            if (lost) atomicAdd(&stats->part_lost, lost);
+        }
     }
 }
 
-/* Level l >= 2 (or level 1 of a k-mer array: FLAT): split every level l-1 bucket into 2^bl children.
- * grid.y = parent; workgroup x of a parent takes its chunks x, x + gridDim.x, ...
- * FLAT: one parent = the n (*d_n if given) k-mers at src, children numbered from 0. */
+/* Level l >= 2: split every level l-1 bucket (parent) into its 2^bits children; workgroup x of a parent
+ * takes its chunks x, x + wgs_per_parent, ...
+ * FLAT (level 1 of a shard, qm2_probe_slabs_device): the parents are the slabs a shard received from its
+ * peers — src_cap apart, src_cursors[slab] k-mers in each — and they all feed the same children 0 .. fan-1. */
 template <bool FLAT>
 __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_t *src, const uint32_t *src_cursors,
-                                                                   uint64_t src_cap, const unsigned long long *d_n,
-                                                                   uint32_t hmask, uint32_t shift,
-                                                                   uint32_t fan, uint32_t wgs_per_parent, uint32_t n_parents,
+                                                                   uint64_t src_cap, uint32_t shift, uint32_t bits,
+                                                                   uint32_t wgs_per_parent, uint32_t n_parents,
                                                                    SplitDst d, DevStats *stats)
 {
+    const uint32_t fan = 1u << bits;
     __shared__ SplitLds L;
     /* Block -> (parent, x).  Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one, each
      * with its own L2): all workgroups of a parent get the same b % 8, so the short runs (~16 k-mers)
@@ -271,19 +289,17 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
      * Speed only: nothing depends on where a block really runs. */
     uint64_t parent;
     uint32_t bx;
-    if (FLAT) { parent = 0; bx = blockIdx.x; }
-    else if ((n_parents & 7u) == 0) {
+    if ((n_parents & 7u) == 0 && !FLAT) {
         const uint32_t q = blockIdx.x >> 3, r = blockIdx.x & 7u;
         parent = (uint64_t)(q / wgs_per_parent) * 8u + r;
         bx = q % wgs_per_parent;
     } else { parent = blockIdx.x / wgs_per_parent; bx = blockIdx.x % wgs_per_parent; }
-    uint64_t n;
-    if constexpr (FLAT) n = d_n && *d_n < src_cap ? *d_n : src_cap;
-    else { n = src_cursors[parent]; if (n > src_cap) n = src_cap; }
+    uint64_t n = src_cursors[parent];
+    if (n > src_cap) n = src_cap;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     unsigned long long lost = 0;
     const uint64_t *in = src + parent * src_cap;
-    const uint64_t child0 = parent * fan;
+    const uint64_t child0 = FLAT ? 0 : parent * fan;
     bool pend = false;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     /* the next chunk's k-mers are loaded (16 bytes a lane: elements 2 t, 2 t + 1 of each row of 2048) while
@@ -311,9 +327,9 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
         fetch(first + (uint64_t)wgs_per_parent * kSplitSlots);
 #define QM2_K(J)                                                                   \
         {                                                                          \
-            const uint32_t b = km[J] != kPad ? ((djb32(km[J]) & hmask) >> shift) & (fan - 1) : (uint32_t)kMaxFan; \
+            const uint32_t b = km[J] != kPad ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
-            if (pend) copy_piece<J>(L, d, child0, hmask, shift, fan);              \
+            if (pend) copy_piece<J>(L, d, child0, shift, bits);                    \
         }
         QM2_K(0) QM2_K(1) QM2_K(2) QM2_K(3) QM2_K(4) QM2_K(5) QM2_K(6) QM2_K(7)
         QM2_K(8) QM2_K(9) QM2_K(10) QM2_K(11) QM2_K(12) QM2_K(13) QM2_K(14) QM2_K(15)
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
         sort_chunk(L, km, tag, child0, fan, d, lost);
         pend = true;
     }
-    if (pend) copy_all(L, d, child0, hmask, shift, fan);
+    if (pend) copy_all(L, d, child0, shift, bits);
     lost = wave_sum(lost);
     if (lane == 0 && lost) atomicAdd(&stats->part_lost, lost);
 }
@@ -792,18 +808,23 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
  * the empty slot, :96-98), is marked SHARED: its whole tile is flushed with atomic adds.  Found once
  * per context; bit 1 of *found: a run too long to follow (the direct kernel counts that table). */
 constexpr uint32_t kRunFollow = 1u << 20;
-__global__ void long_run_kernel(const uint64_t *keys, uint64_t H, uint32_t limit, uint32_t lg_s, uint32_t *shared,
-                                unsigned int *found)
+/* keys: the resident slots (slot0 first, n_slots of them); buckets are numbered from slot range_lo */
+__global__ void long_run_kernel(const uint64_t *keys, uint64_t n_slots, uint64_t slot0, uint64_t range_lo, uint64_t n_buckets,
+                                uint32_t limit, uint32_t lg_s, uint32_t *shared, unsigned int *found)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < H; i += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) {
         if (keys[i] == 0) continue;
         if (i != 0 && keys[i - 1] != 0) continue;             /* not the start of a run */
         uint64_t len = 1;
-        while (len < kRunFollow && i + len < H && keys[i + len] != 0) len++;
+        while (len < kRunFollow && i + len < n_slots && keys[i + len] != 0) len++;
         if (len < limit) continue;
         if (len >= kRunFollow) { atomicOr(found, 2u); continue; }
         atomicOr(found, 1u);
-        const uint64_t lo = (i ? i - 1 : 0) >> lg_s, hi = (i + len < H ? i + len : H - 1) >> lg_s;
+        /* the slots before / behind the run included; buckets exist for [range_lo, range_lo + (n_buckets << lg_s)) only */
+        const uint64_t s_lo = slot0 + (i ? i - 1 : 0), s_hi = slot0 + (i + len < n_slots ? i + len : n_slots - 1);
+        const uint64_t r_hi = range_lo + (n_buckets << lg_s);
+        if (s_hi < range_lo || s_lo >= r_hi) continue;
+        const uint64_t lo = (s_lo > range_lo ? s_lo - range_lo : 0) >> lg_s, hi = ((s_hi < r_hi ? s_hi : r_hi - 1) - range_lo) >> lg_s;
         for (uint64_t b = lo; b <= hi; b++) atomicOr(&shared[b >> 5], 1u << (b & 31));
     }
 }

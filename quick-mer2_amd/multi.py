@@ -10,10 +10,12 @@ increments, so both are exact:
       of the counters at the end.
 
   ShardedJob  (E2, BASELINE config 4)  the table is range-partitioned by the
-      high bits of the home slot; each rank encodes its share of the reads,
-      buckets the k-mers by owner (qm2_encode_device), exchanges them with one
-      all-to-all per batch, and probes what it receives against its own span
-      (qm2_probe_device).  A span = the owned range plus the run of occupied
+      high bits of the home slot; each rank encodes its share of the reads and
+      buckets the k-mers by owner into fixed-capacity slabs (qm2_route_device),
+      exchanges fills and slabs with asynchronous all-to-alls while the next
+      batch is already being encoded, and probes what it receives against its
+      own span with the partitioned pipeline (qm2_probe_slabs_device).  A span =
+      the owned range plus the run of occupied
       slots past its middle-facing edge (qm2_shard_span), so every probe walk
       stays local; counts that land in that overhang are folded into the
       neighbour that owns those slots at the end.
@@ -44,16 +46,30 @@ def rank_slice(buf, rank, world):
 
 
 class HipEngine:
-    """The product's compute legs on one GPU (device pointers are torch tensors' data_ptr())."""
+    """The product's compute legs on one GPU (device pointers are torch tensors' data_ptr()).
+
+    Two HIP streams per rank: the ROUTER stream carries encode + bucket-by-owner (qm2_route_device) and
+    the collectives that follow it; the PROBER stream carries the probe of what has arrived
+    (qm2_probe_slabs_device).  The prober waits for an exchange through its work handle, the router never
+    does: while batch i is on the wire and being probed, batch i+1 is already being encoded."""
 
     def __init__(self, torch, device):
         self.torch = torch
         self.device = device
+        self.s_route = torch.cuda.Stream(device)
+        self.s_probe = torch.cuda.Stream(device)
 
-    def open(self, keys_span, hash_size, k, span, counters):
+    def open(self, keys_span, hash_size, k, span, counters, own=None, ext_keys=None, flags=0):
+        """keys_span: host keys of the span, or None with ext_keys = device pointer to them"""
         self._torch_done()
-        return pyqm2.Counter(keys_span, hash_size=hash_size, k=k, device=self.device.index or 0,
-                             span=span, ext_counters=counters.data_ptr())
+        return pyqm2.Counter(keys_span, hash_size=hash_size, k=k, device=self.device.index or 0, flags=flags,
+                             span=span, own=own, ext_counters=counters.data_ptr(), ext_keys=ext_keys,
+                             stream=self.s_probe.cuda_stream if span is not None else None)
+
+    def open_router(self, hash_size, k, flags=0):
+        """A context that only encodes and routes (no table: a 64-slot stand-in span)."""
+        return pyqm2.Counter(None, hash_size=hash_size, k=k, device=self.device.index or 0, flags=pyqm2.FLAG_KEYS_LATER | flags,
+                             span=(0, min(64, hash_size)), stream=self.s_route.cuda_stream)
 
     def new_counters(self, n):
         return self.torch.zeros(n, dtype=self.torch.int32, device=self.device)
@@ -71,25 +87,40 @@ class HipEngine:
         ctx.submit_device(d_lines.data_ptr(), d_lines.numel())
         ctx.sync()
 
-    def encode(self, ctx, d_lines, n_buckets):
-        """-> (kmers int64[n_buckets * cap] on device, fills int64[n_buckets] on device, cap)"""
-        t = self.torch
-        n = d_lines.numel()
-        # uniform hashing spreads the <= n k-mers evenly over the owners: 30 % head-room per bucket
-        # (a bucket that still overflows is reported by the library as an error, never dropped silently)
-        cap = max(16, n if n_buckets == 1 else int(n / n_buckets * 1.3) + 4096)
-        out = t.empty(n_buckets * cap, dtype=t.int64, device=self.device)
-        fills = t.zeros(n_buckets, dtype=t.int64, device=self.device)
-        self._torch_done()
-        ctx.encode_device(d_lines.data_ptr(), d_lines.numel(), out.data_ptr(), cap, n_buckets, fills.data_ptr())
-        ctx.sync()
-        return out, fills, cap
+    def on_router(self):
+        return self.torch.cuda.stream(self.s_route)
 
-    def probe(self, ctx, d_kmers):
-        if d_kmers.numel():
-            self._torch_done()
-            ctx.probe_device(d_kmers.data_ptr(), d_kmers.numel())
-            ctx.sync()
+    def route(self, rctx, d_lines, n_owners, cap):
+        """-> (slabs int64[n_owners * cap], fill int32[n_owners], call int64[3] = bases, k-mers, not fitted),
+        all on the device, produced on the router stream (the caller is inside on_router())."""
+        t = self.torch
+        slabs = t.empty(n_owners * cap, dtype=t.int64, device=self.device)
+        fill = t.zeros(n_owners, dtype=t.int32, device=self.device)
+        call = t.zeros(3, dtype=t.int64, device=self.device)
+        if d_lines is not None and d_lines.numel():
+            rctx.route_device(d_lines.data_ptr(), d_lines.numel(), slabs.data_ptr(), cap, n_owners, fill.data_ptr(),
+                              call.data_ptr())
+        return slabs, fill, call
+
+    def probe_after(self, ctx, works, slabs, cap, n_slabs, fill):
+        """Probe the received slabs once the exchanges `works` have completed — on the prober stream."""
+        with self.torch.cuda.stream(self.s_probe):
+            for w in works:
+                if w is not None:
+                    w.wait()                    # the prober stream waits; the host and the router stream do not
+            ctx.probe_slabs_device(slabs.data_ptr(), cap, n_slabs, fill.data_ptr())
+
+    def split_lines(self, d_lines):
+        """Two halves of a device text buffer, cut behind a line end."""
+        n = d_lines.numel()
+        nl = (d_lines[n // 2:] == 10).nonzero()
+        cut = n // 2 + int(nl[0]) + 1 if nl.numel() else n
+        return d_lines[:cut], d_lines[cut:]
+
+    def drain(self, ctx):
+        self.s_route.synchronize()
+        self.s_probe.synchronize()
+        ctx.sync()
 
 
 class ReplicaJob:
@@ -121,49 +152,119 @@ class ReplicaJob:
 
     def close(self):
         self.ctx.close()
+        if getattr(self, "rctx", None) is not None:
+            self.rctx.close()
 
 
 class ShardedJob:
-    """E2: table range-partitioned by home slot; k-mers routed by all-to-all."""
+    """E2: table range-partitioned by home slot; k-mers routed by all-to-all in fixed-capacity slabs.
 
-    def __init__(self, dist, engine, keys, k, torch):
+    Per batch and rank: route (encode + bucket by owner, device-side fills) -> ONE small all-reduce that
+    makes the "did every slab fit" decision collective -> all-to-all of the fills and of the slabs
+    (fixed size: no host-side split sizes, no device-to-host copy of counts) -> probe of the received
+    slabs with their device-side fills.  The collectives and the probe are asynchronous; the only thing
+    the host ever waits for is the one-word fit flag of the batch it is about to send.  A batch that
+    does not fit (skewed input: poly-A sends everything to one owner) is cut in two behind a line end
+    and routed again, by every rank alike — exact for any input, never an error and never a hang.
+    Every rank must call count / count_local the same number of times (an empty call is fine)."""
+
+    def __init__(self, dist, engine, keys, k, torch, batch_bytes=None, resident=None, flags=0):
+        """keys: the host key table; or None with resident = (H, (own_lo, own_hi, lo, hi), device pointer to the
+        span's keys) when the table is already on the device (bench.py)."""
         self.dist, self.engine, self.torch = dist, engine, torch
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         assert self.world & (self.world - 1) == 0, "shard count must be a power of two"
-        self.H, self.k = len(keys), k
-        self.own_lo, self.own_hi, self.lo, self.hi = pyqm2.shard_span(keys, self.world, self.rank)
+        self.k = k
+        if resident is None:
+            self.H = len(keys)
+            self.own_lo, self.own_hi, self.lo, self.hi = pyqm2.shard_span(keys, self.world, self.rank)
+        else:
+            self.H, (self.own_lo, self.own_hi, self.lo, self.hi) = resident[0], resident[1]
         self.counters = engine.new_counters(self.hi - self.lo)
-        # the encoder needs no table; the prober holds only this rank's span
-        self.ctx = engine.open(np.ascontiguousarray(keys[self.lo:self.hi]), self.H, k,
-                               (self.lo, self.hi), self.counters)
+        # the router needs no table; the prober holds only this rank's span
+        if resident is None:
+            self.ctx = engine.open(np.ascontiguousarray(keys[self.lo:self.hi]), self.H, k, (self.lo, self.hi), self.counters,
+                                   own=(self.own_lo, self.own_hi))
+            self.rctx = engine.open_router(self.H, k)
+        else:
+            self.ctx = engine.open(None, self.H, k, (self.lo, self.hi), self.counters, own=(self.own_lo, self.own_hi),
+                                   ext_keys=resident[2], flags=flags)
+            self.rctx = engine.open_router(self.H, k, flags=flags)
+        self.batch_bytes = int(batch_bytes) if batch_bytes else 1 << 26
+        # a slab takes a rank's share of one batch with 30 % head-room (uniform hashing spreads the k-mers evenly)
+        self.cap = (int(self.batch_bytes / self.world * 1.3) + 64) & ~1
+        self.n_bases = self.n_kmers = 0
+        self.rounds = self.retries = 0
+        self._keep = []                       # buffers of the rounds still in flight
+        self._totals = []                     # device-side {bases, k-mers} of the accepted rounds
 
     def count(self, lines: bytes):
         a, b = rank_slice(lines, self.rank, self.world)
         self.count_local(self.engine.to_device(lines[a:b]) if b > a else None)
 
     def count_local(self, d_lines):
-        t, dist, W = self.torch, self.dist, self.world
-        if d_lines is not None and d_lines.numel():
-            out, fills, cap = self.engine.encode(self.ctx, d_lines, W)
-        else:
-            cap = 16
-            out = t.empty(W * cap, dtype=t.int64, device=self.counters.device)
-            fills = t.zeros(W, dtype=t.int64, device=self.counters.device)
-        # 1) tell every peer how many k-mers it is about to get
-        incoming = t.empty_like(fills)
-        dist.all_to_all_single(incoming, fills)
-        send = [int(x) for x in fills.cpu()]
-        recv = [int(x) for x in incoming.cpu()]
-        # 2) the k-mers themselves: one all-to-all of ragged int64 slabs
-        packed = t.cat([out[g * cap:g * cap + send[g]] for g in range(W)]) if sum(send) else out[:0]
-        got = t.empty(sum(recv), dtype=t.int64, device=out.device)
-        dist.all_to_all_single(got, packed, output_split_sizes=recv, input_split_sizes=send)
-        # 3) probe + increment locally
-        self.engine.probe(self.ctx, got)
+        t, dist = self.torch, self.dist
+        n = d_lines.numel() if d_lines is not None else 0
+        # the same number of rounds on every rank: the largest share decides
+        rounds = t.tensor([(n + self.batch_bytes - 1) // self.batch_bytes], dtype=t.int64, device=self.counters.device)
+        dist.all_reduce(rounds, op=dist.ReduceOp.MAX)
+        rounds = max(1, int(rounds.item()))
+        pieces = [d_lines] if rounds == 1 else self._cut(d_lines, rounds)
+        for piece in pieces:
+            self._round(piece)
+
+    def _cut(self, d_lines, rounds):
+        out, rest = [], d_lines
+        for left in range(rounds, 1, -1):
+            if rest is None or rest.numel() == 0:
+                out.append(None)
+                continue
+            n = rest.numel()
+            want = (n + left - 1) // left
+            nl = (rest[want - 1:] == 10).nonzero()
+            cut = want + int(nl[0]) if nl.numel() else n
+            out.append(rest[:cut])
+            rest = rest[cut:]
+        out.append(rest)
+        return out
+
+    def _round(self, d_lines, depth=0):
+        t, dist, W, eng = self.torch, self.dist, self.world, self.engine
+        have = d_lines is not None and d_lines.numel() > 0
+        self.rounds += 1
+        with eng.on_router():
+            slabs, fill, call = eng.route(self.rctx, d_lines if have else None, W, self.cap)
+            # collective decision: did every slab on every rank take what was routed to it?
+            unfit = call[2:3].clone()
+            dist.all_reduce(unfit, op=dist.ReduceOp.MAX)
+            fits = int(unfit.item()) == 0
+            if fits:
+                incoming = t.empty_like(fill)
+                w1 = dist.all_to_all_single(incoming, fill, async_op=True)
+                recv = t.empty_like(slabs)
+                w2 = dist.all_to_all_single(recv, slabs, async_op=True)
+                self._totals.append(call)
+        if not fits:
+            # every rank takes this branch together; a piece of at most `cap` bytes cannot overflow a slab
+            assert depth < 48, "a batch keeps overflowing its slabs"
+            self.retries += 1
+            halves = eng.split_lines(d_lines) if have else (None, None)
+            self._round(halves[0], depth + 1)
+            self._round(halves[1], depth + 1)
+            return
+        eng.probe_after(self.ctx, (w1, w2), recv, self.cap, W, incoming)
+        self._keep.append((slabs, fill, recv, incoming, d_lines))
+        del self._keep[:-3]                   # (older rounds have been probed: their buffers may go)
 
     def finish(self):
         """-> uint16[H] on every rank, assembled from the owners' slices."""
         t, dist, W = self.torch, self.dist, self.world
+        self.engine.drain(self.ctx)
+        self._keep = []
+        for call in self._totals:
+            self.n_bases += int(call[0])
+            self.n_kmers += int(call[1])
+        self._totals = []
         c = self.counters
         owned = c[self.own_lo - self.lo:self.own_hi - self.lo].clone()
         # overhang past the middle-facing edge belongs to the next shard towards the middle
@@ -194,3 +295,5 @@ class ShardedJob:
 
     def close(self):
         self.ctx.close()
+        if getattr(self, "rctx", None) is not None:
+            self.rctx.close()

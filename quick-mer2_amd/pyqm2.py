@@ -26,7 +26,7 @@ class Opts(C.Structure):
                 ("n_staging", C.c_uint32), ("staging_bytes", C.c_uint64), ("batch_bytes", C.c_uint64),
                 ("part_max_bits", C.c_uint32), ("reserved0", C.c_uint32),
                 ("ext_keys", C.c_void_p), ("ext_counters", C.c_void_p), ("stream", C.c_void_p),
-                ("span_lo", C.c_uint64), ("span_hi", C.c_uint64)]
+                ("span_lo", C.c_uint64), ("span_hi", C.c_uint64), ("own_lo", C.c_uint64), ("own_hi", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -53,7 +53,7 @@ class Dup(C.Structure):
 
 
 # every symbol include/qm2.h and include/qm2_tools.h declare
-ABI_SYMBOLS = ["qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
+ABI_SYMBOLS = ["qm2_route_device", "qm2_probe_slabs_device", "qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
                "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_submit_raw_device", "qm2_staging_commit_raw", "qm2_raw_verdict",
                "qm2_shard_span", "qm2_last_error",
@@ -115,6 +115,10 @@ def lib():
     L.qm2_encode_device.argtypes = [vp, vp, C.c_size_t, vp, u64, vp, u64, u32, vp]
     L.qm2_probe_device.restype = C.c_int
     L.qm2_probe_device.argtypes = [vp, vp, u64, vp]
+    L.qm2_route_device.restype = C.c_int
+    L.qm2_route_device.argtypes = [vp, vp, C.c_size_t, vp, u64, vp, u64, u32, vp, vp]
+    L.qm2_probe_slabs_device.restype = C.c_int
+    L.qm2_probe_slabs_device.argtypes = [vp, vp, u64, u32, vp]
     L.qm2_chain_gather.restype = C.c_int
     L.qm2_chain_gather.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.qm2_submit_raw_device.restype = C.c_int
@@ -162,7 +166,7 @@ class Counter:
     """One counting context (qm2_ctx).  keys: host uint64[H] (or None with ext_keys)."""
 
     def __init__(self, keys, hash_size=None, k=30, device=-1, flags=0, n_staging=0, staging_bytes=0,
-                 batch_bytes=0, part_max_bits=0, ext_keys=None, ext_counters=None, stream=None, span=None):
+                 batch_bytes=0, part_max_bits=0, ext_keys=None, ext_counters=None, stream=None, span=None, own=None):
         L = lib()
         self._h = C.c_void_p()
         o = Opts()
@@ -178,6 +182,8 @@ class Counter:
         o.stream = stream
         if span is not None:
             o.span_lo, o.span_hi = int(span[0]), int(span[1])
+        if own is not None:
+            o.own_lo, o.own_hi = int(own[0]), int(own[1])
         kp = None
         if keys is not None:
             keys = np.ascontiguousarray(keys, dtype=np.uint64)
@@ -252,6 +258,13 @@ class Counter:
     def encode_device(self, ptr, n, out_ptr, bucket_cap, n_buckets, counts_ptr, suppress_ptr=None, n_suppress=0):
         _check(lib().qm2_encode_device(self._h, ptr, n, suppress_ptr, n_suppress, out_ptr, bucket_cap,
                                        n_buckets, counts_ptr), "qm2_encode_device")
+
+    def route_device(self, ptr, n, slabs_ptr, slab_cap, n_owners, fill_ptr, call_ptr, suppress_ptr=None, n_suppress=0):
+        _check(lib().qm2_route_device(self._h, ptr, n, suppress_ptr, n_suppress, slabs_ptr, slab_cap, n_owners, fill_ptr,
+                                      call_ptr), "qm2_route_device")
+
+    def probe_slabs_device(self, slabs_ptr, slab_cap, n_slabs, fill_ptr):
+        _check(lib().qm2_probe_slabs_device(self._h, slabs_ptr, slab_cap, n_slabs, fill_ptr), "qm2_probe_slabs_device")
 
     def probe_device(self, kmers_ptr, n, n_ptr=None):
         _check(lib().qm2_probe_device(self._h, kmers_ptr, n, n_ptr), "qm2_probe_device")

@@ -689,6 +689,72 @@ def test_encode_then_probe_equals_fused(qm2, torch_cuda, tmp_path):
         assert np.array_equal(total.astype(np.uint16), exp_depth)
 
 
+def test_route_then_probe_slabs_equals_fused(qm2, torch_cuda, tmp_path):
+    """The multi-GPU driver's two legs (qm2_route_device: encode + bucket by owner into fixed slabs;
+    qm2_probe_slabs_device: a shard's span probed with the partitioned pipeline) on 1 / 2 / 4 / 8 logical
+    shards of the mini table, slabs from two "senders": counters, hits and probes equal the oracle's;
+    a slab that is too small reports what did not fit instead of dropping it silently."""
+    torch = torch_cuda
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    keys, H = qm["keys"], len(qm["keys"])
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    blob = ol.strip_reads(rfa)
+    half = blob.rfind(b"\n", 0, len(blob) // 2) + 1
+    parts = [blob[:half], blob[half:]]
+    exp_kmers, nb = ol.extract(blob, 30)
+    exp_depth, exp_st = ol.count_lines(keys, 30, blob)
+    dparts = [torch.frombuffer(bytearray(x), dtype=torch.uint8).cuda() for x in parts]
+    for G in (1, 2, 4, 8):
+        cap = (len(exp_kmers) * 2 // 3 + 64) & ~1
+        spans = [qm2.shard_span(keys, G, g) for g in range(G)]
+        routed = []
+        with qm2.Counter(None, hash_size=H, k=30, flags=qm2.FLAG_KEYS_LATER, span=(0, 64)) as router:
+            for d in dparts:
+                slabs = torch.zeros(G * cap, dtype=torch.int64, device="cuda")
+                fill = torch.zeros(G, dtype=torch.int32, device="cuda")
+                call = torch.zeros(3, dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()
+                router.route_device(d.data_ptr(), d.numel(), slabs.data_ptr(), cap, G, fill.data_ptr(), call.data_ptr())
+                router.sync()
+                routed.append((slabs, fill, call))
+            assert router.finish(want_depth=False)[1]["n_kmers"] == 0        # the context's own statistics stay out of it
+        assert sum(int(r[2][0]) for r in routed) == nb and sum(int(r[2][1]) for r in routed) == len(exp_kmers)
+        assert all(int(r[2][2]) == 0 for r in routed)
+        got = np.concatenate([r[0][g * cap:g * cap + int(r[1][g])].cpu().numpy().view(np.uint64) for r in routed for g in range(G)])
+        assert np.array_equal(np.sort(got), np.sort(exp_kmers))
+        for flags in (qm2.FLAG_PARTITION, qm2.FLAG_DIRECT):
+            total = np.zeros(H, dtype=np.uint64)
+            hits = probes = 0
+            for g, (own_lo, own_hi, lo, hi) in enumerate(spans):
+                # what shard g receives: slab g of every sender, side by side
+                recv = torch.cat([r[0][g * cap:(g + 1) * cap] for r in routed])
+                rfill = torch.stack([r[1][g] for r in routed]).contiguous()
+                torch.cuda.synchronize()
+                with qm2.Counter(keys[lo:hi], hash_size=H, k=30, span=(lo, hi), own=(own_lo, own_hi) if G > 1 else None,
+                                 flags=flags | qm2.FLAG_TIMING) as pc:
+                    pc.probe_slabs_device(recv.data_ptr(), cap, len(routed), rfill.data_ptr())
+                    d, st = pc.finish()
+                    prof = pc.profile()
+                if flags == qm2.FLAG_PARTITION and hi - lo >= 2 * 4096:
+                    assert prof["partitioned_batches"] == 1 and prof["class_launches"]["bucket_count"] == 1, (G, g)
+                total[lo:hi] += d
+                hits += st["n_hits"]
+                probes += st["n_probes"]
+            assert hits == exp_st["n_hits"] and probes == exp_st["n_probes"], (G, flags)
+            assert np.array_equal(total.astype(np.uint16), exp_depth), (G, flags)
+    # too small a slab: the fill says what was routed, d_call[2] what did not fit
+    small = 1000
+    slabs = torch.zeros(2 * small, dtype=torch.int64, device="cuda")
+    fill = torch.zeros(2, dtype=torch.int32, device="cuda")
+    call = torch.zeros(3, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    with qm2.Counter(None, hash_size=H, k=30, flags=qm2.FLAG_KEYS_LATER, span=(0, 64)) as router:
+        router.route_device(dparts[0].data_ptr(), dparts[0].numel(), slabs.data_ptr(), small, 2, fill.data_ptr(), call.data_ptr())
+        router.sync()
+    n0 = len(ol.extract(parts[0], 30)[0])
+    assert int(fill.sum()) == n0 and int(call[2]) == n0 - 2 * small and int(call[1]) == n0
+
+
 def test_multi_drivers_on_the_gpu_single_rank(qm2, torch_cuda, tmp_path):
     """quick-mer2_amd/multi.py with the real HipEngine and the RCCL backend (world size 1 is all a
     one-GPU box allows; ranks > 1 run under gloo in tests/test_multi_gloo.py): init, all_reduce,
@@ -1024,10 +1090,11 @@ def test_c5_hifi_reads_at_hg38_scale(qm2, torch_cuda, hg38_scale):
 
 def test_c4_eight_logical_shards_at_hg38_scale(qm2, torch_cuda, hg38_scale):
     """C4's shape without 8 GPUs: the H = 2^32 table cut into 8 hash-range
-    shards; qm2_encode_device buckets the k-mers of the C3 stream by owner, every shard probes its
-    bucket against its own span (qm2_shard_span: owned range + the run of occupied slots past the
-    middle-facing edge, QuicKmer.c:90-99) in its own context, overhang counts are folded into the
-    neighbour that owns those slots — and all 4 G counters equal the single-context result."""
+    shards; qm2_route_device buckets the k-mers of the C3 stream by owner into fixed slabs, every shard
+    probes its slab against its own span (qm2_shard_span: owned range + the run of occupied slots past
+    the middle-facing edge, QuicKmer.c:90-99) with the PARTITIONED pipeline in its own context, overhang
+    counts are folded into the neighbour that owns those slots — and all 4 G counters, the hits and the
+    probes equal the single-context result."""
     torch, env = torch_cuda, hg38_scale
     H, k, keys, reads, truth, sd = env["H"], env["k"], env["keys"], env["reads"], env["direct"], env["direct_stats"]
     G, per = 8, H // 8
@@ -1039,18 +1106,19 @@ def test_c4_eight_logical_shards_at_hg38_scale(qm2, torch_cuda, hg38_scale):
         sparse[e - W:e + W] = keys[e - W:e + W].cpu().numpy().view(np.uint64)
     spans = [qm2.shard_span(sparse, G, g) for g in range(G)]
     for own_lo, own_hi, lo, hi in spans:
-        assert own_lo - lo < W - 1 and hi - own_hi < W - 1      # every walk ended inside the copied window
+        assert own_lo - lo < W - 64 and hi - own_hi < W - 64      # every walk ended inside the copied window
     del sparse
     n_km = sd["n_kmers"]
-    cap = int(n_km / G * 1.05) + 65536
-    out = torch.empty(G * cap, dtype=torch.int64, device="cuda")
-    fills = torch.zeros(G, dtype=torch.int64, device="cuda")
+    cap = (int(n_km / G * 1.05) + 65536) & ~1
+    slabs = torch.empty(G * cap, dtype=torch.int64, device="cuda")
+    fill = torch.zeros(G, dtype=torch.int32, device="cuda")
+    call = torch.zeros(3, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
-    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr()) as enc:
-        enc.encode_device(reads.data_ptr(), reads.numel(), out.data_ptr(), cap, G, fills.data_ptr())
-        _, se = enc.finish(want_depth=False)
-    assert se["n_kmers"] == n_km and se["n_bases"] == sd["n_bases"]
-    fl = [int(x) for x in fills.cpu()]
+    with qm2.Counter(None, hash_size=H, k=k, flags=qm2.FLAG_KEYS_LATER, span=(0, 64)) as router:
+        router.route_device(reads.data_ptr(), reads.numel(), slabs.data_ptr(), cap, G, fill.data_ptr(), call.data_ptr())
+        router.sync()
+    assert [int(x) for x in call] == [sd["n_bases"], n_km, 0]
+    fl = [int(x) for x in fill.cpu()]
     assert sum(fl) == n_km and max(fl) < cap
     full = torch.zeros(H, dtype=torch.int32, device="cuda")
     hits = probes = 0
@@ -1058,9 +1126,11 @@ def test_c4_eight_logical_shards_at_hg38_scale(qm2, torch_cuda, hg38_scale):
         cnt = torch.zeros(hi - lo, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr() + 8 * lo, ext_counters=cnt.data_ptr(),
-                         span=(lo, hi)) as pc:
-            pc.probe_device(out.data_ptr() + 8 * g * cap, fl[g], fills.data_ptr() + 8 * g)
+                         span=(lo, hi), own=(own_lo, own_hi), flags=qm2.FLAG_TIMING) as pc:
+            pc.probe_slabs_device(slabs.data_ptr() + 8 * g * cap, cap, 1, fill.data_ptr() + 4 * g)
             _, s = pc.finish(want_depth=False)
+            prof = pc.profile()
+        assert prof["partitioned_batches"] == 1 and prof["fallback_batches"] == 0    # a shard is counted like a table
         hits += s["n_hits"]
         probes += s["n_probes"]
         # owned slots and overhang alike: slot lo + i of the table (the fold of ShardedJob.finish)

@@ -30,12 +30,18 @@ class OracleEngine:
     class Ctx:
         pass
 
-    def open(self, keys_span, hash_size, k, span, counters):
+    def open(self, keys_span, hash_size, k, span, counters, own=None):
         c = self.Ctx()
         c.keys = np.ascontiguousarray(keys_span, dtype=np.uint64)
         c.H, c.k = hash_size, k
         c.lo = 0 if span is None else span[0]
         c.counters = counters
+        c.close = lambda: None
+        return c
+
+    def open_router(self, hash_size, k):
+        c = self.Ctx()
+        c.H, c.k = hash_size, k
         c.close = lambda: None
         return c
 
@@ -68,24 +74,49 @@ class OracleEngine:
         kmers, _ = self.ol.extract(d_lines.numpy().tobytes(), c.k)
         self._probe_np(c, kmers)
 
-    def encode(self, c, d_lines, n_buckets):
-        kmers, _ = self.ol.extract(d_lines.numpy().tobytes(), c.k)
+    def on_router(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def route(self, c, d_lines, n_owners, cap):
+        """the contract of qm2_route_device: fixed slabs, fill = what was ROUTED, call = bases, k-mers, not fitted"""
+        slabs = torch.zeros(n_owners * cap, dtype=torch.int64)
+        fill = torch.zeros(n_owners, dtype=torch.int32)
+        call = torch.zeros(3, dtype=torch.int64)
+        if d_lines is None or d_lines.numel() == 0:
+            return slabs, fill, call
+        kmers, nb = self.ol.extract(d_lines.numpy().tobytes(), c.k)
         L = self.ol.lib()
         lgH = int(np.log2(c.H))
-        shift = lgH - int(np.log2(n_buckets))
+        shift = lgH - int(np.log2(n_owners))
         owner = np.array([(L.qm2o_djb(int(x)) & (c.H - 1)) >> shift for x in kmers], dtype=np.int64) \
-            if n_buckets > 1 else np.zeros(len(kmers), dtype=np.int64)
-        cap = max(16, d_lines.numel())
-        out = torch.zeros(n_buckets * cap, dtype=torch.int64)
-        fills = torch.zeros(n_buckets, dtype=torch.int64)
-        for g in range(n_buckets):
+            if n_owners > 1 else np.zeros(len(kmers), dtype=np.int64)
+        lost = 0
+        for g in range(n_owners):
             sel = kmers[owner == g].view(np.int64)
-            out[g * cap:g * cap + len(sel)] = torch.from_numpy(sel.copy())
-            fills[g] = len(sel)
-        return out, fills, cap
+            fill[g] = len(sel)
+            keep = min(len(sel), cap)
+            lost += len(sel) - keep
+            slabs[g * cap:g * cap + keep] = torch.from_numpy(sel[:keep].copy())
+        call[0], call[1], call[2] = nb, len(kmers), lost
+        return slabs, fill, call
 
-    def probe(self, c, d_kmers):
-        self._probe_np(c, d_kmers.numpy().view(np.uint64))
+    def probe_after(self, c, works, slabs, cap, n_slabs, fill):
+        for w in works:
+            if w is not None:
+                w.wait()
+        for g in range(n_slabs):
+            n = min(int(fill[g]), cap)
+            self._probe_np(c, slabs[g * cap:g * cap + n].numpy().view(np.uint64))
+
+    def split_lines(self, d_lines):
+        b = d_lines.numpy().tobytes()
+        cut = b.find(b"\n", len(b) // 2)
+        cut = len(b) if cut < 0 else cut + 1
+        return d_lines[:cut], d_lines[cut:]
+
+    def drain(self, c):
+        pass
 
 
 def _free_port():
@@ -96,7 +127,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, qm_path, lines, out_dir):
+def _worker(rank, world, port, mode, qm_path, lines, out_dir, batch_bytes=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -109,12 +140,14 @@ def _worker(rank, world, port, mode, qm_path, lines, out_dir):
     if mode == "replica":
         job = multi.ReplicaJob(dist, eng, qm["keys"], qm["k"])
     else:
-        job = multi.ShardedJob(dist, eng, qm["keys"], qm["k"], torch)
+        job = multi.ShardedJob(dist, eng, qm["keys"], qm["k"], torch, batch_bytes=batch_bytes)
     half = lines.rfind(b"\n", 0, len(lines) // 2) + 1
     job.count(lines[:half])              # two "batches"
     job.count(lines[half:])
     depth = job.finish()
     np.save(os.path.join(out_dir, "depth_%s_%d.npy" % (mode, rank)), depth)
+    if mode == "sharded":
+        np.save(os.path.join(out_dir, "info_%d.npy" % rank), np.array([job.rounds, job.retries, job.n_bases, job.n_kmers]))
     job.close()
     dist.destroy_process_group()
 
@@ -134,6 +167,36 @@ def test_multi_rank_counts_equal_single_process(mode, world, tmp_path):
     for r in range(world):
         got = np.load(str(tmp_path / ("depth_%s_%d.npy" % (mode, r))))
         assert np.array_equal(got, exp), (mode, world, r)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_skewed_input_is_cut_and_rerouted_not_hung(world, tmp_path):
+    """Poly-A (every k-mer goes to ONE owner) with slabs sized for an even spread: the ranks decide
+    together that the batch does not fit, cut it and route it again — exact counts, no error, no hang
+    (round 1 raised on one rank only and left the others in the collective).  Small batches also
+    exercise the several-rounds-per-call path."""
+    import oracle_lib as ol
+    import synth
+    qm_path = os.path.join(HERE, "golden", "kat", "ref.fa.qm")
+    qm = ol.load_qm(qm_path)
+    cases = synth.kat_cases(synth.kat_reference())
+    p = tmp_path / "r.fa"
+    poly = b"".join(b">a\n" + b"A" * 150 + b"\n" for _ in range(300))          # 45 kb of k-mer 0: one owner gets it all
+    p.write_bytes(poly + cases["reads_fa"][1][:40_000] + b"\n" + poly)
+    lines = ol.strip_reads(str(p))
+    exp, exp_st = ol.count_lines(qm["keys"], qm["k"], lines)
+    mp.spawn(_worker, args=(world, _free_port(), "sharded", qm_path, lines, str(tmp_path), 6000), nprocs=world, join=True)
+    retries = 0
+    bases = kmers = 0
+    for r in range(world):
+        got = np.load(str(tmp_path / ("depth_sharded_%d.npy" % r)))
+        assert np.array_equal(got, exp), (world, r)
+        info = np.load(str(tmp_path / ("info_%d.npy" % r)))
+        retries += int(info[1])
+        bases += int(info[2])
+        kmers += int(info[3])
+    assert retries > 0                                  # the skew did overflow the slabs
+    assert bases == exp_st["n_bases"] and kmers == exp_st["n_kmers"]   # nothing counted twice, nothing lost
 
 
 def test_rank_slices_partition_the_stream():
