@@ -5,18 +5,24 @@
  * the end (:335, :338, :342), same stdout lines, same output files.
  */
 #define _GNU_SOURCE
+#include <getopt.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
 
+#include "qm2_dispatch.h"
 #include "qm2_host.h"
+
+#define QM2_MAX_DEVICES 16
 
 static void help_count(void)
 {
     puts("\nquicKmer2 count [Options] ref.fa sample.fast[a/q] Out_prefix\n\nOptions:");   /* :299 */
     puts("-h\t\tShow this help information");
     puts("-t [num]\tNumber of threads");
+    puts("--devices a,b,..\tGPUs to count on (a replica of the dictionary on each, the reads dealt to them a device");
+    puts("\t\tbatch at a time, the counts summed on the first); default: the current device");
 }
 
 /* The reference prints `Read %liG kmers` whenever its k-mer count reaches a multiple of 2^30 (:446).
@@ -28,11 +34,19 @@ static void progress_upto(uint64_t n_kmers)
 {
     while (progress_printed_g < (n_kmers >> 30)) printf("Read %liG kmers\n", (long)++progress_printed_g);
 }
+static qm2_ctx *progress_ctx[QM2_MAX_DEVICES];
+static int progress_n;
 static void progress_peek(qm2_ctx *ctx)
 {
-    qm2_stats st;
-    if (qm2_stats_peek(ctx, &st) == 0) progress_upto(st.n_kmers);
+    (void)ctx;
+    uint64_t total = 0;
+    for (int i = 0; i < progress_n; i++) {
+        qm2_stats st;
+        if (qm2_stats_peek(progress_ctx[i], &st) == 0) total += st.n_kmers;
+    }
+    progress_upto(total);
 }
+static int out_flush(void *user) { return qm2_flush((qm2_ctx *)user); }
 
 static int out_acquire(void *user, char **buf, size_t *cap) { return qm2_staging_acquire((qm2_ctx *)user, buf, cap); }
 static int out_commit(void *user, char *buf, size_t n)
@@ -52,6 +66,58 @@ static int out_commit_raw(void *user, char *buf, size_t offset, size_t n, int fa
     return qm2_raw_verdict((qm2_ctx *)user) ? 2 : 0;       /* refused: no point in reading on */
 }
 
+/* --devices a,b,...: a replica of the dictionary on every listed GPU (the same ordinal may be listed
+ * twice: two contexts on one GPU), one reader, the sequence lines dealt to the contexts a device batch at
+ * a time (qm2_dispatch.c), the counters summed into the first context before the epilogue.  The host
+ * strips the input here (the device line discipline numbers the lines of consecutive text, which turns
+ * do not give it).  On return ctxs[0] holds the job's counters and *st its totals. */
+static int count_on_devices(qm2_dict_file *d, const char *reads, int n_strip, const int *devices, int n_dev,
+                            qm2_ctx **ctxs, qm2_stats *st, int timing)
+{
+    qm2_sink sinks[QM2_MAX_DEVICES];
+    struct timespec ta, tb;
+    clock_gettime(CLOCK_MONOTONIC, &ta);
+    size_t turn = 0;
+    for (int i = 0; i < n_dev; i++) {
+        qm2_opts o;
+        memset(&o, 0, sizeof o);
+        o.struct_size = sizeof o;
+        o.device = devices[i];
+        o.flags = QM2_FLAG_KEYS_LATER;
+        o.n_staging = (uint32_t)n_strip + 3;
+        if (qm2_open(&ctxs[i], NULL, d->hash_size, d->k, &o)) return 1;
+        if (qm2_prepare(ctxs[i], 0, QM2_PREPARE_HOST)) return 1;
+        if (qm2_dict_load_keys_quiet(d, ctxs[i], i == 0)) return 1;
+        sinks[i].acquire = out_acquire; sinks[i].commit = out_commit; sinks[i].submit = out_submit;
+        sinks[i].flush = out_flush; sinks[i].user = ctxs[i];
+        progress_ctx[i] = ctxs[i];
+    }
+    progress_n = n_dev;
+    clock_gettime(CLOCK_MONOTONIC, &tb);
+    if (timing) printf("QM2 phase load-dictionary %.3f s (file -> %d devices)\n", (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec), n_dev);
+    /* a turn = one device batch (1.5 bytes per table slot, 1..6 GiB: qm2_open's default) */
+    {
+        uint64_t bb = d->hash_size + d->hash_size / 2;
+        if (bb < (1ull << 30)) bb = 1ull << 30;
+        if (bb > (6ull << 30)) bb = 6ull << 30;
+        const char *env = getenv("QM2_TURN_BYTES");           /* (tests: small turns on small inputs) */
+        turn = env ? (size_t)strtoull(env, NULL, 10) : (size_t)bb;
+    }
+    qm2_dispatch *disp = qm2_dispatch_new(sinks, n_dev, turn);
+    if (!disp) { puts("Memory allocation failed"); return 1; }
+    qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, disp, NULL};
+    int rc = qm2_stream_reads(reads, &out, n_strip);
+    qm2_dispatch_free(disp);
+    memset(st, 0, sizeof *st);
+    for (int i = 0; i < n_dev && !rc; i++) {
+        qm2_stats s1;
+        rc = qm2_finish(ctxs[i], NULL, &s1);
+        st->n_bases += s1.n_bases; st->n_kmers += s1.n_kmers; st->n_probes += s1.n_probes; st->n_hits += s1.n_hits;
+    }
+    for (int i = 1; i < n_dev && !rc; i++) rc = qm2_merge_counters(ctxs[0], ctxs[i]);
+    return rc;
+}
+
 int qm2_main_count(int argc, char **argv)
 {
     unsigned thread_count = 0;
@@ -59,8 +125,16 @@ int qm2_main_count(int argc, char **argv)
     if (argc < 2) { help_count(); return 1; }                /* :309-312 */
     int opt;
     optind = 1;
-    while ((opt = getopt(argc, argv, "ht:")) != -1) {        /* :314 */
+    int devices[QM2_MAX_DEVICES], n_dev = 0;
+    static const struct option long_opts[] = {{"devices", required_argument, NULL, 'D'}, {NULL, 0, NULL, 0}};
+    while ((opt = getopt_long(argc, argv, "ht:", long_opts, NULL)) != -1) {        /* :314 (+ --devices) */
         switch (opt) {
+        case 'D':
+            for (char *tok = strtok(optarg, ","); tok; tok = strtok(NULL, ",")) {
+                if (n_dev == QM2_MAX_DEVICES) { printf("At most %d devices\n", QM2_MAX_DEVICES); return 1; }
+                devices[n_dev++] = atoi(tok);
+            }
+            break;
         case 'h': help_count(); return 1;
         case 't':
             thread_count = (unsigned)atoi(optarg) & 0xFFu;   /* uint8_t in the reference (:306) */
@@ -95,10 +169,30 @@ int qm2_main_count(int argc, char **argv)
     /* (the reference's Kmer_hash and Kmer_depth, :353 and :360, live on the device: qm2_open allocates
      * both and zeroes the counters; the keys are streamed from the file, never held on the host) */
     qm2_ctx *ctx = NULL;
+    if (n_dev > 1) {
+        qm2_ctx *ctxs[QM2_MAX_DEVICES] = {NULL};
+        qm2_stats st;
+        struct timespec t0, t1;
+        progress_printed_g = 0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        int rc = count_on_devices(&d, reads, n_strip, devices, n_dev, ctxs, &st, timing);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (!rc) {
+            progress_upto(st.n_kmers);
+            printf("Counting elapse %u sec, total %lu kmers\n", (unsigned)(t1.tv_sec - t0.tv_sec), (unsigned long)st.n_kmers);   /* :481 */
+            if (timing) printf("QM2 phase load+count on %d devices %.3f s\n", n_dev, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
+            rc = qm2_write_outputs(&d, ctxs[0], ref_prefix, out_prefix);
+        }
+        for (int i = 0; i < n_dev; i++) qm2_close(ctxs[i]);
+        qm2_dict_close(&d);
+        if (rc) return 1;
+        puts("Exit quicK-mer2 count");                        /* :543 */
+        return 0;
+    }
     qm2_opts o;
     memset(&o, 0, sizeof o);
     o.struct_size = sizeof o;
-    o.device = -1;
+    o.device = n_dev == 1 ? devices[0] : -1;
     o.flags = QM2_FLAG_KEYS_LATER;
     o.n_staging = (uint32_t)n_strip + 3;
     clock_gettime(CLOCK_MONOTONIC, &ta);
@@ -128,6 +222,8 @@ int qm2_main_count(int argc, char **argv)
      * the whole input then goes through the host path again, from zeroed counters — exact either
      * way, nothing extra on stdout.  QM2_READER_RAW=0 goes straight to the host path. */
     progress_printed_g = 0;
+    progress_ctx[0] = ctx;
+    progress_n = 1;
     qm2_lines_out out = {out_acquire, out_commit, out_submit, ctx, want_raw ? out_commit_raw : NULL};
     int rc = qm2_stream_reads(reads, &out, n_strip);
     qm2_stats st;

@@ -1,0 +1,35 @@
+/*
+ * qm2_dispatch.h — one reader, several counting contexts (`quicKmer2 count --devices 0,1,...`).
+ *
+ * The reference's only parallelism knob is -t N (QuicKmer.c:304-333): one producer hands 4096-k-mer
+ * batches to the first idle of N workers that share one table (:421-439).  Here the workers are whole
+ * GPUs with a replica of the table each (it always fits: SURVEY section 0): the one reader's blocks of
+ * sequence lines go to the contexts in turns of one device batch, and the counters are summed on the
+ * first device before the epilogue (integer adds commute: exact).  Plain C, no GPU call in here: the
+ * sinks are function pointers (the CLI binds them to the C-ABI of include/qm2.h; the CPU test suite
+ * to a harness).
+ */
+#ifndef QM2_DISPATCH_H
+#define QM2_DISPATCH_H
+#include <stddef.h>
+
+typedef struct {
+    int (*acquire)(void *user, char **buf, size_t *capacity);
+    int (*commit)(void *user, char *buf, size_t n);
+    int (*submit)(void *user, const char *lines, size_t n);
+    int (*flush)(void *user);          /* launch what is pending, do not wait for it */
+    void *user;
+} qm2_sink;
+
+typedef struct qm2_dispatch qm2_dispatch;
+
+/* bytes_per_turn: how much one sink is given before the next one's turn (a device batch) */
+qm2_dispatch *qm2_dispatch_new(const qm2_sink *sinks, int n_sinks, size_t bytes_per_turn);
+void qm2_dispatch_free(qm2_dispatch *d);
+
+/* the three callbacks of qm2_lines_out (qm2_host.h), `user` = the qm2_dispatch.  A buffer is
+ * committed to the sink that lent it, whoever's turn it is by then. */
+int qm2_dispatch_acquire(void *d, char **buf, size_t *capacity);
+int qm2_dispatch_commit(void *d, char *buf, size_t n);
+int qm2_dispatch_submit(void *d, const char *lines, size_t n);
+#endif

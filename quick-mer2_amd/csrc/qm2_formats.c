@@ -47,13 +47,15 @@ int qm2_dict_open(const char *ref_prefix, qm2_dict_file *d)
     return 0;
 }
 
-int qm2_dict_load_keys(qm2_dict_file *d, qm2_ctx *ctx)
+int qm2_dict_load_keys_quiet(qm2_dict_file *d, qm2_ctx *ctx, int print)
 {
     /* :353-359 without the host array: file -> pinned pieces -> device */
     if (qm2_keys_from_fd(ctx, fileno(d->fp), 24)) return 1;                      /* says "... truncated" itself */
-    printf("Read 0x%lX hash\n", (unsigned long)d->hash_size);                    /* :359 */
+    if (print) printf("Read 0x%lX hash\n", (unsigned long)d->hash_size);         /* :359 */
     return 0;
 }
+
+int qm2_dict_load_keys(qm2_dict_file *d, qm2_ctx *ctx) { return qm2_dict_load_keys_quiet(d, ctx, 1); }
 
 void qm2_dict_close(qm2_dict_file *d)
 {

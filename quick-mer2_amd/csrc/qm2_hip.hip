@@ -998,6 +998,52 @@ extern "C" int qm2_sync(qm2_ctx *c)
     return 0;
 }
 
+extern "C" int qm2_flush(qm2_ctx *c)
+{
+    if (!c) return fail("qm2_flush: null context");
+    if (use_device(c)) return 1;
+    return batch_flush(c);
+}
+
+/* dst += src, whole counter arrays (replicas of one table on one or two devices) */
+__global__ void add_counters_kernel(uint32_t *dst, const uint32_t *src, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        dst[i] += src[i];
+}
+
+extern "C" int qm2_merge_counters(qm2_ctx *dst, qm2_ctx *src)
+{
+    if (!dst || !src || dst == src) return fail("qm2_merge_counters: two different contexts needed");
+    if (dst->H != src->H || dst->span_lo != src->span_lo || dst->span_hi != src->span_hi)
+        return fail("qm2_merge_counters: the contexts hold different tables");
+    if (qm2_sync(src) || qm2_sync(dst)) return 1;
+    const uint64_t n = dst->span_hi - dst->span_lo;
+    const int grid = dst->n_cu * 8;
+    if (dst->device == src->device) {
+        hipLaunchKernelGGL(add_counters_kernel, dim3(grid), dim3(256), 0, dst->stream, dst->counters, src->counters, n);
+        HIP_OK(hipGetLastError());
+    } else {
+        /* a piece at a time through a scratch buffer on the destination (peer access need not be enabled) */
+        const uint64_t piece = std::min<uint64_t>(n, 1ull << 26);
+        uint32_t *scratch = nullptr;
+        HIP_OK(hipMalloc((void **)&scratch, piece * sizeof(uint32_t)));
+        hipError_t e = hipSuccess;
+        for (uint64_t at = 0; at < n && e == hipSuccess; at += piece) {
+            const uint64_t m = std::min(piece, n - at);
+            e = hipMemcpyPeerAsync(scratch, dst->device, src->counters + at, src->device, m * sizeof(uint32_t), dst->stream);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(add_counters_kernel, dim3(grid), dim3(256), 0, dst->stream, dst->counters + at, scratch, m);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(dst->stream);
+        (void)hipFree(scratch);
+        if (e != hipSuccess) return fail("qm2_merge_counters: %s", hipGetErrorString(e));
+    }
+    HIP_OK(hipStreamSynchronize(dst->stream));
+    return 0;
+}
+
 extern "C" int qm2_stats_peek(qm2_ctx *c, qm2_stats *st)
 {
     if (!c || !st) return fail("qm2_stats_peek: null argument");

@@ -27,6 +27,7 @@ typedef struct {
  * the host never holds the 32 GiB array. */
 int  qm2_dict_open(const char *ref_prefix, qm2_dict_file *d);
 int  qm2_dict_load_keys(qm2_dict_file *d, qm2_ctx *ctx);      /* prints the reference's "Read 0x.. hash" (:359) */
+int  qm2_dict_load_keys_quiet(qm2_dict_file *d, qm2_ctx *ctx, int print);   /* the same for a further replica: one line in all */
 void qm2_dict_close(qm2_dict_file *d);
 
 /* Epilogue (:483-542): counts in chain order -> <out>.bin, optional .qgc stats ->

@@ -173,3 +173,64 @@ int main(int argc, char **argv) { O = fopen(argv[2], "wb"); CAP = (size_t)atol(a
             subprocess.run([exe, "/dev/fd/0", outp, str(64 << 20), "2"], stdin=pr.stdout, check=True)
             pr.wait()
         assert open(outp, "rb").read() == ol.strip_reads(str(p), seekable=False), name
+
+
+def test_dispatcher_deals_blocks_in_turns(tmp_path):
+    """qm2_dispatch.c (`quicKmer2 count --devices a,b,..`): the one reader's buffers go to the sinks in
+    turns of a fixed number of bytes, every buffer is committed to the sink that lent it, a sink is
+    flushed when its turn ends, and together the sinks receive exactly the reader's stream."""
+    src = os.path.join(ROOT, "quick-mer2_amd", "csrc")
+    harness = tmp_path / "d.c"
+    harness.write_text('''
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "qm2_dispatch.h"
+#include "qm2_host.h"
+typedef struct { int id; FILE *f; long lent, flushes, bytes; } Sink;
+static FILE *LOG;
+static int acq(void *u, char **b, size_t *c) { Sink *s = u; *c = 4096; *b = malloc(*c + 8); memcpy(*b, &s->id, sizeof s->id); *b += 8; s->lent++; return 0; }
+static int com(void *u, char *b, size_t n) { Sink *s = u; int id; memcpy(&id, b - 8, sizeof id);
+  if (id != s->id) { puts("commit to the wrong sink"); return 1; }
+  fwrite(b, 1, n, s->f); fprintf(LOG, "%d %zu\\n", s->id, n); s->bytes += (long)n; s->lent--; free(b - 8); return 0; }
+static int sub(void *u, const char *p, size_t n) { Sink *s = u; fwrite(p, 1, n, s->f); fprintf(LOG, "%d %zu\\n", s->id, n); s->bytes += (long)n; return 0; }
+static int flu(void *u) { Sink *s = u; s->flushes++; fprintf(LOG, "%d flush\\n", s->id); return 0; }
+int main(int argc, char **argv) {
+  int n = atoi(argv[2]); size_t turn = (size_t)atol(argv[3]); Sink S[8]; qm2_sink sinks[8]; char name[512];
+  LOG = fopen(argv[4], "w");
+  for (int i = 0; i < n; i++) { snprintf(name, sizeof name, "%s.%d", argv[4], i); S[i].id = i; S[i].f = fopen(name, "wb"); S[i].lent = S[i].flushes = S[i].bytes = 0;
+    sinks[i].acquire = acq; sinks[i].commit = com; sinks[i].submit = sub; sinks[i].flush = flu; sinks[i].user = &S[i]; }
+  qm2_dispatch *d = qm2_dispatch_new(sinks, n, turn);
+  qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, d, NULL};
+  int rc = qm2_stream_reads(argv[1], &out, atoi(argv[5]));
+  qm2_dispatch_free(d);
+  for (int i = 0; i < n; i++) { if (S[i].lent) rc = 3; fclose(S[i].f); }
+  fclose(LOG); return rc; }
+''')
+    exe = str(tmp_path / "d")
+    subprocess.run(["gcc", "-O1", "-pthread", "-I", src, "-o", exe, str(harness), os.path.join(src, "qm2_reader.c"),
+                    os.path.join(src, "qm2_dispatch.c")], check=True)
+    import oracle_lib as ol
+    import synth
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    exp = ol.strip_reads(rfq)
+    for n_sinks, turn, thr in ((1, 10_000, 0), (2, 10_000, 0), (3, 50_000, 2), (4, 1, 3), (2, 1 << 30, 1)):
+        log = str(tmp_path / "log")
+        subprocess.run([exe, rfq, str(n_sinks), str(turn), log, str(thr)], check=True)
+        parts = [open("%s.%d" % (log, i), "rb").read() for i in range(n_sinks)]
+        # every sink got whole lines, and all of them together are the reader's stream (as a multiset of lines)
+        assert all(p == b"" or p.endswith(b"\n") for p in parts)
+        assert sorted(b"".join(parts).split(b"\n")) == sorted(exp.split(b"\n"))
+        events = [l.split() for l in open(log).read().splitlines()]
+        if n_sinks > 1 and turn < len(exp):
+            assert all(len(p) > 0 for p in parts)                           # everybody had a turn
+            # a sink is flushed once it has been given its share, and then it is the next one's turn
+            share, cur = 0, 0
+            for e in events:
+                if e[1] == "flush":
+                    assert int(e[0]) == cur and share >= turn
+                    cur, share = (cur + 1) % n_sinks, 0
+                elif int(e[0]) == cur:
+                    share += int(e[1])
+        else:
+            assert len(parts[0]) == len(exp) or n_sinks > 1

@@ -172,6 +172,24 @@ def test_cli_mini_fasta_fastq_and_pipe(tmp_path):
     assert r.returncode == 0 and md5_file(out + ".bin") == m["bin_md5"]
 
 
+def test_cli_devices_two_contexts_sum_to_the_reference(tmp_path):
+    """`quicKmer2 count --devices 0,0`: two replicas of the dictionary (here on the one GPU of the box), one
+    reader, the reads dealt to the two contexts in turns (small ones, so that both really count), the
+    counters summed into the first before the epilogue: .bin / .txt are the reference's own, stdout too."""
+    m = MAN["sets"]["mini"]
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    ref_prefix = os.path.join(GOLD, "mini", "ref.fa")
+    for tag, reads, devs, thr in (("fa", rfa, "0,0", "2"), ("fq", rfq, "0,0,0", "0"), ("one", rfq, "0", "4")):
+        out = str(tmp_path / tag)
+        r = subprocess.run([CLI, "count", "-t", thr, "--devices", devs, ref_prefix, reads, out], stdout=subprocess.PIPE,
+                           timeout=300, env=dict(os.environ, QM2_TURN_BYTES="100000"))
+        assert r.returncode == 0, r.stdout
+        assert md5_file(out + ".bin") == m["bin_md5"] and md5_file(out + ".txt") == m["txt_md5"]
+        text = r.stdout.decode()
+        assert ("total %d kmers" % m["n_kmers"]) in text and text.count("Read 0x") == 1
+        assert text.rstrip().endswith("Exit quicK-mer2 count")
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(ol.ORACLE_DIR, "_ref", "quicKmer2")),
                     reason="real reference binary not shipped")
 def test_cli_c1_against_live_reference(tmp_path):
