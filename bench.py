@@ -219,7 +219,10 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
         for c in p1["class_ms"]:
             t_class[c] = t_class.get(c, 0.0) + p1["class_ms"][c] - p0["class_ms"][c]
 
-    if world > 1:
+    job_path = world > 1 or (use_dist and os.environ.get("QM2_SHARDED_JOB") == "1")     # (1-rank rehearsal of the N>1 path)
+    if job_path:
+        G = world
+        spans = shard_spans_device(pyqm2, np, keys, H, G) if G > 1 else [(0, H, 0, H)]
         import torch.distributed as dist
         sys.path.insert(0, ROOT)
         import __graft_entry__ as ge
@@ -235,7 +238,7 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
         eng.drain(job.ctx)
         _, s0 = job.ctx.finish(want_depth=False)
         p0, r0 = job.ctx.profile(), job.rctx.profile()
-        b0 = sum(int(c[0]) for c in job._totals)
+        acc0 = [int(x) for x in job._acc] if job._acc is not None else [0, 0, 0]
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -251,7 +254,7 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
         _, s1 = job.ctx.finish(want_depth=False)
         add_prof(p0, job.ctx.profile())
         add_prof(r0, job.rctx.profile())
-        tot = torch.tensor([sum(int(c[0]) for c in job._totals) - b0, sum(int(c[1]) for c in job._totals[args.warmup:]),
+        tot = torch.tensor([int(job._acc[0]) - acc0[0], int(job._acc[1]) - acc0[1],
                             s1["n_probes"] - s0["n_probes"], s1["n_hits"] - s0["n_hits"],
                             int(job.counters.sum(dtype=torch.int64)), s1["n_hits"]], dtype=torch.int64, device=dev)
         dist.all_reduce(tot)

@@ -90,25 +90,51 @@ class HipEngine:
     def on_router(self):
         return self.torch.cuda.stream(self.s_route)
 
-    def route(self, rctx, d_lines, n_owners, cap):
-        """-> (slabs int64[n_owners * cap], fill int32[n_owners], call int64[3] = bases, k-mers, not fitted),
-        all on the device, produced on the router stream (the caller is inside on_router())."""
+    def new_set(self, n_owners, cap):
+        """One set of exchange buffers: (slabs, fill, call, recv, incoming); allocated once, reused."""
         t = self.torch
-        slabs = t.empty(n_owners * cap, dtype=t.int64, device=self.device)
-        fill = t.zeros(n_owners, dtype=t.int32, device=self.device)
-        call = t.zeros(3, dtype=t.int64, device=self.device)
+        return (t.empty(n_owners * cap, dtype=t.int64, device=self.device), t.zeros(n_owners, dtype=t.int32, device=self.device),
+                t.zeros(3, dtype=t.int64, device=self.device), t.empty(n_owners * cap, dtype=t.int64, device=self.device),
+                t.zeros(n_owners, dtype=t.int32, device=self.device))
+
+    def route(self, rctx, d_lines, n_owners, cap, bufs, after=None):
+        """Fills bufs = (slabs int64[n_owners * cap], fill int32[n_owners], call int64[3] = bases, k-mers, not
+        fitted, ...) on the router stream (the caller is inside on_router()); `after`: what probe_after returned
+        for the round that used these buffers last — the router waits for it before it overwrites them."""
+        if after is not None:
+            self.s_route.wait_event(after)
+        slabs, fill, call = bufs[0], bufs[1], bufs[2]
+        fill.zero_()
+        call.zero_()
         if d_lines is not None and d_lines.numel():
             rctx.route_device(d_lines.data_ptr(), d_lines.numel(), slabs.data_ptr(), cap, n_owners, fill.data_ptr(),
                               call.data_ptr())
         return slabs, fill, call
 
+    class _After:
+        """what a work handle is to a collective: the prober stream waits for the router stream's work so far"""
+        def __init__(self, torch, stream):
+            self.ev = torch.cuda.Event()
+            self.ev.record(stream)
+            self.torch = torch
+
+        def wait(self):
+            self.torch.cuda.current_stream().wait_event(self.ev)
+
+    def routed(self):
+        return self._After(self.torch, self.s_route)
+
     def probe_after(self, ctx, works, slabs, cap, n_slabs, fill):
-        """Probe the received slabs once the exchanges `works` have completed — on the prober stream."""
+        """Probe the received slabs once the exchanges `works` have completed — on the prober stream.
+        Returns an event that fires when the probe is done with the buffers."""
         with self.torch.cuda.stream(self.s_probe):
             for w in works:
                 if w is not None:
                     w.wait()                    # the prober stream waits; the host and the router stream do not
             ctx.probe_slabs_device(slabs.data_ptr(), cap, n_slabs, fill.data_ptr())
+            ev = self.torch.cuda.Event()
+            ev.record(self.s_probe)
+        return ev
 
     def split_lines(self, d_lines):
         """Two halves of a device text buffer, cut behind a line end."""
@@ -195,8 +221,11 @@ class ShardedJob:
         self.cap = (int(self.batch_bytes / self.world * 1.3) + 64) & ~1
         self.n_bases = self.n_kmers = 0
         self.rounds = self.retries = 0
-        self._keep = []                       # buffers of the rounds still in flight
-        self._totals = []                     # device-side {bases, k-mers} of the accepted rounds
+        self._keep = []
+        self._sets = None                     # two sets of exchange buffers, used in turn
+        self._busy = [None, None]             # per set: the probe that reads it has finished (engine event)
+        self._turn = 0
+        self._acc = None                      # device-side {bases, k-mers, -} of the accepted rounds
 
     def count(self, lines: bytes):
         a, b = rank_slice(lines, self.rank, self.world)
@@ -232,18 +261,26 @@ class ShardedJob:
         t, dist, W, eng = self.torch, self.dist, self.world, self.engine
         have = d_lines is not None and d_lines.numel() > 0
         self.rounds += 1
+        if self._sets is None:
+            self._sets = [eng.new_set(W, self.cap), eng.new_set(W, self.cap)]
+            self._acc = self._sets[0][2].clone()
+        which = self._turn
+        bufs = self._sets[which]
         with eng.on_router():
-            slabs, fill, call = eng.route(self.rctx, d_lines if have else None, W, self.cap)
+            slabs, fill, call = eng.route(self.rctx, d_lines if have else None, W, self.cap, bufs, after=self._busy[which])
+            self._busy[which] = None
             # collective decision: did every slab on every rank take what was routed to it?
             unfit = call[2:3].clone()
             dist.all_reduce(unfit, op=dist.ReduceOp.MAX)
             fits = int(unfit.item()) == 0
             if fits:
-                incoming = t.empty_like(fill)
-                w1 = dist.all_to_all_single(incoming, fill, async_op=True)
-                recv = t.empty_like(slabs)
-                w2 = dist.all_to_all_single(recv, slabs, async_op=True)
-                self._totals.append(call)
+                if W == 1:                        # nothing to exchange: what was routed is what is probed
+                    recv, incoming, w1, w2 = slabs, fill, eng.routed(), None
+                else:
+                    recv, incoming = bufs[3], bufs[4]
+                    w1 = dist.all_to_all_single(incoming, fill, async_op=True)
+                    w2 = dist.all_to_all_single(recv, slabs, async_op=True)
+                self._acc += call
         if not fits:
             # every rank takes this branch together; a piece of at most `cap` bytes cannot overflow a slab
             assert depth < 48, "a batch keeps overflowing its slabs"
@@ -252,19 +289,17 @@ class ShardedJob:
             self._round(halves[0], depth + 1)
             self._round(halves[1], depth + 1)
             return
-        eng.probe_after(self.ctx, (w1, w2), recv, self.cap, W, incoming)
-        self._keep.append((slabs, fill, recv, incoming, d_lines))
-        del self._keep[:-3]                   # (older rounds have been probed: their buffers may go)
+        self._busy[which] = eng.probe_after(self.ctx, (w1, w2), recv, self.cap, W, incoming)
+        self._keep = (self._keep + [d_lines])[-2:]      # (the text of the rounds still being routed)
+        self._turn ^= 1
 
     def finish(self):
         """-> uint16[H] on every rank, assembled from the owners' slices."""
         t, dist, W = self.torch, self.dist, self.world
         self.engine.drain(self.ctx)
         self._keep = []
-        for call in self._totals:
-            self.n_bases += int(call[0])
-            self.n_kmers += int(call[1])
-        self._totals = []
+        if self._acc is not None:
+            self.n_bases, self.n_kmers = int(self._acc[0]), int(self._acc[1])
         c = self.counters
         owned = c[self.own_lo - self.lo:self.own_hi - self.lo].clone()
         # overhang past the middle-facing edge belongs to the next shard towards the middle

@@ -78,11 +78,16 @@ class OracleEngine:
         import contextlib
         return contextlib.nullcontext()
 
-    def route(self, c, d_lines, n_owners, cap):
+    def new_set(self, n_owners, cap):
+        return (torch.zeros(n_owners * cap, dtype=torch.int64), torch.zeros(n_owners, dtype=torch.int32),
+                torch.zeros(3, dtype=torch.int64), torch.zeros(n_owners * cap, dtype=torch.int64),
+                torch.zeros(n_owners, dtype=torch.int32))
+
+    def route(self, c, d_lines, n_owners, cap, bufs, after=None):
         """the contract of qm2_route_device: fixed slabs, fill = what was ROUTED, call = bases, k-mers, not fitted"""
-        slabs = torch.zeros(n_owners * cap, dtype=torch.int64)
-        fill = torch.zeros(n_owners, dtype=torch.int32)
-        call = torch.zeros(3, dtype=torch.int64)
+        slabs, fill, call = bufs[0], bufs[1], bufs[2]
+        fill.zero_()
+        call.zero_()
         if d_lines is None or d_lines.numel() == 0:
             return slabs, fill, call
         kmers, nb = self.ol.extract(d_lines.numpy().tobytes(), c.k)
@@ -108,6 +113,10 @@ class OracleEngine:
         for g in range(n_slabs):
             n = min(int(fill[g]), cap)
             self._probe_np(c, slabs[g * cap:g * cap + n].numpy().view(np.uint64))
+        return None
+
+    def routed(self):
+        return None
 
     def split_lines(self, d_lines):
         b = d_lines.numpy().tobytes()
