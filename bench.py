@@ -154,20 +154,37 @@ def cpu_legs(args, wl, pyqm2, torch, keys, buf0, nbytes0, H, k, local, n_unique)
                 f.write(b">r\n")
                 f.write(host)
             tA = time.perf_counter()
+            # (on a pseudo-terminal: the reference printf()s through stdio, which holds its lines back on a pipe)
+            import pty
+            master, slave = pty.openpty()
             pr = subprocess.Popen([ref_bin, "count", "-t", str(args.cpu_threads), os.path.join(work, "ref.fa"),
                                    os.path.join(work, "reads.fa"), os.path.join(work, "out")],
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, bufsize=1)
+                                  stdout=slave, stderr=slave, stdin=subprocess.DEVNULL, close_fds=True)
+            os.close(slave)
             t_loaded = t_done = None
             nk_ref = None
-            for line in pr.stdout:
-                if line.startswith("Read 0x") and t_loaded is None:
-                    t_loaded = time.perf_counter()               # keys are in (:359): the timed loop starts (:386)
-                if line.startswith("Counting elapse"):
-                    t_done = time.perf_counter()
-                    nk_ref = int(line.split("total")[1].split()[0])
+            pending = b""
+            deadline = tA + 600
+            while t_done is None and time.perf_counter() < deadline:
+                try:
+                    chunk = os.read(master, 4096)
+                except OSError:
                     break
+                if not chunk:
+                    break
+                now = time.perf_counter()
+                pending += chunk
+                while b"\n" in pending:
+                    line, pending = pending.split(b"\n", 1)
+                    line = line.decode(errors="replace").strip()
+                    if line.startswith("Read 0x") and t_loaded is None:
+                        t_loaded = now                           # keys are in (:359): the timed loop starts (:386)
+                    if line.startswith("Counting elapse"):
+                        t_done = now
+                        nk_ref = int(line.split("total")[1].split()[0])
             pr.kill()
             pr.wait()
+            os.close(master)
             if t_loaded and t_done:
                 # the threaded drain sleeps one fixed second (:469); it is not counting time
                 sec = (t_done - t_loaded) - (1.0 if args.cpu_threads > 0 else 0.0)
