@@ -154,12 +154,23 @@ def cpu_legs(args, wl, pyqm2, torch, keys, buf0, nbytes0, H, k, local, n_unique)
                 f.write(b">r\n")
                 f.write(host)
             tA = time.perf_counter()
-            # (on a pseudo-terminal: the reference printf()s through stdio, which holds its lines back on a pipe)
+            # The reference printf()s through stdio, which holds its lines back on a pipe: give it a pseudo-terminal,
+            # or (no pty devices on the box) preload a three-line shim that makes its stdout line-buffered — what
+            # `stdbuf -oL` does; the reference binary itself is untouched.
             import pty
-            master, slave = pty.openpty()
-            pr = subprocess.Popen([ref_bin, "count", "-t", str(args.cpu_threads), os.path.join(work, "ref.fa"),
-                                   os.path.join(work, "reads.fa"), os.path.join(work, "out")],
-                                  stdout=slave, stderr=slave, stdin=subprocess.DEVNULL, close_fds=True)
+            cmd = [ref_bin, "count", "-t", str(args.cpu_threads), os.path.join(work, "ref.fa"),
+                   os.path.join(work, "reads.fa"), os.path.join(work, "out")]
+            env = dict(os.environ)
+            try:
+                master, slave = pty.openpty()
+            except OSError:
+                shim_dir = tempfile.mkdtemp(prefix="qm2_lb_")            # (not under /dev/shm: it may be mounted noexec)
+                shim_c, shim_so = os.path.join(shim_dir, "lb.c"), os.path.join(shim_dir, "lb.so")
+                open(shim_c, "w").write('#include <stdio.h>\n__attribute__((constructor)) static void lb(void) { setvbuf(stdout, NULL, _IOLBF, 0); }\n')
+                subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", shim_so, shim_c], check=True)
+                env["LD_PRELOAD"] = shim_so + (":" + env["LD_PRELOAD"] if env.get("LD_PRELOAD") else "")
+                master, slave = os.pipe()
+            pr = subprocess.Popen(cmd, stdout=slave, stderr=slave, stdin=subprocess.DEVNULL, close_fds=True, env=env)
             os.close(slave)
             t_loaded = t_done = None
             nk_ref = None
