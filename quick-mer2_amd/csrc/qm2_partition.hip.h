@@ -194,16 +194,16 @@ template <int PIECE>
 __device__ __forceinline__ void copy_piece(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
 {
     const uint32_t i = threadIdx.x + PIECE * kSplitThreads;
-    if (i < L.total) {
-        const uint64_t km = L.sorted[i];
-        const uint32_t child = child_of(km, shift, bits);
-        const uint2 dl = L.dl[child];
-        /* (an address-space-1 pointer: a generic one would make this a flat_store, which also counts on
-         * lgkmcnt — and every LDS wait and lds_barrier() of these kernels would wait for the stores) */
-        typedef uint64_t __attribute__((address_space(1))) global_u64;
-        global_u64 *dst = (global_u64 *)(uintptr_t)(d.kmers + (child0 + child) * (uint64_t)d.cap);
-        if (i < dl.y) dst[i + dl.x] = km;
-    }
+    /* no bounds test on i: beyond the chunk's last k-mer L.sorted holds stale k-mers, and whatever child such
+     * a one hashes to, that child's limit (offset + fit <= the chunk's total <= i) keeps it from being stored */
+    const uint64_t km = L.sorted[i];
+    const uint32_t child = child_of(km, shift, bits);
+    const uint2 dl = L.dl[child];
+    /* (an address-space-1 pointer: a generic one would make this a flat_store, which also counts on
+     * lgkmcnt — and every LDS wait and lds_barrier() of these kernels would wait for the stores) */
+    typedef uint64_t __attribute__((address_space(1))) global_u64;
+    global_u64 *dst = (global_u64 *)(uintptr_t)(d.kmers + (child0 + child) * (uint64_t)d.cap);
+    if (i < dl.y) dst[i + dl.x] = km;
 }
 
 __device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
