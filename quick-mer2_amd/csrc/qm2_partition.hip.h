@@ -190,20 +190,34 @@ __device__ __forceinline__ uint32_t child_of(uint64_t km, uint32_t shift, uint32
     return __builtin_amdgcn_ubfe(djb32(km), shift, bits);
 }
 
+/* two halves so that the caller can put the k-mer's own work between the LDS read and its use */
 template <int PIECE>
-__device__ __forceinline__ void copy_piece(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
+__device__ __forceinline__ uint64_t copy_fetch(const SplitLds &L)
+{
+    return L.sorted[threadIdx.x + PIECE * kSplitThreads];
+}
+
+template <int PIECE>
+__device__ __forceinline__ void copy_store(const SplitLds &L, uint64_t km, const SplitDst &d, uint64_t child0, uint32_t shift,
+                                           uint32_t bits)
 {
     const uint32_t i = threadIdx.x + PIECE * kSplitThreads;
     /* no bounds test on i: beyond the chunk's last k-mer L.sorted holds stale k-mers, and whatever child such
      * a one hashes to, that child's limit (offset + fit <= the chunk's total <= i) keeps it from being stored */
-    const uint64_t km = L.sorted[i];
     const uint32_t child = child_of(km, shift, bits);
-    const uint2 dl = L.dl[child];
+    const uint64_t dlw = *reinterpret_cast<const uint64_t *>(&L.dl[child]);      /* one 8-byte read: x = low, y = high */
+    const uint32_t dx = (uint32_t)dlw, dy = (uint32_t)(dlw >> 32);
     /* (an address-space-1 pointer: a generic one would make this a flat_store, which also counts on
      * lgkmcnt — and every LDS wait and lds_barrier() of these kernels would wait for the stores) */
     typedef uint64_t __attribute__((address_space(1))) global_u64;
     global_u64 *dst = (global_u64 *)(uintptr_t)(d.kmers + (child0 + child) * (uint64_t)d.cap);
-    if (i < dl.y) dst[i + dl.x] = km;
+    if (i < dy) dst[i + dx] = km;
+}
+
+template <int PIECE>
+__device__ __forceinline__ void copy_piece(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
+{
+    copy_store<PIECE>(L, copy_fetch<PIECE>(L), d, child0, shift, bits);
 }
 
 __device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
@@ -245,10 +259,11 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
         /* k-mer J of this chunk, then copy-out piece J of the previous chunk */
 #define QM2_T(J)                                                                   \
         {                                                                          \
+            const uint64_t out = pend ? copy_fetch<J>(L) : 0;    /* (its LDS latency hides behind the k-mer's own work) */ \
             km[J] = kmer_at<K30, J>(W, k);                                         \
             const uint32_t b = (W.emit & (0x8000u >> J)) ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
-            if (pend) copy_piece<J>(L, d, 0, shift, bits);                         \
+            if (pend) copy_store<J>(L, out, d, 0, shift, bits);                    \
         }
         QM2_T(0) QM2_T(1) QM2_T(2) QM2_T(3) QM2_T(4) QM2_T(5) QM2_T(6) QM2_T(7)
         QM2_T(8) QM2_T(9) QM2_T(10) QM2_T(11) QM2_T(12) QM2_T(13) QM2_T(14) QM2_T(15)
@@ -327,9 +342,10 @@ __global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_
         fetch(first + (uint64_t)wgs_per_parent * kSplitSlots);
 #define QM2_K(J)                                                                   \
         {                                                                          \
+            const uint64_t out = pend ? copy_fetch<J>(L) : 0;                      \
             const uint32_t b = km[J] != kPad ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
-            if (pend) copy_piece<J>(L, d, child0, shift, bits);                    \
+            if (pend) copy_store<J>(L, out, d, child0, shift, bits);               \
         }
         QM2_K(0) QM2_K(1) QM2_K(2) QM2_K(3) QM2_K(4) QM2_K(5) QM2_K(6) QM2_K(7)
         QM2_K(8) QM2_K(9) QM2_K(10) QM2_K(11) QM2_K(12) QM2_K(13) QM2_K(14) QM2_K(15)
