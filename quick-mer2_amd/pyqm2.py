@@ -115,6 +115,10 @@ def lib():
     L.qm2_encode_device.argtypes = [vp, vp, C.c_size_t, vp, u64, vp, u64, u32, vp]
     L.qm2_probe_device.restype = C.c_int
     L.qm2_probe_device.argtypes = [vp, vp, u64, vp]
+    L.qm2_flush.restype = C.c_int
+    L.qm2_flush.argtypes = [vp]
+    L.qm2_merge_counters.restype = C.c_int
+    L.qm2_merge_counters.argtypes = [vp, vp]
     L.qm2_route_device.restype = C.c_int
     L.qm2_route_device.argtypes = [vp, vp, C.c_size_t, vp, u64, vp, u64, u32, vp, vp]
     L.qm2_probe_slabs_device.restype = C.c_int
@@ -283,6 +287,12 @@ class Counter:
 
     def prepare(self, batch_bytes=0, host=False, raw=False):
         _check(lib().qm2_prepare(self._h, int(batch_bytes), (1 if host else 0) | (2 if raw else 0)), "qm2_prepare")
+
+    def flush(self):
+        _check(lib().qm2_flush(self._h), "qm2_flush")
+
+    def merge_counters(self, src):
+        _check(lib().qm2_merge_counters(self._h, src._h), "qm2_merge_counters")
 
     def stats_peek(self):
         st = Stats()

@@ -308,6 +308,39 @@ def test_zero_copy_staging_and_cli_threads(qm2, tmp_path):
         assert md5_file(out + ".bin") == m["bin_md5"] and md5_file(out + ".txt") == m["txt_md5"]
 
 
+def test_prepare_peek_flush_and_merge(qm2, tmp_path):
+    """Round-2 entry points: qm2_prepare (no allocation once the stream runs), qm2_stats_peek (a snapshot that
+    never blocks and ends at the totals), qm2_flush (launch without waiting), qm2_merge_counters (two replicas
+    of one table: the sum of their counts is the count of the whole stream)."""
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    keys = qm["keys"]
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    lines = ol.strip_reads(rfq)
+    exp_depth, exp_st = ol.count_lines(keys, qm["k"], lines)
+    cut = lines.rfind(b"\n", 0, len(lines) // 3) + 1
+    for flags in (qm2.FLAG_PARTITION, qm2.FLAG_DIRECT):
+        with qm2.Counter(keys, k=qm["k"], flags=flags, staging_bytes=1 << 16, batch_bytes=1 << 18, n_staging=6) as a, \
+                qm2.Counter(keys, k=qm["k"], flags=flags, staging_bytes=1 << 16, batch_bytes=1 << 18) as b:
+            a.prepare(host=True, raw=True)
+            n0 = a.profile()["allocations"]
+            assert n0 > 0 and a.stats_peek()["n_kmers"] == 0
+            a.submit_zero_copy(lines[:cut])
+            a.flush()                                   # launches the pending batch, does not wait
+            peek = a.stats_peek()
+            assert 0 <= peek["n_kmers"] <= exp_st["n_kmers"]
+            _, sa = a.finish(want_depth=False)
+            assert a.profile()["allocations"] == n0     # nothing was allocated while the stream ran
+            assert a.stats_peek() == sa                 # after a sync the snapshot is the total
+            b.submit(lines[cut:])
+            _, sb = b.finish(want_depth=False)
+            assert {x: sa[x] + sb[x] for x in sa} == exp_st
+            a.merge_counters(b)
+            depth, _ = a.finish()
+            assert np.array_equal(depth, exp_depth)
+            d_b, _ = b.finish()                         # the source keeps its own counts
+            assert int(d_b.astype(np.uint64).sum()) == sb["n_hits"]
+
+
 def test_empty_and_degenerate_inputs(qm2):
     qm = kat_qm()
     with qm2.Counter(qm["keys"], k=30) as c:
