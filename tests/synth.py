@@ -132,6 +132,8 @@ def kat_cases(ref):
     cases = {}
     one = ref[1000:1030].tobytes()
     cases["wrap70000"] = ("fa", b"".join(b">\n" + one + b"\n" for _ in range(70000)))
+    # a control-region k-mer at depth 50000: its square overflows the `int` the reference squares it in (QuicKmer.c:507)
+    cases["deep50000"] = ("fa", b"".join(b">\n" + one + b"\n" for _ in range(50000)))
     cases["upper"] = ("fa", b">r\n" + rd + b"\n")
     cases["lower"] = ("fa", b">r\n" + rd.lower() + b"\n")
     cases["crlf"] = ("fa", b">r\r\n" + rd + b"\r\n")
