@@ -639,6 +639,19 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
             LM = (uint32_t)__ffs((int)zm_) - 1u;                                             \
             LE = (uint32_t)__ffs((int)ze_) - 1u;                                             \
         }
+        /* the same over EIGHT slots (two fingerprint words): bit indices 0..63 */
+#define QM2_WINDOW8(W0, W1, KM, LM, LE)                                                      \
+        {                                                                                    \
+            const uint32_t f_ = __builtin_amdgcn_perm(0u, fp8(KM), 0u);                      \
+            const uint32_t x0_ = (W0) ^ f_, x1_ = (W1) ^ f_;                                 \
+            const uint64_t zm_ = ((uint64_t)((x1_ - 0x01010101u) & ~x1_ & 0x80808080u) << 32) | ((x0_ - 0x01010101u) & ~x0_ & 0x80808080u); \
+            const uint64_t ze_ = ((uint64_t)(((W1) - 0x01010101u) & ~(W1) & 0x80808080u) << 32) | (((W0) - 0x01010101u) & ~(W0) & 0x80808080u); \
+            LM = (uint32_t)__ffsll((long long)zm_) - 1u;                                     \
+            LE = (uint32_t)__ffsll((long long)ze_) - 1u;                                     \
+        }
+#ifndef QM2_WIN8
+#define QM2_WIN8 0          /* 8 fingerprints per k-mer in phase A: queue 10 % -> 2 %, but 3 % SLOWER at C3 (25.2 vs 24.5 ms, same box) */
+#endif
         /* finish a walk that stands at staged position p; adds the slots it inspects from there on.
          * Beyond the slice — only behind a run of >= kHalo occupied slots — it goes on in global
          * memory like the direct kernel. */
@@ -672,7 +685,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                 const uint32_t c = __builtin_amdgcn_ubfe(lm, 3, 2);
                 seen += (min(min(lm, le), 31u) >> 3) + 1u;
                 if (lm > le) break;                                         /* an empty slot first */
-                if (bkey[p + c] == km) { atomicAdd(&bcnt[p + c], 1u); n_hits++; break; }
+                if (lm <= 31u && bkey[p + c] == km) { atomicAdd(&bcnt[p + c], 1u); n_hits++; break; }
                 p += c + 1u;
             }
             n_probes += seen;
@@ -689,28 +702,42 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         auto probe_set = [&](const auto &km, const auto &live) {
             constexpr int K = (int)(sizeof(km) / sizeof(km[0]));
             uint32_t pp[K], d0[K], d1[K], lm[K], le[K];
+#if QM2_WIN8
+            uint32_t d2[K];
+#endif
             uint64_t vv[K];
+            constexpr uint32_t kWinBits = QM2_WIN8 ? 3u : 2u, kWinLast = QM2_WIN8 ? 63u : 31u;
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 pp[j] = ((djb32(km[j]) & tv.hmask) ^ xm) + ad;              /* :92 */
                 d0[j] = bfp[pp[j] >> 2];
                 d1[j] = bfp[(pp[j] >> 2) + 1];
+#if QM2_WIN8
+                d2[j] = bfp[(pp[j] >> 2) + 2];
+#endif
             }
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 const uint32_t w = __builtin_amdgcn_alignbyte(d1[j], d0[j], pp[j]);   /* fingerprints of p .. p+3 */
+#if QM2_WIN8
+                const uint32_t w1 = __builtin_amdgcn_alignbyte(d2[j], d1[j], pp[j]);  /* ... and of p+4 .. p+7 */
+                QM2_WINDOW8(w, w1, km[j], lm[j], le[j])
+#else
                 QM2_WINDOW(w, km[j], lm[j], le[j])
-                vv[j] = bkey[pp[j] + __builtin_amdgcn_ubfe(lm[j], 3, 2)];
+#endif
+                vv[j] = bkey[pp[j] + __builtin_amdgcn_ubfe(lm[j], 3, kWinBits)];
             }
 #pragma unroll
             for (int j = 0; j < K; j++) {
-                const uint32_t c = __builtin_amdgcn_ubfe(lm[j], 3, 2);
+                const uint32_t c = __builtin_amdgcn_ubfe(lm[j], 3, kWinBits);
                 const bool on = live[j] && km[j] != 0;                      /* k-mer 0: everything is left to walk() */
                 const bool cand = lm[j] <= le[j];
-                const bool hit = on && cand && vv[j] == km[j];              /* :98 */
+                /* (lm <= kWinLast: a real fingerprint match — with none, slot c holds a key of another fingerprint,
+                 *  or, in a slice cut short by its span, whatever the buffer held before) */
+                const bool hit = on && cand && lm[j] <= kWinLast && vv[j] == km[j];   /* :98 */
                 atomicAdd(&bcnt[pp[j] + c], hit ? 1u : 0u);                 /* :291 */
                 w_hits_a += __popcll(__ballot(hit));
-                n_probes += on ? (min(min(lm[j], le[j]), 31u) >> 3) + 1u : 0u;
+                n_probes += on ? (min(min(lm[j], le[j]), kWinLast) >> 3) + 1u : 0u;
                 /* a false fingerprint match, or nothing decisive in 4 slots: this wave's queue */
                 const bool more = live[j] && (km[j] == 0 || (cand && !hit));
                 const unsigned long long m = __ballot(more);
@@ -785,9 +812,16 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                         const uint32_t p = ((djb32(km) & tv.hmask) ^ xm) + ad;
                         uint32_t lm, le;
                         const uint32_t w = __builtin_amdgcn_alignbyte(bfp[(p >> 2) + 1], bfp[p >> 2], p);
+#if QM2_WIN8
+                        const uint32_t w1 = __builtin_amdgcn_alignbyte(bfp[(p >> 2) + 2], bfp[(p >> 2) + 1], p);
+                        QM2_WINDOW8(w, w1, km, lm, le)
+                        const uint32_t c = __builtin_amdgcn_ubfe(lm, 3, 3);
+                        more = km == 0 || (lm <= le && !(lm <= 63u && bkey[p + c] == km));
+#else
                         QM2_WINDOW(w, km, lm, le)
                         const uint32_t c = __builtin_amdgcn_ubfe(lm, 3, 2);
-                        more = km == 0 || (lm <= le && bkey[p + c] != km);
+                        more = km == 0 || (lm <= le && !(lm <= 31u && bkey[p + c] == km));
+#endif
                         at = km ? p + c + 1u : p;
                     }
                     const unsigned long long m = __ballot(more);           /* every lane: the same count as phase A's */
@@ -798,6 +832,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
             }
         }
 #undef QM2_WINDOW
+#undef QM2_WINDOW8
         QM2_STAMP(6);
         lds_barrier();                                                      /* barrier k+1 */
         QM2_STAMP(7);
