@@ -740,6 +740,71 @@ def test_encode_then_probe_equals_fused(qm2, torch_cuda, tmp_path):
         assert np.array_equal(total.astype(np.uint16), exp_depth)
 
 
+def _count_on_logical_shards(qm2, torch, keys, k, dparts, G, cap, flags):
+    """qm2_route_device for every "sender" in dparts, then every shard's span probed with what was routed to
+    it (qm2_probe_slabs_device); -> (uint64 depth[H] with the overhangs folded in, hits, probes, profiles)."""
+    H = len(keys)
+    spans = [qm2.shard_span(keys, G, g) for g in range(G)]
+    routed = []
+    with qm2.Counter(None, hash_size=H, k=k, flags=qm2.FLAG_KEYS_LATER, span=(0, 64)) as router:
+        for d in dparts:
+            slabs = torch.zeros(G * cap, dtype=torch.int64, device="cuda")
+            fill = torch.zeros(G, dtype=torch.int32, device="cuda")
+            call = torch.zeros(3, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            router.route_device(d.data_ptr(), d.numel(), slabs.data_ptr(), cap, G, fill.data_ptr(), call.data_ptr())
+            router.sync()
+            assert int(call[2]) == 0
+            routed.append((slabs, fill, call))
+    total = np.zeros(H, dtype=np.uint64)
+    hits = probes = 0
+    profs = []
+    for g, (own_lo, own_hi, lo, hi) in enumerate(spans):
+        recv = torch.cat([r[0][g * cap:(g + 1) * cap] for r in routed])
+        rfill = torch.stack([r[1][g] for r in routed]).contiguous()
+        torch.cuda.synchronize()
+        with qm2.Counter(keys[lo:hi], hash_size=H, k=k, span=(lo, hi), own=(own_lo, own_hi) if G > 1 else None,
+                         flags=flags | qm2.FLAG_TIMING) as pc:
+            pc.probe_slabs_device(recv.data_ptr(), cap, len(routed), rfill.data_ptr())
+            d, st = pc.finish()
+            profs.append((hi - lo, pc.profile()))
+        total[lo:hi] += d
+        hits += st["n_hits"]
+        probes += st["n_probes"]
+    return total, hits, probes, profs
+
+
+def test_shards_with_long_runs_across_their_edges(qm2, torch_cuda):
+    """Hash-range shards whose walks leave the owned range by thousands of slots: a 9000-slot run of
+    occupied slots across the edge between two lower-half shards (walks go up, into the neighbour's range)
+    and one across an edge in the upper half (walks go down).  The span (qm2_shard_span) then carries a
+    long overhang, the last buckets' halos lie outside the owned range, walks finish in global memory
+    inside the span, and the long-run marking is done per span: counts, hits and probes must still be
+    the oracle's, with the partitioned pipeline on every shard."""
+    torch = torch_cuda
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    ref = synth.kat_reference().tobytes()
+    rng = np.random.default_rng(82)
+    blob = b"".join(ref[int(p):int(p) + 150] + b"\n" for p in rng.integers(0, 4800, 8000))
+    half = blob.rfind(b"\n", 0, len(blob) // 2) + 1
+    dparts = [torch.frombuffer(bytearray(x), dtype=torch.uint8).cuda() for x in (blob[:half], blob[half:])]
+    H = len(qm["keys"])
+    n_km = len(ol.extract(blob, 30)[0])
+    for name, start, length in (("up_across_an_edge", H // 4 - 3000, 9000), ("down_across_an_edge", 3 * H // 4 - 6000, 9000),
+                                ("short_of_the_halo", H // 4 - 100, 230)):
+        keys = qm["keys"].copy()
+        gap = np.flatnonzero(keys[start:start + length] == 0) + start
+        keys[gap] = (np.uint64(1) << np.uint64(62)) + gap.astype(np.uint64)      # > any 60-bit k-mer
+        # make sure reads hit slots INSIDE the run: plant the homes of real read k-mers there?  the mini table's own
+        # keys inside the stretch stay where they are, so walks that start in it run on to its end
+        exp_depth, exp_st = ol.count_lines(keys, 30, blob)
+        for G in (2, 4):
+            total, hits, probes, profs = _count_on_logical_shards(qm2, torch, keys, 30, dparts, G, (n_km + 64) & ~1, qm2.FLAG_PARTITION)
+            assert hits == exp_st["n_hits"] and probes == exp_st["n_probes"], (name, G)
+            assert np.array_equal(total.astype(np.uint16), exp_depth), (name, G)
+            assert all(p["partitioned_batches"] == 1 for n_slots, p in profs if n_slots >= 2 * 4096), (name, G)
+
+
 def test_route_then_probe_slabs_equals_fused(qm2, torch_cuda, tmp_path):
     """The multi-GPU driver's two legs (qm2_route_device: encode + bucket by owner into fixed slabs;
     qm2_probe_slabs_device: a shard's span probed with the partitioned pipeline) on 1 / 2 / 4 / 8 logical
