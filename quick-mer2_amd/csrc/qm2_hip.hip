@@ -320,28 +320,35 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
          * copy of the stats block) wastes the fewest rows */
         stats_peek_harvest(c);
         const uint64_t per_bucket = (uint64_t)((double)src.n_upper * (src.sv ? c->kmers_per_byte : 1.0 / 1.3)) / n_buckets;
-        int g = 4;
+        int g = 4, lw = 3;
         {
+            /* loader waves (3 or 4 of the 16) and group size: the fewest rows of 2 k-mers per prober thread that
+             * take a bucket's fill; ties: 4 loader waves, the larger group */
             const double fill = (double)per_bucket + 3.0 * std::sqrt((double)per_bucket + 1.0);
-            const int rows = std::max(1, (int)std::ceil(fill / (2.0 * kProberThreads)));   /* rows of 2 k-mers per thread */
             int best_rows = 1 << 30;
-            for (int cand = 2; cand <= 6; cand++) {
-                const int run = (rows + cand - 1) / cand * cand;               /* rows executed */
-                if (run <= best_rows) { best_rows = run; g = cand; }           /* ties: the larger group */
+            for (int cand_lw = 3; cand_lw <= 4; cand_lw++) {
+                const int prober_threads = kCountThreads - cand_lw * kWave;
+                const int rows = std::max(1, (int)std::ceil(fill / (2.0 * prober_threads)));
+                for (int cand = 2; cand <= 6; cand++) {
+                    const int run = (rows + cand - 1) / cand * cand;           /* rows executed */
+                    if (run <= best_rows) { best_rows = run; g = cand; lw = cand_lw; }
+                }
             }
         }
         const CountGeo cg = {c->own_lo, c->span_lo, c->span_hi, c->H >> 1};
-#define QM2_LAUNCH_COUNT(G_)                                                                                    \
-        hipLaunchKernelGGL((bucket_count_kernel<kLgS, G_>), dim3(grid), dim3(kCountThreads), 0, s,             \
+#define QM2_LAUNCH_COUNT(G_, LW_)                                                                               \
+        hipLaunchKernelGGL((bucket_count_kernel<kLgS, G_, LW_>), dim3(grid), dim3(kCountThreads), 0, s,        \
                            p.buf[L & 1], p.cursors + p.cursor_off[L], p.cap[L], table_view(c), cg, n_buckets,   \
                            p.shared, c->stats)
+#define QM2_LAUNCH_COUNT_LW(G_) do { if (lw == 3) QM2_LAUNCH_COUNT(G_, 3); else QM2_LAUNCH_COUNT(G_, 4); } while (0)
         switch (g) {
-            case 2: QM2_LAUNCH_COUNT(2); break;
-            case 3: QM2_LAUNCH_COUNT(3); break;
-            case 4: QM2_LAUNCH_COUNT(4); break;
-            case 5: QM2_LAUNCH_COUNT(5); break;
-            default: QM2_LAUNCH_COUNT(6); break;
+            case 2: QM2_LAUNCH_COUNT_LW(2); break;
+            case 3: QM2_LAUNCH_COUNT_LW(3); break;
+            case 4: QM2_LAUNCH_COUNT_LW(4); break;
+            case 5: QM2_LAUNCH_COUNT_LW(5); break;
+            default: QM2_LAUNCH_COUNT_LW(6); break;
         }
+#undef QM2_LAUNCH_COUNT_LW
 #undef QM2_LAUNCH_COUNT
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;

@@ -409,21 +409,17 @@ __device__ __forceinline__ uint32_t fp8(uint64_t key)
 }
 constexpr uint32_t kFpPad = 0xFEu;
 
-#ifndef QM2_LOADER_WAVES
-#define QM2_LOADER_WAVES 3
-#endif
-constexpr int kLoaderWaves = QM2_LOADER_WAVES;
-
-constexpr int kLoaderThreads = kLoaderWaves * kWave;
-constexpr int kProberThreads = kCountThreads - kLoaderThreads;
-constexpr int kProberWaves = kProberThreads / kWave;
-
-template <int LG_S, int G2>
+/* LW loader waves (3 or 4; the rest of the 16 probe): chosen per launch so that a bucket's fill takes the fewest
+ * rows of 2 k-mers per prober thread — measured at C3: 50 M reads per launch 24.5 (3) vs 23.5 ms (4), 40 M reads
+ * 22.0 vs 24.4; 2 loader waves: 51 ms (their prefetch registers spill). */
+template <int LG_S, int G2, int LW>
 __global__ __launch_bounds__(kCountThreads)
 void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_t cap, TableView tv, CountGeo cg,
                          uint32_t n_buckets, const uint32_t *shared, DevStats *stats)
 {
     if (stats->part_lost != 0) return;       /* this batch is recounted by the direct kernel */
+    constexpr int kLoaderWaves = LW, kLoaderThreads = LW * kWave;
+    constexpr int kProberThreads = kCountThreads - kLoaderThreads, kProberWaves = kProberThreads / kWave;
     constexpr int S = 1 << LG_S;
     constexpr int kSeg = S + kHalo;
     constexpr int kQueueCap = 128;                    /* per wave and bucket; what does not fit is finished in place */
