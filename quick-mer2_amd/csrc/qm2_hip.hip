@@ -280,7 +280,7 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
         if (src.sv) {
             const SeqView &sv = *src.sv;
             const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
-            const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu);
+            const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * kSplitWgPerCu);
             if (time_begin(c, &t, QM2_K_SPLIT_TEXT)) return 1;
             if (c->k == 30)
                 hipLaunchKernelGGL(split_text_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k,
@@ -1218,7 +1218,7 @@ extern "C" int qm2_route_device(qm2_ctx *c, const void *d_seq, size_t n, const u
     while ((1u << lgG) < n_owners) lgG++;
     SplitDst d = {d_slabs, d_fill, (uint32_t)slab_cap, nullptr, nullptr, 0};
     const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
-    const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu);
+    const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * kSplitWgPerCu);
     TimedLaunch t;
     if (time_begin(c, &t, QM2_K_ENCODE)) return 1;
     if (c->k == 30)

@@ -96,13 +96,21 @@ struct SplitLds {
     uint64_t sorted[kSplitSlots + 1];       /* the chunk sorted by child; last = trash slot          */
     uint32_t hist[kMaxFan + 1];             /* [kMaxFan] = trash bin of the empty slots (keeps the
                                                rank atomics and the scatter branch-free)             */
-    uint32_t off[kMaxFan];                  /* exclusive prefix of hist                              */
+    uint16_t off[kMaxFan];                  /* exclusive prefix of hist (< 2^16: a chunk has <= 16 K k-mers) */
     uint2    dl[kMaxFan];                   /* copy-out of the sorted chunk: element i of child c goes
                                                to slot i + dl.x of the child's region if i < dl.y
                                                (dl.x = reserved start - off, dl.y = off + what fits)  */
     uint32_t wsum[kMaxFan / kWave];
     uint32_t total;                         /* real k-mers in the sorted chunk                       */
 };
+static_assert(kMaxFan % kSplitThreads == 0 || kSplitThreads > kMaxFan, "whole children per thread");
+constexpr int kChildPerThread = kSplitThreads >= kMaxFan ? 1 : kMaxFan / kSplitThreads;
+constexpr int kSplitWgPerCu = kSplitThreads >= 1024 ? 1 : 2;      /* what the LDS of a CU holds */
+#if QM2_SPLIT_THREADS < 1024
+#define QM2_SPLIT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define QM2_SPLIT_OCCUPANCY
+#endif
 
 /* Sort one chunk by child in LDS.  Every thread holds kKpt k-mers km[j] with
  * tag[j] = (child << 16) | rank_in_child (rank from an LDS atomic on hist); empty slots carry
@@ -116,23 +124,27 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
 {
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     lds_barrier();                 /* hist complete; every wave is done reading the previous L.sorted / L.dl */
-    /* exclusive scan of hist[0..fan): one thread per child */
-    static_assert(kSplitThreads >= kMaxFan, "the scan uses one thread per child");
-    uint32_t mine = 0, incl = 0;
-    if (tid < kMaxFan) {
-        mine = tid < (int)fan ? L.hist[tid] : 0;
-        incl = mine;
+    /* exclusive scan of hist[0..fan): thread t takes children t, t + kSplitThreads, ... (kChildPerThread of them:
+     * consecutive lanes = consecutive children, so the reservations below are the contiguous, full-rate atomic shape) */
+    constexpr int C = kChildPerThread;
+    constexpr int kScanWaves = (kMaxFan / C) / kWave;          /* waves that hold children */
+    uint32_t mine[C], incl[C];
+    const bool holder = tid < kMaxFan / C;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+        const int child = tid + i * kSplitThreads;
+        mine[i] = holder && child < (int)fan ? L.hist[child] : 0;
+        incl[i] = mine[i];
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) {
-            uint32_t v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
+            const uint32_t v = __shfl_up(incl[i], o);
+            if (lane >= o) incl[i] += v;
         }
-        if (lane == kWave - 1) L.wsum[wave] = incl;
+        if (holder && lane == kWave - 1) L.wsum[i * kScanWaves + wave] = incl[i];
     }
     lds_barrier();
-    uint32_t g = 0, off = 0;
-    const bool reserve = tid < (int)fan && mine != 0;
-    if (tid < kMaxFan) {
+    uint32_t g[C], off[C];
+    {
         /* sums of the waves before this one: every wave scans the (at most 16) wave totals itself */
         static_assert(kMaxFan / kWave <= kWave, "one lane per wave total");
         uint32_t ws = lane < kMaxFan / kWave ? L.wsum[lane] : 0u;
@@ -141,48 +153,59 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
             const uint32_t v = __shfl_up(ws, o);
             if (lane >= o) ws += v;
         }
-        const uint32_t before = wave ? __shfl(ws, wave - 1) : 0u;
-        off = before + incl - mine;
-        L.off[tid] = off;
-        if (tid == kMaxFan - 1) L.total = before + incl;
-        /* reserve the run in the child's region; the returned offset is only needed for the
-         * copy-out, so the round trip overlaps the LDS scatter below */
-        if (reserve) g = atomicAdd(&d.cursors[child0 + (uint64_t)tid], mine);
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+            const int widx = i * kScanWaves + wave;            /* position of this wave's total for its i-th children */
+            const uint32_t before = widx ? __shfl(ws, widx - 1) : 0u;
+            off[i] = before + incl[i] - mine[i];
+            g[i] = 0;
+            if (holder) {
+                const int child = tid + i * kSplitThreads;
+                L.off[child] = (uint16_t)off[i];
+                /* reserve the run in the child's region; the returned offset is only needed for the
+                 * copy-out, so the round trip overlaps the LDS scatter below */
+                if (mine[i]) g[i] = atomicAdd(&d.cursors[child0 + (uint64_t)child], mine[i]);
+            }
+        }
+        const uint32_t tot = __shfl(ws, kMaxFan / kWave - 1);
+        if (tid == 0) L.total = tot;
     }
     lds_barrier();
 #pragma unroll
     for (int j = 0; j < kKpt; j++) {
         /* empty slots carry child id kMaxFan: they all land in the trash slot, no branch */
         const uint32_t child = tag[j] >> 16;
-        const uint32_t pos = child >= kMaxFan ? (uint32_t)kSplitSlots : L.off[child & (kMaxFan - 1)] + (tag[j] & 0xFFFFu);
+        const uint32_t pos = child >= kMaxFan ? (uint32_t)kSplitSlots : (uint32_t)L.off[child & (kMaxFan - 1)] + (tag[j] & 0xFFFFu);
         L.sorted[pos] = km[j];
     }
-    uint32_t f = mine;
-    if (tid < kMaxFan) {
-        if (reserve) f = g >= d.cap ? 0u : (d.cap - g < mine ? d.cap - g : mine);
-        L.dl[tid] = make_uint2(g - off, off + f);
+    uint32_t f[C];
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+        f[i] = mine[i];
+        if (holder) {
+            if (mine[i]) f[i] = g[i] >= d.cap ? 0u : (d.cap - g[i] < mine[i] ? d.cap - g[i] : mine[i]);
+            L.dl[tid + i * kSplitThreads] = make_uint2(g[i] - off[i], off[i] + f[i]);
+        }
     }
     lds_barrier();
-    if (reserve && f < mine) {
-        /* rare (skewed input): the child is full; this thread moves the rest of the run to the
-         * spill list, which the direct kernel probes at the end of the batch */
-        if (d.spill_cap == 0) lost += mine - f;               /* (qm2_route_device: no spill list, the caller is told) */
-        else {
-            const unsigned long long sb = atomicAdd(d.spill_count, (unsigned long long)(mine - f));
-            for (uint32_t i = f; i < mine; i++) {
-                const unsigned long long at = sb + (i - f);
-                if (at < d.spill_cap) d.spill[at] = L.sorted[off + i];
-                else lost++;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+        if (f[i] < mine[i]) {
+            /* rare (skewed input): the child is full; this thread moves the rest of the run to the
+             * spill list, which the direct kernel probes at the end of the batch */
+            if (d.spill_cap == 0) lost += mine[i] - f[i];         /* (qm2_route_device: no spill list, the caller is told) */
+            else {
+                const unsigned long long sb = atomicAdd(d.spill_count, (unsigned long long)(mine[i] - f[i]));
+                for (uint32_t e = f[i]; e < mine[i]; e++) {
+                    const unsigned long long at = sb + (e - f[i]);
+                    if (at < d.spill_cap) d.spill[at] = L.sorted[off[i] + e];
+                    else lost++;
+                }
             }
         }
     }
 }
 
-/* Copy-out of elements tid + PIECE * kSplitThreads of the sorted chunk: one element per lane, its child
- * found again from its hash (cheaper than keeping 16 K child ids in LDS), its destination from L.dl.
- * Neighbouring lanes hold neighbours of the same run, so the 8-byte stores of a wave fall into a few
- * contiguous pieces whatever the fan-out — a copy-out per RUN (round 1) costs instructions per run and
- * was what kept the fan-out at 128 and hg38-scale tables at three levels. */
 /* child of a k-mer at a level: `bits` bits of its home slot from bit `shift` on (shift + bits <= log2 H, so
  * the & (H - 1) of :92 is implied; bits = 0: everything is child 0) — one v_bfe_u32 */
 __device__ __forceinline__ uint32_t child_of(uint64_t km, uint32_t shift, uint32_t bits)
@@ -234,7 +257,7 @@ __device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, u
 /* `call` (qm2_route_device): the launch's totals {bases, k-mers, k-mers that fitted nowhere} go there
  * instead of into the context's statistics. */
 template <bool K30>
-__global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, uint32_t k, uint32_t shift, uint32_t bits,
+__global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_kernel(SeqView sv, uint32_t k, uint32_t shift, uint32_t bits,
                                                                    uint64_t n_chunks, SplitDst d, DevStats *stats,
                                                                    unsigned long long *call)
 {
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_text_kernel(SeqView sv, u
  * FLAT (level 1 of a shard, qm2_probe_slabs_device): the parents are the slabs a shard received from its
  * peers — src_cap apart, src_cursors[slab] k-mers in each — and they all feed the same children 0 .. fan-1. */
 template <bool FLAT>
-__global__ __launch_bounds__(kSplitThreads) void split_kmer_kernel(const uint64_t *src, const uint32_t *src_cursors,
+__global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_kernel(const uint64_t *src, const uint32_t *src_cursors,
                                                                    uint64_t src_cap, uint32_t shift, uint32_t bits,
                                                                    uint32_t wgs_per_parent, uint32_t n_parents,
                                                                    SplitDst d, DevStats *stats)
