@@ -105,7 +105,11 @@ __host__ __device__ __forceinline__ Packed pack16(uint4 v)
 /* Low 32 bits of (hi:lo) >> s, 0 <= s < 32 (one v_alignbit_b32). */
 __host__ __device__ __forceinline__ uint32_t funnel_r(uint32_t lo, uint32_t hi, int s)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s);     /* (written out, hipcc makes 64-bit shifts of some of them) */
+#else
     return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> s);
+#endif
 }
 
 /* Reverse-complement image of a packed word: base i moves to bits [2i+1:2i]
