@@ -506,6 +506,16 @@ def main():
         barrier()
         reduce_ms = 1e3 * (time.perf_counter() - tr0)
 
+    if os.environ.get("QM2_CURSOR_PROBE"):    # diagnostic builds only (-DQM2_EXPERIMENT)
+        import ctypes as _C
+        fn = pyqm2.lib().qm2_debug_cursor_probe
+        fn.argtypes = [_C.c_void_p, _C.c_int, _C.c_int, _C.POINTER(_C.c_float)]
+        res = {}
+        for lg in (0, 0, 2, 4, 6):
+            ms = _C.c_float()
+            fn(ctx._h, 2000, lg, _C.byref(ms))
+            res.setdefault(lg, []).append(round(256 * 1024 * 2000 / ms.value / 1e6, 1))
+        sys.stderr.write("CURSOR_PROBE G atomics/s by lg stride: %s\n" % res)
     try:                                     # diagnostic builds only (-DQM2_STAMPS): phase stamps of bucket_count
         import ctypes as _C
         fn = pyqm2.lib().qm2_debug_stamps
@@ -520,10 +530,11 @@ def main():
                             100.0 * acc[2] / max(1, lt), 100.0 * acc[3] / max(1, lt),
                             npw, ptot / npw, 100.0 * acc[4] / max(1, ptot), 100.0 * acc[5] / max(1, ptot),
                             100.0 * acc[6] / max(1, ptot), 100.0 * acc[7] / max(1, ptot)))
-        if acc[24]:
+        if acc[20]:
             tot = sum(acc[16:20])
-            sys.stderr.write("STAMPS split_kmer waves=%d cycles/wave=%.0f zero+barrier=%.1f%% load_hash_hist_copy=%.1f%% sort=%.1f%% tail=%.1f%%\n"
-                             % (acc[24], tot / acc[24], 100.0 * acc[16] / tot, 100.0 * acc[17] / tot, 100.0 * acc[18] / tot, 100.0 * acc[19] / tot))
+            sys.stderr.write("STAMPS split_text waves=%d kcycles/wave: window=%.0f zero+barrier=%.0f kmers+copy_out=%.0f sort=%.0f total=%.0f\n"
+                             % (acc[20], acc[16] / acc[20] / 1e3, acc[17] / acc[20] / 1e3, acc[18] / acc[20] / 1e3, acc[19] / acc[20] / 1e3,
+                                tot / acc[20] / 1e3))
     except AttributeError:
         pass
 

@@ -194,13 +194,26 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
         const double capd = mean * (l == 0 ? 1.12 : 1.22) + 8.0 * std::sqrt(mean + 1.0) + 128.0;
         if (capd > 4.0e9) return fail("qm2: batch too large for the partition plan");
         p.cap[l] = ((uint32_t)capd + 63u) & ~63u;          /* whole sectors */
-        slots[l] = p.buckets[l] * (uint64_t)p.cap[l];
-        mean = (double)p.cap[l];
+        mean = (double)p.cap[l];                           /* (the next level is sized from the whole child) */
+        if (l == 0) {
+            /* a level that another split reads: one sub-region per XCD and child (sub_region0), each with the
+             * Poisson room of its own, smaller, fill */
+            p.subs0 = p.levels >= 2 && p.cap[0] >= 8u * 4096u && !getenv("QM2_NO_SUBS") ? 8u : 1u;
+            if (p.subs0 > 1) {
+                const double m8 = capd / 8.0;
+                p.cap[0] = ((uint32_t)(m8 + 8.0 * std::sqrt(m8 + 1.0) + 128.0) + 63u) & ~63u;
+            }
+            /* segmented on top of that (C3, 50 M reads per launch: split_text 19.2 -> 18.4 ms, split_kmer 21.8 -> 21.4;
+             * without the sub-regions it was the slower layout: 27.7 ms): whole segments per region then */
+            p.seg0 = p.subs0 > 1 && p.cap[0] >= 4u * kSegKmers && !getenv("QM2_NO_SEG");
+            if (p.seg0) p.cap[0] = (p.cap[0] + kSegKmers - 1u) & ~(kSegKmers - 1u);
+        }
+        slots[l] = p.buckets[l] * (l == 0 ? p.subs0 : 1u) * (uint64_t)p.cap[l];
     }
     p.buf_slots[0] = std::max(slots[0], slots[2]);
     p.buf_slots[1] = slots[1];
     p.n_cursors = 0;
-    for (int l = 0; l < p.levels; l++) { p.cursor_off[l] = p.n_cursors; p.n_cursors += p.buckets[l]; }
+    for (int l = 0; l < p.levels; l++) { p.cursor_off[l] = p.n_cursors; p.n_cursors += p.buckets[l] * (l == 0 ? p.subs0 : 1u); }
     p.spill_cap = want / 4 + 4096;                                     /* 2 B of HBM per input byte */
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++)
@@ -276,36 +289,49 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
     TimedLaunch t;
     /* level 1: text or slabs -> buckets[0] */
     {
-        SplitDst d = {p.buf[0], p.cursors + p.cursor_off[0], p.cap[0], p.spill, p.spill_count, p.spill_cap};
+        uint32_t lg_subs = 0;
+        while ((1u << lg_subs) < p.subs0) lg_subs++;
+        SplitDst d = {p.buf[0], p.cursors + p.cursor_off[0], p.cap[0], p.spill, p.spill_count, p.spill_cap,
+                      p.bits[0] + lg_subs + kSegLg, p.subs0};
         if (src.sv) {
             const SeqView &sv = *src.sv;
             const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
             const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * kSplitWgPerCu);
             if (time_begin(c, &t, QM2_K_SPLIT_TEXT)) return 1;
-            if (c->k == 30)
-                hipLaunchKernelGGL(split_text_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k,
-                                   p.shift[0], p.bits[0], n_chunks, d, c->stats, (unsigned long long *)nullptr);
-            else
-                hipLaunchKernelGGL(split_text_kernel<false>, dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k,
-                                   p.shift[0], p.bits[0], n_chunks, d, c->stats, (unsigned long long *)nullptr);
+#define QM2_LAUNCH_TEXT(K30_, SEG_)                                                                                      \
+            hipLaunchKernelGGL((split_text_kernel<K30_, SEG_>), dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k,       \
+                               p.shift[0], p.bits[0], n_chunks, d, c->stats, (unsigned long long *)nullptr)
+            if (c->k == 30) { if (p.seg0) QM2_LAUNCH_TEXT(true, true); else QM2_LAUNCH_TEXT(true, false); }
+            else            { if (p.seg0) QM2_LAUNCH_TEXT(false, true); else QM2_LAUNCH_TEXT(false, false); }
+#undef QM2_LAUNCH_TEXT
         } else {
             const uint32_t chunks = (uint32_t)std::max<uint64_t>(1, ((src.slab_cap + kSplitSlots - 1) / kSplitSlots + 3) / 4);
             if (time_begin(c, &t, QM2_K_SPLIT_KMER)) return 1;
-            hipLaunchKernelGGL(split_kmer_kernel<true>, dim3(chunks * src.n_slabs), dim3(kSplitThreads), 0, s,
-                               src.slabs, src.fill, src.slab_cap, p.shift[0], p.bits[0], chunks, src.n_slabs, d, c->stats);
+#define QM2_LAUNCH_FLAT(SEG_)                                                                                            \
+            hipLaunchKernelGGL((split_kmer_kernel<true, false, SEG_>), dim3(chunks * src.n_slabs), dim3(kSplitThreads), 0, s, \
+                               src.slabs, src.fill, src.slab_cap, 0u, ~0u, p.shift[0], p.bits[0], chunks, src.n_slabs, d, c->stats)
+            if (p.seg0) QM2_LAUNCH_FLAT(true); else QM2_LAUNCH_FLAT(false);
+#undef QM2_LAUNCH_FLAT
         }
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
     }
     /* deeper levels: buckets[l-1] -> buckets[l], ping-pong between the two buffers */
     for (int l = 1; l < p.levels; l++) {
-        SplitDst d = {p.buf[l & 1], p.cursors + p.cursor_off[l], p.cap[l], p.spill, p.spill_count, p.spill_cap};
+        SplitDst d = {p.buf[l & 1], p.cursors + p.cursor_off[l], p.cap[l], p.spill, p.spill_count, p.spill_cap, 0, 1};
+        const uint32_t n_parents = (uint32_t)p.buckets[l - 1] * (l == 1 ? p.subs0 : 1u);
+        uint32_t lg_subs = 0;
+        while ((1u << lg_subs) < p.subs0) lg_subs++;
         /* ~4 chunks per workgroup so that the prefetch has something to hide behind */
         const uint32_t chunks = std::max<uint32_t>(1u, ((p.cap[l - 1] + kSplitSlots - 1) / kSplitSlots + 3) / 4);
         if (time_begin(c, &t, QM2_K_SPLIT_KMER)) return 1;
-        hipLaunchKernelGGL(split_kmer_kernel<false>, dim3(chunks * (uint32_t)p.buckets[l - 1]), dim3(kSplitThreads), 0, s,
-                           p.buf[(l - 1) & 1], p.cursors + p.cursor_off[l - 1], (uint64_t)p.cap[l - 1],
-                           p.shift[l], p.bits[l], chunks, (uint32_t)p.buckets[l - 1], d, c->stats);
+#define QM2_LAUNCH_LEVEL(SRC_SEG_)                                                                                       \
+        hipLaunchKernelGGL((split_kmer_kernel<false, SRC_SEG_, false>), dim3(chunks * n_parents), dim3(kSplitThreads),  \
+                           0, s, p.buf[(l - 1) & 1], p.cursors + p.cursor_off[l - 1], (uint64_t)p.cap[l - 1],         \
+                           p.bits[0] + lg_subs + kSegLg, (uint32_t)p.buckets[l - 1] - 1u, p.shift[l], p.bits[l], chunks, \
+                           n_parents, d, c->stats)
+        if (l == 1 && p.seg0) QM2_LAUNCH_LEVEL(true); else QM2_LAUNCH_LEVEL(false);
+#undef QM2_LAUNCH_LEVEL
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
     }
@@ -1216,16 +1242,16 @@ extern "C" int qm2_route_device(qm2_ctx *c, const void *d_seq, size_t n, const u
     const SeqView sv = seq_view((const uint8_t *)d_seq, n, 0, d_sup, n_sup);
     uint32_t lgG = 0;
     while ((1u << lgG) < n_owners) lgG++;
-    SplitDst d = {d_slabs, d_fill, (uint32_t)slab_cap, nullptr, nullptr, 0};
+    SplitDst d = {d_slabs, d_fill, (uint32_t)slab_cap, nullptr, nullptr, 0, 0, 1};
     const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
     const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * kSplitWgPerCu);
     TimedLaunch t;
     if (time_begin(c, &t, QM2_K_ENCODE)) return 1;
     if (c->k == 30)
-        hipLaunchKernelGGL(split_text_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, c->stream, sv, c->k,
+        hipLaunchKernelGGL((split_text_kernel<true, false>), dim3(grid), dim3(kSplitThreads), 0, c->stream, sv, c->k,
                            c->lgH - lgG, lgG, n_chunks, d, c->stats, (unsigned long long *)d_call);
     else
-        hipLaunchKernelGGL(split_text_kernel<false>, dim3(grid), dim3(kSplitThreads), 0, c->stream, sv, c->k,
+        hipLaunchKernelGGL((split_text_kernel<false, false>), dim3(grid), dim3(kSplitThreads), 0, c->stream, sv, c->k,
                            c->lgH - lgG, lgG, n_chunks, d, c->stats, (unsigned long long *)d_call);
     HIP_OK(hipGetLastError());
     return time_end(c, &t, true);

@@ -83,14 +83,56 @@ __device__ __forceinline__ unsigned long long stamp_now()
 #define QM2_STAMP(I) do { } while (0)
 #endif
 
+/* Two layouts of a level's buffer.
+ *   child-major (SEG = false): child c occupies [c * cap, (c + 1) * cap).
+ *   segmented   (SEG = true; the level that the text — or the slabs — are split into, when another split reads
+ *     it): 64 KiB segments laid out [segment][child], k-mer e of child c at
+ *         ((e >> kSegLg) << lg_row) + (c << kSegLg) + (e & (kSegKmers - 1)),    2^lg_row = children * kSegKmers.
+ *     Why: that level is written as 1024 streams by every workgroup.  Child-major they lie ~70 MB apart over a 72 GB
+ *     buffer (C3, 50 M reads per launch), and rocprofv3 shows what that costs: TCP_UTCL1_TRANSLATION_MISS = one per
+ *     run written (5.0e8 per launch, 23 % of the requests; split_kmer, whose 1024 children are neighbours: 1e5) and
+ *     GRBM_UTCL2_BUSY = the whole kernel.  tools/micro/tlb_probe.hip: a CU's translation cache holds 1024 write
+ *     streams 2 MiB apart (no misses) but not 64 of them 64 MiB apart.  Uniform hashing fills all children at the
+ *     same pace, so segmented, all 1024 fronts sit inside one or two 64 MiB rows. */
+#ifndef QM2_SEG_LG
+#define QM2_SEG_LG 13
+#endif
+constexpr uint32_t kSegLg = QM2_SEG_LG, kSegKmers = 1u << kSegLg;
+
 struct SplitDst {
-    uint64_t           *kmers;      /* child c occupies [c*cap, (c+1)*cap)                      */
+    uint64_t           *kmers;      /* the level's buffer                                        */
     uint32_t           *cursors;    /* per child: k-mers reserved so far (may exceed cap)        */
-    uint32_t            cap;
+    uint32_t            cap;        /* k-mers a child's region holds (segmented: whole segments) */
     uint64_t           *spill;      /* k-mers that did not fit: probed by the direct kernel      */
     unsigned long long *spill_count;
     uint64_t            spill_cap;
+    uint32_t            lg_row;     /* segmented layout: log2(k-mers per row of segments)        */
+    uint32_t            subs;       /* 1, or 8: every child's region is cut into one sub-region per XCD (below) */
 };
+
+/* Sub-regions (the level the text — or the slabs — are split into, when another split reads it).
+ *
+ * A run is ~16 k-mers and starts wherever the previous reservation of its child ended, so most 128-byte lines of
+ * a child's region are written by two workgroups.  When those sit on different XCDs, the line is dirty in two L2s,
+ * each of which writes its part back as a masked write: tools/micro/front_probe.hip measures 23 ms for 35 GB
+ * written that way against 12.9 ms when every line only ever passes through ONE L2 (and 18.6 - 23 ms from one
+ * process to the next — the text level's own spread, 21 - 29 ms, before this).  So each child has 8 sub-regions
+ * with a cursor each, region (x * fan + c) for workgroups with blockIdx.x % 8 == x, which is the XCD the
+ * hardware dispatches them to (round-robin; were it not, only this speed-up would be lost).  The next level
+ * takes the 8 * fan sub-regions as parents; parent P feeds the children of P % fan. */
+__device__ __forceinline__ uint64_t sub_region0(const SplitDst &d, uint32_t fan)
+{
+    return (uint64_t)(blockIdx.x & (d.subs - 1u)) * fan;
+}
+
+template <bool SEG>
+__device__ __forceinline__ uint64_t slot_of(uint64_t child, uint32_t e, uint32_t cap, uint32_t lg_row)
+{
+    if constexpr (SEG)
+        return ((uint64_t)(e >> kSegLg) << lg_row) + (((uint32_t)child << kSegLg) | (e & (kSegKmers - 1u)));
+    else
+        return child * (uint64_t)cap + e;
+}
 
 struct SplitLds {
     uint64_t sorted[kSplitSlots + 1];       /* the chunk sorted by child; last = trash slot          */
@@ -220,7 +262,7 @@ __device__ __forceinline__ uint64_t copy_fetch(const SplitLds &L)
     return L.sorted[threadIdx.x + PIECE * kSplitThreads];
 }
 
-template <int PIECE>
+template <int PIECE, bool SEG>
 __device__ __forceinline__ void copy_store(const SplitLds &L, uint64_t km, const SplitDst &d, uint64_t child0, uint32_t shift,
                                            uint32_t bits)
 {
@@ -233,19 +275,25 @@ __device__ __forceinline__ void copy_store(const SplitLds &L, uint64_t km, const
     /* (an address-space-1 pointer: a generic one would make this a flat_store, which also counts on
      * lgkmcnt — and every LDS wait and lds_barrier() of these kernels would wait for the stores) */
     typedef uint64_t __attribute__((address_space(1))) global_u64;
-    global_u64 *dst = (global_u64 *)(uintptr_t)(d.kmers + (child0 + child) * (uint64_t)d.cap);
-    if (i < dy) dst[i + dx] = km;
+    if constexpr (SEG) {
+        global_u64 *dst = (global_u64 *)(uintptr_t)d.kmers;
+        if (i < dy) dst[slot_of<true>(child0 + child, i + dx, d.cap, d.lg_row)] = km;
+    } else {
+        global_u64 *dst = (global_u64 *)(uintptr_t)(d.kmers + (child0 + child) * (uint64_t)d.cap);
+        if (i < dy) dst[i + dx] = km;
+    }
 }
 
-template <int PIECE>
+template <int PIECE, bool SEG>
 __device__ __forceinline__ void copy_piece(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
 {
-    copy_store<PIECE>(L, copy_fetch<PIECE>(L), d, child0, shift, bits);
+    copy_store<PIECE, SEG>(L, copy_fetch<PIECE>(L), d, child0, shift, bits);
 }
 
+template <bool SEG>
 __device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
 {
-#define QM2_CP(J) copy_piece<J>(L, d, child0, shift, bits);
+#define QM2_CP(J) copy_piece<J, SEG>(L, d, child0, shift, bits);
     QM2_CP(0) QM2_CP(1) QM2_CP(2) QM2_CP(3) QM2_CP(4) QM2_CP(5) QM2_CP(6) QM2_CP(7)
     QM2_CP(8) QM2_CP(9) QM2_CP(10) QM2_CP(11) QM2_CP(12) QM2_CP(13) QM2_CP(14) QM2_CP(15)
 #undef QM2_CP
@@ -256,7 +304,7 @@ __device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, u
  * the home slot.  One chunk = 16 tiles (one per wave). */
 /* `call` (qm2_route_device): the launch's totals {bases, k-mers, k-mers that fitted nowhere} go there
  * instead of into the context's statistics. */
-template <bool K30>
+template <bool K30, bool SEG>
 __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_kernel(SeqView sv, uint32_t k, uint32_t shift, uint32_t bits,
                                                                    uint64_t n_chunks, SplitDst d, DevStats *stats,
                                                                    unsigned long long *call)
@@ -266,8 +314,12 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     unsigned long long n_bases = 0, n_kmers = 0, lost = 0;
     bool pend = false;
+    const uint64_t child0 = sub_region0(d, fan);
     /* the 16 bytes of this lane for the NEXT chunk are fetched while the current one is processed */
     uint4 bytes = load16_raw(sv, lane_offset(((uint64_t)blockIdx.x * kSplitWaves + wave) * kTileBytes, lane));
+#ifdef QM2_STAMPS
+    unsigned long long st_acc[24] = {0}, st_last = stamp_now();
+#endif
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint64_t tile = chunk * kSplitWaves + wave;
         const uint4 cur = bytes;
@@ -275,8 +327,10 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
         const Window W = make_window_from<K30>(sv, tile * kTileBytes, lane, k, cur);
         n_bases += W.n_bases;
         n_kmers += __builtin_popcount(W.emit);
+        QM2_STAMP(16);
         for (int i = tid; i <= kMaxFan; i += kSplitThreads) L.hist[i] = 0;
         lds_barrier();
+        QM2_STAMP(17);
         uint64_t km[kKpt];
         uint32_t tag[kKpt];
         /* k-mer J of this chunk, then copy-out piece J of the previous chunk */
@@ -286,15 +340,23 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
             km[J] = kmer_at<K30, J>(W, k);                                         \
             const uint32_t b = (W.emit & (0x8000u >> J)) ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
-            if (pend) copy_store<J>(L, out, d, 0, shift, bits);                    \
+            if (pend) copy_store<J, SEG>(L, out, d, child0, shift, bits);          \
         }
         QM2_T(0) QM2_T(1) QM2_T(2) QM2_T(3) QM2_T(4) QM2_T(5) QM2_T(6) QM2_T(7)
         QM2_T(8) QM2_T(9) QM2_T(10) QM2_T(11) QM2_T(12) QM2_T(13) QM2_T(14) QM2_T(15)
 #undef QM2_T
-        sort_chunk(L, km, tag, 0, fan, d, lost);
+        QM2_STAMP(18);
+        sort_chunk(L, km, tag, child0, fan, d, lost);
+        QM2_STAMP(19);
         pend = true;
     }
-    if (pend) copy_all(L, d, 0, shift, bits);
+    if (pend) copy_all<SEG>(L, d, child0, shift, bits);
+#ifdef QM2_STAMPS
+    if (lane == 0) {
+        for (int i = 16; i < 20; i++) atomicAdd(&qm2_stamp_acc[i], st_acc[i]);
+        atomicAdd(&qm2_stamp_acc[20], 1ull);
+    }
+#endif
     n_bases = wave_sum(n_bases); n_kmers = wave_sum(n_kmers); lost = wave_sum(lost);
     if (lane == 0) {
         if (call) {
@@ -313,9 +375,9 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
  * takes its chunks x, x + wgs_per_parent, ...
  * FLAT (level 1 of a shard, qm2_probe_slabs_device): the parents are the slabs a shard received from its
  * peers — src_cap apart, src_cursors[slab] k-mers in each — and they all feed the same children 0 .. fan-1. */
-template <bool FLAT>
+template <bool FLAT, bool SRC_SEG, bool DST_SEG>
 __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_kernel(const uint64_t *src, const uint32_t *src_cursors,
-                                                                   uint64_t src_cap, uint32_t shift, uint32_t bits,
+                                                                   uint64_t src_cap, uint32_t src_lg_row, uint32_t parent_mask, uint32_t shift, uint32_t bits,
                                                                    uint32_t wgs_per_parent, uint32_t n_parents,
                                                                    SplitDst d, DevStats *stats)
 {
@@ -336,8 +398,8 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
     if (n > src_cap) n = src_cap;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     unsigned long long lost = 0;
-    const uint64_t *in = src + parent * src_cap;
-    const uint64_t child0 = FLAT ? 0 : parent * fan;
+    /* (parent_mask: the parents are the sub-regions of the level above, see sub_region0) */
+    const uint64_t child0 = FLAT ? sub_region0(d, fan) : (parent & parent_mask) * fan;
     bool pend = false;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     /* the next chunk's k-mers are loaded (16 bytes a lane: elements 2 t, 2 t + 1 of each row of 2048) while
@@ -347,7 +409,9 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
 #pragma unroll
         for (int j = 0; j < kKpt / 2; j++) {
             const uint64_t at = first + 2u * ((uint64_t)j * kSplitThreads + tid);
-            nxt[j] = at < n ? *reinterpret_cast<const u32x4 *>(in + at) : u32x4{~0u, ~0u, ~0u, ~0u};
+            /* (at is even and so is every segment's length: both k-mers of a load lie in one segment) */
+            nxt[j] = at < n ? *reinterpret_cast<const u32x4 *>(src + slot_of<SRC_SEG>(parent, (uint32_t)at, (uint32_t)src_cap, src_lg_row))
+                            : u32x4{~0u, ~0u, ~0u, ~0u};
         }
     };
     fetch((uint64_t)bx * kSplitSlots);
@@ -368,7 +432,7 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
             const uint64_t out = pend ? copy_fetch<J>(L) : 0;                      \
             const uint32_t b = km[J] != kPad ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
-            if (pend) copy_store<J>(L, out, d, child0, shift, bits);               \
+            if (pend) copy_store<J, DST_SEG>(L, out, d, child0, shift, bits);      \
         }
         QM2_K(0) QM2_K(1) QM2_K(2) QM2_K(3) QM2_K(4) QM2_K(5) QM2_K(6) QM2_K(7)
         QM2_K(8) QM2_K(9) QM2_K(10) QM2_K(11) QM2_K(12) QM2_K(13) QM2_K(14) QM2_K(15)
@@ -376,7 +440,7 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
         sort_chunk(L, km, tag, child0, fan, d, lost);
         pend = true;
     }
-    if (pend) copy_all(L, d, child0, shift, bits);
+    if (pend) copy_all<DST_SEG>(L, d, child0, shift, bits);
     lost = wave_sum(lost);
     if (lane == 0 && lost) atomicAdd(&stats->part_lost, lost);
 }
