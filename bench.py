@@ -506,16 +506,6 @@ def main():
         barrier()
         reduce_ms = 1e3 * (time.perf_counter() - tr0)
 
-    if os.environ.get("QM2_CURSOR_PROBE"):    # diagnostic builds only (-DQM2_EXPERIMENT)
-        import ctypes as _C
-        fn = pyqm2.lib().qm2_debug_cursor_probe
-        fn.argtypes = [_C.c_void_p, _C.c_int, _C.c_int, _C.POINTER(_C.c_float)]
-        res = {}
-        for lg in (0, 0, 2, 4, 6):
-            ms = _C.c_float()
-            fn(ctx._h, 2000, lg, _C.byref(ms))
-            res.setdefault(lg, []).append(round(256 * 1024 * 2000 / ms.value / 1e6, 1))
-        sys.stderr.write("CURSOR_PROBE G atomics/s by lg stride: %s\n" % res)
     try:                                     # diagnostic builds only (-DQM2_STAMPS): phase stamps of bucket_count
         import ctypes as _C
         fn = pyqm2.lib().qm2_debug_stamps

@@ -1161,6 +1161,33 @@ def test_c3_scale_partitioned_equals_direct(qm2, torch_cuda, hg38_scale):
         _oracle_sample_equal(qm2, env, sample, flags)
 
 
+def test_c3_scale_skew_overflows_the_sub_regions(qm2, torch_cuda, hg38_scale):
+    """Two-level partition at hg38 scale with a skewed stream: 4 % poly-A / poly-T reads put 24 M copies of k-mer 0
+    into ONE level-1 child, i.e. into its 8 per-XCD sub-regions (~90 k k-mers each at this batch size), which
+    overflow into the spill list; a run of one repeated real read floods another child the same way.  Counters and
+    statistics must equal the direct kernel's on the same bytes."""
+    torch, env = torch_cuda, hg38_scale
+    H, k, keys, reads, rl = env["H"], env["k"], env["keys"], env["reads"], env["rl"]
+    poly = torch.frombuffer(bytearray((b"A" * rl + b"\n") * 150_000 + (b"T" * rl + b"\n") * 50_000), dtype=torch.uint8).cuda()
+    one = reads[:rl + 1].repeat(100_000)                                        # the same 121 k-mers 100 k times
+    blob = torch.cat([reads[:2_000_000 * (rl + 1)], poly, one, reads[2_000_000 * (rl + 1):3_000_000 * (rl + 1)]])
+    out = []
+    for flags in (qm2.FLAG_DIRECT, qm2.FLAG_PARTITION | qm2.FLAG_TIMING):
+        cnt = torch.zeros(H, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=cnt.data_ptr(), flags=flags) as c:
+            c.submit_device(blob.data_ptr(), blob.numel())
+            _, st = c.finish(want_depth=False)
+            if flags & qm2.FLAG_PARTITION:
+                pr = c.profile()
+                assert pr["partitioned_batches"] == 1 and pr["fallback_batches"] == 0     # spill list, not a recount
+                assert pr["class_launches"]["probe"] >= 1
+        out.append((cnt, st))
+    assert out[0][1] == out[1][1]
+    assert out[0][1]["n_bases"] == 3_300_000 * rl
+    assert torch.equal(out[0][0], out[1][0])
+
+
 def test_c5_hifi_reads_at_hg38_scale(qm2, torch_cuda, hg38_scale):
     """C5 at its stated shape: 50 k HiFi-like reads U(15 000, 20 000) bp (0.87 G bases, one line per
     read, QuicKmer.c:388) against the H = 2^32 dictionary: both pipelines equal, conservation,

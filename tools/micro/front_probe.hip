@@ -41,7 +41,8 @@ __global__ __launch_bounds__(1024) void fronts_kernel(uint64_t *buf, uint32_t *c
         const uint32_t rot = (blockIdx.x * 37u + c * 101u) & 1023u;
         // all of the chunk's reservations first, like the real kernel (one atomic per thread), then the stores
         // ragged: run lengths run/2 .. run (mean 3/4 run), so that runs start and end anywhere in a sector, as the real ones do
-        auto len_of = [&](uint32_t i) { return ragged ? run / 2u + ((i * 0x9E3779B1u + c * 0x85EBCA6Bu + blockIdx.x * 0xC2B2AE35u) >> 20) % (run / 2u + 1u) : run; };
+        auto len_of = [&](uint32_t i) { const uint32_t raw = run / 2u + ((i * 0x9E3779B1u + c * 0x85EBCA6Bu + blockIdx.x * 0xC2B2AE35u) >> 20) % (run / 2u + 1u);
+                                        return ragged ? (raw + ragged - 1u) / ragged * ragged : run; };   /* (ragged = 1: as is; 4, 8: padded to that many k-mers) */
         const uint32_t sub = L.mode == 3 ? (blockIdx.x & 7u) << 10 : 0u;
         if (threadIdx.x < nf) base[c & 1][threadIdx.x] = atomicAdd(&cursors[sub + ((rot + threadIdx.x) & 1023u)], len_of(threadIdx.x));
         __syncthreads();
@@ -81,6 +82,10 @@ int main(int argc, char **argv)
         {"child-major RAGGED 8..16    ", {0, 0, cap}, 16, 1},
         {"per-XCD     RAGGED 8..16    ", {3, 0, cap}, 16, 1},
         {"per-XCD     aligned 16      ", {3, 0, cap}, 16, 0},
+        {"per-XCD RAGGED padded to 4  ", {3, 0, cap}, 16, 4},
+        {"per-XCD RAGGED padded to 8  ", {3, 0, cap}, 16, 8},
+        {"per-XCD RAGGED 16..32       ", {3, 0, cap}, 32, 1},
+        {"per-XCD RAGGED 16..32 pad 4 ", {3, 0, cap}, 32, 4},
         {"staggered   RAGGED 8..16    ", {2, 0, cap}, 16, 1},
         {"segmented 4 KiB  RAGGED     ", {1, 9, 0}, 16, 1},
         {"segmented 64 KiB RAGGED     ", {1, 13, 0}, 16, 1},

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/sweep_env_args.sh "bench args" VAR v1 v2 ...  — one bench process per value of VAR
+# usage: tools/sweep.sh "bench args" VAR v1 v2 ...  — one bench process per value of VAR
 args=$1; var=$2; shift 2
 for v in "$@"; do
   env $var=$v timeout -k 10 300 python bench.py --no-cpu-baseline --no-streamed $args 2>/tmp/sweep.err > /tmp/sweep.json || { echo "$var=$v failed"; tail -3 /tmp/sweep.err; continue; }
