@@ -732,6 +732,9 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
             LM = (uint32_t)__ffsll((long long)zm_) - 1u;                                     \
             LE = (uint32_t)__ffsll((long long)ze_) - 1u;                                     \
         }
+#ifndef QM2_WALK8
+#define QM2_WALK8 1         /* 8 fingerprints per step in the queue walk (phase B) */
+#endif
 #ifndef QM2_WIN8
 #define QM2_WIN8 0          /* 8 fingerprints per k-mer in phase A: queue 10 % -> 2 %, but 3 % SLOWER at C3 (25.2 vs 24.5 ms, same box) */
 #endif
@@ -741,7 +744,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         auto walk = [&](uint64_t km, uint32_t p) {
             uint32_t seen = 0;
             for (;;) {
-                if (p + 4u > seg || km == 0) {
+                if (p + (QM2_WALK8 ? 8u : 4u) > seg || km == 0) {
                     for (;;) {
                         uint64_t v;
                         uint32_t *ctr;
@@ -763,12 +766,24 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                     break;
                 }
                 uint32_t lm, le;
+#if QM2_WALK8
+                /* eight fingerprints a step: a wave's queue is finished when its LONGEST walk is, and every step
+                 * is three dependent LDS round trips */
+                const uint32_t f0 = bfp[p >> 2], f1 = bfp[(p >> 2) + 1], f2 = bfp[(p >> 2) + 2];
+                const uint32_t w = __builtin_amdgcn_alignbyte(f1, f0, p), w1 = __builtin_amdgcn_alignbyte(f2, f1, p);
+                QM2_WINDOW8(w, w1, km, lm, le)
+                const uint32_t c = __builtin_amdgcn_ubfe(lm, 3, 3);
+                seen += (min(min(lm, le), 63u) >> 3) + 1u;
+                if (lm > le) break;                                         /* an empty slot first */
+                if (lm <= 63u && bkey[p + c] == km) { atomicAdd(&bcnt[p + c], 1u); n_hits++; break; }
+#else
                 const uint32_t w = __builtin_amdgcn_alignbyte(bfp[(p >> 2) + 1], bfp[p >> 2], p);
                 QM2_WINDOW(w, km, lm, le)
                 const uint32_t c = __builtin_amdgcn_ubfe(lm, 3, 2);
                 seen += (min(min(lm, le), 31u) >> 3) + 1u;
                 if (lm > le) break;                                         /* an empty slot first */
                 if (lm <= 31u && bkey[p + c] == km) { atomicAdd(&bcnt[p + c], 1u); n_hits++; break; }
+#endif
                 p += c + 1u;
             }
             n_probes += seen;
