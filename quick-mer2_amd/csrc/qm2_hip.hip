@@ -185,16 +185,16 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     double mean = (double)want;
     uint64_t slots[kMaxLevels] = {0, 0, 0};
     for (int l = 0; l < p.levels; l++) {
-        mean /= (double)(1u << p.bits[l]);
-        /* expected fill + room for skew (repeated k-mers all land in one child, so the room grows
-         * with depth: each level is sized from the capacity of the one above) + the Poisson spread
-         * of uniform hashing; what still does not fit goes to the spill list.  Sizing every level
-         * from the true mean instead saves 15 % of the memory but was measured 10 % slower in
-         * split_kmer (the bucket stride matters), so the compounding stays. */
-        const double capd = mean * (l == 0 ? 1.12 : 1.22) + 8.0 * std::sqrt(mean + 1.0) + 128.0;
+        /* every level from the batch's own bound (its bytes bound its k-mers; 150-bp reads use 0.8 of it):
+         * expected fill + 12 % for skew (repeated k-mers all land in one child) + the Poisson spread of uniform
+         * hashing; what still does not fit goes to the spill list.  (Until late in round 2 each level was sized
+         * from the CAPACITY of the one above — 1.12 x 1.22 compounded, 96 instead of 79 GB for the finest level
+         * of a 7.55 GB batch — because the smaller stride had measured 10 % slower in split_kmer; with the
+         * per-XCD sub-regions above it the difference is 1.5 %: 21.2 vs 20.8 ms.) */
+        mean = (double)want / (double)p.buckets[l];
+        const double capd = mean * 1.12 + 8.0 * std::sqrt(mean + 1.0) + 128.0;
         if (capd > 4.0e9) return fail("qm2: batch too large for the partition plan");
         p.cap[l] = ((uint32_t)capd + 63u) & ~63u;          /* whole sectors */
-        mean = (double)p.cap[l];                           /* (the next level is sized from the whole child) */
         if (l == 0) {
             /* a level that another split reads: one sub-region per XCD and child (sub_region0), each with the
              * Poisson room of its own, smaller, fill */
@@ -230,6 +230,10 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
         return 1;
     }
     p.reserved = want;
+    if (getenv("QM2_PLAN_PRINT"))
+        fprintf(stderr, "QM2 plan for %llu bytes: levels %d, bits %u+%u+%u, sub-regions %u%s, cap %u / %u / %u k-mers, buffers %.1f + %.1f GB, spill %.1f GB, %llu cursors\n",
+                (unsigned long long)n, p.levels, p.bits[0], p.bits[1], p.bits[2], p.subs0, p.seg0 ? " segmented" : "", p.cap[0], p.cap[1], p.cap[2],
+                p.buf_slots[0] * 8e-9, p.buf_slots[1] * 8e-9, p.spill_cap * 8e-9, (unsigned long long)p.n_cursors);
     return 0;
 }
 
