@@ -488,11 +488,30 @@ struct CountGeo {
     uint64_t half;          /* H >> 1: buckets at or above walk down                            */
 };
 
-/* fingerprint of a stored key: odd, 1..255; of an empty slot: 0; beyond the staged slice: 0xFE */
+/* fingerprint of a stored key: odd, 1..255; of an empty slot: 0; beyond the staged slice: 0xFE.
+ * A fold of the whole k-mer.  (-DQM2_FP_BYTE=1: just byte 1 of it, two instructions instead of five for the four
+ * copies a window compares against — measured at C3: 25.5 instead of 22.8 ms, the k-mers of a genome are not
+ * uniform in any one byte and every false match is a queue entry.) */
+#ifndef QM2_FP_BYTE
+#define QM2_FP_BYTE 0
+#endif
 __device__ __forceinline__ uint32_t fp8(uint64_t key)
 {
+#if QM2_FP_BYTE
+    return (((uint32_t)key >> 8) & 0xFFu) | 1u;
+#else
     const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
     return ((lo ^ hi ^ (lo >> 13)) & 0xFFu) | 1u;
+#endif
+}
+/* the same in all four bytes of a word */
+__device__ __forceinline__ uint32_t fp8x4(uint64_t key)
+{
+#if QM2_FP_BYTE
+    return __builtin_amdgcn_perm(0u, (uint32_t)key, 0x01010101u) | 0x01010101u;
+#else
+    return __builtin_amdgcn_perm(0u, fp8(key), 0u);
+#endif
 }
 constexpr uint32_t kFpPad = 0xFEu;
 
@@ -661,6 +680,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
     /* ============================ PROBERS ============================ */
     const int pt = tid - kLoaderThreads, pw = wave - kLoaderWaves;
     uint32_t n_probes = 0;                  /* per lane: < 2^32 for any batch that fits the plan */
+    uint32_t probes8 = 0;                   /* phase A's share of it, times 8 (every term a multiple of 8) */
     uint32_t n_hits = 0;                    /* phase A: per WAVE (scalar popcounts); lane 0 .. 63 add their own walk() hits */
     uint32_t w_hits_a = 0;
     constexpr uint32_t kGroupKmers = 2u * G2 * kProberThreads;
@@ -716,7 +736,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
          * Slots the reference has inspected by then: min(c, e, 3) + 1. */
 #define QM2_WINDOW(W, KM, LM, LE)                                                            \
         {                                                                                    \
-            const uint32_t x_ = (W) ^ __builtin_amdgcn_perm(0u, fp8(KM), 0u);                \
+            const uint32_t x_ = (W) ^ fp8x4(KM);                                             \
             const uint32_t zm_ = (x_ - 0x01010101u) & ~x_ & 0x80808080u;                     \
             const uint32_t ze_ = ((W) - 0x01010101u) & ~(W) & 0x80808080u;                   \
             LM = (uint32_t)__ffs((int)zm_) - 1u;                                             \
@@ -725,7 +745,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         /* the same over EIGHT slots (two fingerprint words): bit indices 0..63 */
 #define QM2_WINDOW8(W0, W1, KM, LM, LE)                                                      \
         {                                                                                    \
-            const uint32_t f_ = __builtin_amdgcn_perm(0u, fp8(KM), 0u);                      \
+            const uint32_t f_ = fp8x4(KM);                                                   \
             const uint32_t x0_ = (W0) ^ f_, x1_ = (W1) ^ f_;                                 \
             const uint64_t zm_ = ((uint64_t)((x1_ - 0x01010101u) & ~x1_ & 0x80808080u) << 32) | ((x0_ - 0x01010101u) & ~x0_ & 0x80808080u); \
             const uint64_t ze_ = ((uint64_t)(((W1) - 0x01010101u) & ~(W1) & 0x80808080u) << 32) | (((W0) - 0x01010101u) & ~(W0) & 0x80808080u); \
@@ -835,7 +855,9 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                 const bool hit = on && cand && lm[j] <= kWinLast && vv[j] == km[j];   /* :98 */
                 atomicAdd(&bcnt[pp[j] + c], hit ? 1u : 0u);                 /* :291 */
                 w_hits_a += __popcll(__ballot(hit));
-                n_probes += on ? (min(min(lm[j], le[j]), kWinLast) >> 3) + 1u : 0u;
+                /* slots inspected = (first flagged bit >> 3) + 1, and a flagged bit is 8 c + 7: summed as bit + 1,
+                 * divided by 8 once per wave at the end */
+                probes8 += on ? min(min(lm[j], le[j]), kWinLast) + 1u : 0u;
                 /* a false fingerprint match, or nothing decisive in 4 slots: this wave's queue */
                 const bool more = live[j] && (km[j] == 0 || (cand && !hit));
                 const unsigned long long m = __ballot(more);
@@ -941,7 +963,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         atomicAdd(&qm2_stamp_acc[9], 1ull);
     }
 #endif
-    const unsigned long long w_probes = wave_sum((unsigned long long)n_probes),
+    const unsigned long long w_probes = wave_sum((unsigned long long)n_probes + (probes8 >> 3)),
                              w_hits = wave_sum((unsigned long long)n_hits) + w_hits_a;
     if (lane == 0) {
         atomicAdd(&stats->n_probes, w_probes);
