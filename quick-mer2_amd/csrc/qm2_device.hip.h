@@ -270,6 +270,25 @@ __host__ __device__ __forceinline__ Window assemble_window(const SeqView &sv, in
     return W;
 }
 
+/* ---- where a k-mer lives in a partition level's buffer (qm2_partition.hip.h, SplitDst) ----
+ * child-major (SEG = false): k-mer e of region r at r * cap + e.
+ * segmented   (SEG = true):  segments of kSegKmers k-mers laid out [segment][region]:
+ *                            ((e >> kSegLg) << lg_row) + (r << kSegLg) + (e & (kSegKmers - 1)),  2^lg_row = regions * kSegKmers.
+ * Host-callable: tests/emul checks that both are one-to-one and that a 16-byte pair never straddles a segment. */
+#ifndef QM2_SEG_LG
+#define QM2_SEG_LG 13
+#endif
+constexpr uint32_t kSegLg = QM2_SEG_LG, kSegKmers = 1u << kSegLg;
+
+template <bool SEG>
+__host__ __device__ __forceinline__ uint64_t slot_of(uint64_t region, uint32_t e, uint32_t cap, uint32_t lg_row)
+{
+    if constexpr (SEG)
+        return ((uint64_t)(e >> kSegLg) << lg_row) + (((uint32_t)region << kSegLg) | (e & (kSegKmers - 1u)));
+    else
+        return region * (uint64_t)cap + e;
+}
+
 /* Byte offset (from sv.base) of the 16 bytes lane `lane` owns in the tile that
  * starts at byte tile0. */
 __host__ __device__ __forceinline__ int64_t lane_offset(uint64_t tile0, int lane)

@@ -94,11 +94,6 @@ __device__ __forceinline__ unsigned long long stamp_now()
  *     GRBM_UTCL2_BUSY = the whole kernel.  tools/micro/tlb_probe.hip: a CU's translation cache holds 1024 write
  *     streams 2 MiB apart (no misses) but not 64 of them 64 MiB apart.  Uniform hashing fills all children at the
  *     same pace, so segmented, all 1024 fronts sit inside one or two 64 MiB rows. */
-#ifndef QM2_SEG_LG
-#define QM2_SEG_LG 13
-#endif
-constexpr uint32_t kSegLg = QM2_SEG_LG, kSegKmers = 1u << kSegLg;
-
 struct SplitDst {
     uint64_t           *kmers;      /* the level's buffer                                        */
     uint32_t           *cursors;    /* per child: k-mers reserved so far (may exceed cap)        */
@@ -125,14 +120,6 @@ __device__ __forceinline__ uint64_t sub_region0(const SplitDst &d, uint32_t fan)
     return (uint64_t)(blockIdx.x & (d.subs - 1u)) * fan;
 }
 
-template <bool SEG>
-__device__ __forceinline__ uint64_t slot_of(uint64_t child, uint32_t e, uint32_t cap, uint32_t lg_row)
-{
-    if constexpr (SEG)
-        return ((uint64_t)(e >> kSegLg) << lg_row) + (((uint32_t)child << kSegLg) | (e & (kSegKmers - 1u)));
-    else
-        return child * (uint64_t)cap + e;
-}
 
 struct SplitLds {
     uint64_t sorted[kSplitSlots + 1];       /* the chunk sorted by child; last = trash slot          */

@@ -74,4 +74,11 @@ uint64_t qm2e_extract(const char *buf, size_t n, uint32_t k, size_t staging_byte
 
 uint32_t qm2e_djb32(uint64_t kmer) { return djb32(kmer); }
 
+/* the buffer layouts of a partition level (slot_of): where k-mer e of region r goes */
+uint64_t qm2e_slot_of(int segmented, uint64_t region, uint32_t e, uint32_t cap, uint32_t lg_row)
+{
+    return segmented ? slot_of<true>(region, e, cap, lg_row) : slot_of<false>(region, e, cap, lg_row);
+}
+uint32_t qm2e_seg_kmers(void) { return kSegKmers; }
+
 }

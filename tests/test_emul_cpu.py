@@ -132,3 +132,33 @@ def test_kat_case_streams():
             exp, exp_nb = ol.extract(blob, k)
             got, nb, _ = emul_extract(blob, k, 5000, 7)
             assert nb == exp_nb and np.array_equal(got, exp), name
+
+
+def test_partition_buffer_layouts_are_one_to_one():
+    """slot_of (qm2_device.hip.h): the child-major and the segmented [segment][region] layout of a partition
+    level's buffer each map (region, k-mer index) one-to-one onto the buffer's slots, and in the segmented one
+    the two k-mers of an aligned 16-byte load (even index, split_kmer's fetch) are neighbours inside one segment."""
+    L = emul()
+    L.qm2e_slot_of.restype = C.c_uint64
+    L.qm2e_slot_of.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.qm2e_seg_kmers.restype = C.c_uint32
+    seg = int(L.qm2e_seg_kmers())
+    lg_seg = seg.bit_length() - 1
+    regions, n_seg = 16, 3                       # 8 sub-regions of 2 children, 3 segments each
+    cap = n_seg * seg
+    lg_row = 4 + lg_seg
+    for segmented in (0, 1):
+        seen = np.zeros(regions * cap, dtype=np.uint8)
+        for r in range(regions):
+            es = np.unique(np.concatenate([np.arange(0, 64), np.arange(seg - 64, seg + 64), np.arange(cap - 64, cap),
+                                           np.random.default_rng(r).integers(0, cap, 4000)]))
+            for e in es:
+                at = L.qm2e_slot_of(segmented, r, int(e), cap, lg_row)
+                assert at < regions * cap
+                seen[at] += 1
+                if e % 2 == 0 and e + 1 < cap:
+                    assert L.qm2e_slot_of(segmented, r, int(e) + 1, cap, lg_row) == at + 1
+        assert seen.max() == 1
+    # a region's segment s starts at row s, column region
+    assert L.qm2e_slot_of(1, 5, 2 * seg + 7, cap, lg_row) == (2 << lg_row) + 5 * seg + 7
+    assert L.qm2e_slot_of(0, 5, 2 * seg + 7, cap, lg_row) == 5 * cap + 2 * seg + 7
