@@ -215,6 +215,11 @@ def cpu_legs(args, wl, pyqm2, torch, keys, buf0, nbytes0, H, k, local, n_unique)
     return out
 
 
+def sum64(torch, counters, piece=1 << 28):
+    """Sum of a large int32 tensor in int64 without a full-size int64 temporary."""
+    return sum(int(counters[a:a + piece].sum(dtype=torch.int64)) for a in range(0, counters.numel(), piece))
+
+
 def shard_spans_device(pyqm2, np, keys, H, G):
     """qm2_shard_span needs host keys but only looks at the slots around the shard edges: give it a sparse
     host image (untouched pages stay unmapped) with windows copied from the device table."""
@@ -284,7 +289,7 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
         add_prof(r0, job.rctx.profile())
         tot = torch.tensor([int(job._acc[0]) - acc0[0], int(job._acc[1]) - acc0[1],
                             s1["n_probes"] - s0["n_probes"], s1["n_hits"] - s0["n_hits"],
-                            int(job.counters.sum(dtype=torch.int64)), s1["n_hits"]], dtype=torch.int64, device=dev)
+                            sum64(torch, job.counters), s1["n_hits"]], dtype=torch.int64, device=dev)
         dist.all_reduce(tot)
         n_bases, n_kmers, n_probes, n_hits, csum, hsum = [int(x) for x in tot]
         conserved = csum == hsum
@@ -337,7 +342,7 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
         assert unfit == 0
         n_probes = sum(b["n_probes"] - a["n_probes"] for a, b in zip(s0, s1))
         n_hits = sum(b["n_hits"] - a["n_hits"] for a, b in zip(s0, s1))
-        conserved = sum(int(cnt.sum(dtype=torch.int64)) for _, cnt in shards) == sum(b["n_hits"] for b in s1)
+        conserved = sum(sum64(torch, cnt) for _, cnt in shards) == sum(b["n_hits"] for b in s1)
         retries = 0
         par = "hash-range shards x%d, LOGICAL on one GPU (route + one partitioned probe per shard; the exchange is a no-op)" % G
         for c, _ in shards:
