@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""How does the partitioned pipeline take reads with heavy hitters (repeat families, poly-A) — the k-mers that real
+WGS data has and bench.py's uniform reads do not?  One C3 batch (50 M x 150 bp); a fraction of its reads is replaced by
+copies of a few reads (every k-mer of such a read then occurs thousands of times in the batch and overflows its
+finest bucket into the spill list) and by poly-A lines.  Prints per-kernel times per variant.
+
+    python tools/heavy_hitters.py [reads]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "quick-mer2_amd"))
+
+
+def main():
+    reads = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+    import torch
+    import bench
+    import pyqm2
+    dev = torch.device("cuda", 0)
+    wl = dict(bench.WORKLOADS["c3"])
+    k, H, n = 30, 1 << wl["lgH"], wl["genome"]
+    genome = torch.empty(n, dtype=torch.uint8, device=dev)
+    n_blocks, dups, covered = bench.genome_layout(n)
+    pyqm2.tools.genome_generate(genome.data_ptr(), n, seed=22, n_blocks=n_blocks, dups=dups)
+    keys = torch.empty(H, dtype=torch.int64, device=dev)
+    scratch = torch.empty(H, dtype=torch.int64, device=dev)
+    pyqm2.tools.dict_build(genome.data_ptr(), n, k, keys.data_ptr(), H, scratch.data_ptr())
+    del scratch
+    torch.cuda.empty_cache()
+    counters = torch.zeros(H, dtype=torch.int32, device=dev)
+    off = pyqm2.tools.read_offsets(reads, 0, 150, 150, 22)
+    nbytes = int(off[-1])
+    base = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    pyqm2.tools.reads_generate(genome.data_ptr(), n, base.data_ptr(), None, reads, 0, 150, 150, 22, sub_rate=wl["sub"], sample_from=covered)
+    del genome
+    torch.cuda.empty_cache()
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+
+    def variant(frac_rep, families, frac_poly):
+        buf = base.clone().view(reads, 151)
+        if frac_rep:
+            m = int(reads * frac_rep)
+            where = torch.randint(0, reads, (m,), device=dev, generator=g)
+            what = torch.randint(0, families, (m,), device=dev, generator=g)
+            buf[where] = base.view(reads, 151)[what]
+        if frac_poly:
+            m = int(reads * frac_poly)
+            where = torch.randint(0, reads, (m,), device=dev, generator=g)
+            line = torch.full((151,), ord("A"), dtype=torch.uint8, device=dev)
+            line[150] = 10
+            buf[where] = line
+        return buf.view(-1)
+
+    ctx = pyqm2.Counter(None, hash_size=H, k=k, device=0, flags=pyqm2.FLAG_TIMING, ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr())
+    ctx.prepare(nbytes)
+    for name, args in (("uniform reads", (0, 0, 0)), ("5 % of the reads from 1000 families", (0.05, 1000, 0)),
+                       ("5 % from 100 000 families", (0.05, 100_000, 0)), ("20 % from 10 000 families", (0.20, 10_000, 0)),
+                       ("0.5 % poly-A", (0, 0, 0.005)), ("5 % from 1000 families + 0.5 % poly-A", (0.05, 1000, 0.005))):
+        buf = variant(*args)
+        ctx.submit_device(buf.data_ptr(), nbytes)
+        ctx.sync()
+        p0 = ctx.profile()
+        for _ in range(3):
+            ctx.submit_device(buf.data_ptr(), nbytes)
+        ctx.sync()
+        p1 = ctx.profile()
+        ms = {c: round((p1["class_ms"][c] - p0["class_ms"][c]) / 3, 2) for c in p1["class_ms"] if p1["class_ms"][c] - p0["class_ms"][c] > 0.3}
+        tot = (p1["kernel_ms"] - p0["kernel_ms"]) / 3
+        print("%-44s %6.1f ms per batch = %5.1f G bases/s  %s  fallbacks %d" % (name, tot, reads * 150 / tot / 1e6, ms,
+              p1["fallback_batches"] - p0["fallback_batches"]), flush=True)
+        del buf
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
