@@ -176,6 +176,7 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const uint64_t *kmers, ui
     const uint64_t per_wave = (uint64_t)kWave * kNJ;
     const uint64_t n_groups = (n + per_wave - 1) / per_wave;
     unsigned long long n_probes = 0, n_hits = 0;
+    uint32_t held_idx = 0xFFFFFFFFu, held = 0;          /* wave-uniform: increments not added yet, `held` of them on slot held_idx */
 
     for (uint64_t grp = wave_id; grp < n_groups; grp += n_waves) {
         uint64_t km[kNJ];
@@ -196,10 +197,11 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const uint64_t *kmers, ui
                 n_probes++;
             }
         }
-        /* One probe round per pass, like QM2_RESOLVE_ROUND, but the increments of a wave's NEIGHBOURING lanes that
-         * hit the same slot in the same pass are added as one atomic: the spill list holds the overflow of single
-         * buckets, i.e. floods of ONE k-mer (poly-A: 30 M copies of k-mer 0 per 50 M reads at 0.5 % poly-A reads),
-         * and 30 M atomics on one counter took 340 ms.  (Wave-uniform control flow around the ballots.) */
+        /* One probe round per pass, like QM2_RESOLVE_ROUND, but the wave keeps ONE slot whose increments it sums
+         * instead of adding them one by one: the spill list holds the overflow of single buckets, i.e. floods of
+         * one k-mer mixed with the ordinary k-mers of its bucket (poly-A: 30 M copies of k-mer 0 per 50 M reads at
+         * 0.5 % poly-A reads; 30 M atomics on one counter took 340 ms).  A slot that 8 or more lanes hit in one
+         * pass becomes the held one.  (Wave-uniform control flow around the ballots.) */
         while (__ballot(pending != 0)) {
 #pragma unroll
             for (int j = 0; j < kNJ; j++) {
@@ -207,16 +209,22 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const uint64_t *kmers, ui
                 const bool on = (pending & bit) != 0;
                 const uint64_t s = slot[j];
                 const bool hit = on && s == km[j];              /* (k-mer 0 matches an empty slot, exactly like :96-98) */
-                const unsigned long long hm = __ballot(hit);
-                if (hm) {
-                    const uint32_t up = __shfl_up(idx[j], 1);
-                    const bool head = hit && (lane == 0 || !((hm >> (lane - 1)) & 1ull) || up != idx[j]);
-                    const unsigned long long heads = __ballot(head);
-                    if (head) {
-                        const unsigned long long stop = lane == kWave - 1 ? 0ull : (heads | ~hm) >> (lane + 1);   /* first lane behind the run */
-                        const uint32_t len = stop ? (uint32_t)__ffsll((long long)stop) : (uint32_t)(kWave - lane);
-                        atomicAdd(&tv.counters[idx[j]], len);
+                unsigned long long rest = __ballot(hit);
+                if (rest) {
+                    const unsigned long long mh = __ballot(hit && idx[j] == held_idx);
+                    held += (uint32_t)__popcll(mh);
+                    rest &= ~mh;
+                    if (__popcll(rest) >= 8) {                  /* a new flood?  the slot of the first lane left */
+                        const uint32_t cand = (uint32_t)__shfl((int)idx[j], __ffsll((long long)rest) - 1);
+                        const unsigned long long mc = __ballot(hit && idx[j] == cand);
+                        if (__popcll(mc) >= 8) {
+                            if (held && lane == 0) atomicAdd(&tv.counters[held_idx], held);
+                            held_idx = cand;
+                            held = (uint32_t)__popcll(mc);
+                            rest &= ~mc;
+                        }
                     }
+                    if ((rest >> lane) & 1ull) atomicAdd(&tv.counters[idx[j]], 1u);
                 }
                 if (hit) { n_hits++; pending &= ~bit; }
                 else if (on && s == 0) pending &= ~bit;         /* empty: not in the dictionary */
@@ -228,6 +236,7 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const uint64_t *kmers, ui
             }
         }
     }
+    if (held && lane == 0) atomicAdd(&tv.counters[held_idx], held);
     if (stats) {
         n_probes = wave_sum(n_probes); n_hits = wave_sum(n_hits);
         if (lane == 0) {

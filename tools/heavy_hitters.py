@@ -40,7 +40,7 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(5)
 
-    def variant(frac_rep, families, frac_poly):
+    def variant(frac_rep, families, frac_poly, base_char="A"):
         buf = base.clone().view(reads, 151)
         if frac_rep:
             m = int(reads * frac_rep)
@@ -50,19 +50,25 @@ def main():
         if frac_poly:
             m = int(reads * frac_poly)
             where = torch.randint(0, reads, (m,), device=dev, generator=g)
-            line = torch.full((151,), ord("A"), dtype=torch.uint8, device=dev)
+            line = torch.full((151,), ord(base_char), dtype=torch.uint8, device=dev)
             line[150] = 10
             buf[where] = line
         return buf.view(-1)
 
     ctx = pyqm2.Counter(None, hash_size=H, k=k, device=0, flags=pyqm2.FLAG_TIMING, ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr())
     ctx.prepare(nbytes)
+    only = os.environ.get("HH_ONLY")
     for name, args in (("uniform reads", (0, 0, 0)), ("5 % of the reads from 1000 families", (0.05, 1000, 0)),
                        ("5 % from 100 000 families", (0.05, 100_000, 0)), ("20 % from 10 000 families", (0.20, 10_000, 0)),
-                       ("0.5 % poly-A", (0, 0, 0.005)), ("5 % from 1000 families + 0.5 % poly-A", (0.05, 1000, 0.005))):
+                       ("0.5 % poly-A", (0, 0, 0.005)), ("0.5 % poly-C (not in the dictionary)", (0, 0, 0.005, "C")), ("5 % from 1000 families + 0.5 % poly-A", (0.05, 1000, 0.005))):
+        if only and only not in name:
+            continue
         buf = variant(*args)
+        _, s0 = ctx.finish(want_depth=False)
         ctx.submit_device(buf.data_ptr(), nbytes)
         ctx.sync()
+        _, s1 = ctx.finish(want_depth=False)
+        per = {a: s1[a] - s0[a] for a in s1}
         p0 = ctx.profile()
         for _ in range(3):
             ctx.submit_device(buf.data_ptr(), nbytes)
@@ -70,8 +76,8 @@ def main():
         p1 = ctx.profile()
         ms = {c: round((p1["class_ms"][c] - p0["class_ms"][c]) / 3, 2) for c in p1["class_ms"] if p1["class_ms"][c] - p0["class_ms"][c] > 0.3}
         tot = (p1["kernel_ms"] - p0["kernel_ms"]) / 3
-        print("%-44s %6.1f ms per batch = %5.1f G bases/s  %s  fallbacks %d" % (name, tot, reads * 150 / tot / 1e6, ms,
-              p1["fallback_batches"] - p0["fallback_batches"]), flush=True)
+        print("%-44s %6.1f ms per batch = %5.1f G bases/s  %s  fallbacks %d; slots inspected per k-mer %.3f" % (
+              name, tot, reads * 150 / tot / 1e6, ms, p1["fallback_batches"] - p0["fallback_batches"], per["n_probes"] / max(1, per["n_kmers"])), flush=True)
         del buf
     ctx.close()
 
