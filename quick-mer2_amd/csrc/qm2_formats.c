@@ -3,13 +3,93 @@
  * Formats per SURVEY Appendix A; behaviour per QuicKmer.c:334-366 and :483-545.
  */
 #define _GNU_SOURCE
+#include <errno.h>
+#include <fcntl.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "qm2_host.h"
 
-#define QM2_FLUSH_ENTRIES (1u << 20)    /* the reference flushes .bin every 2^20 entries (:11, :511) */
+#define QM2_PIECE_ENTRIES (1u << 22)    /* (the reference flushes .bin every 2^20 entries, :11, :511; here 8 MiB pieces, in parallel) */
+#define QM2_OUT_THREADS 8
+
+/* The loop of :498-516 over the counts in chain order — depth to .bin, and with a .qgc the sums of the GC curve —
+ * split into pieces that worker threads take in turn: fetch from the device, pread the piece's GC values, add up,
+ * pwrite.  At hg38 scale the serial loop took 7 s with a .qgc (2.27 G entries through fread / fwrite and one
+ * branchy accumulation each), most of a small run.  The sums are kept in 64-bit integers and converted at the end:
+ * the reference adds into doubles, which is the same number as long as every partial sum is below 2^53 (SURVEY
+ * Appendix B.9: depths would have to average > 4 x 10^6 over a GC bin for that to fail). */
+typedef struct {
+    qm2_ctx   *ctx;
+    int        bin_fd, qgc_fd;                  /* qgc_fd < 0: no .qgc */
+    uint64_t   n_entries;
+    uint64_t   next;                            /* next piece to hand out (under `lock`) */
+    int        failed;
+    pthread_mutex_t lock;
+    int64_t    sum[401], sumsq[401];
+    uint64_t   cnt[401];
+} out_job;
+
+static void *out_worker(void *arg)
+{
+    out_job *j = arg;
+    uint16_t *out = malloc(QM2_PIECE_ENTRIES * sizeof(uint16_t));
+    uint16_t *gc = j->qgc_fd >= 0 ? malloc(QM2_PIECE_ENTRIES * sizeof(uint16_t)) : NULL;
+    int64_t sum[401], sumsq[401];
+    uint64_t cnt[401];
+    memset(sum, 0, sizeof sum); memset(sumsq, 0, sizeof sumsq); memset(cnt, 0, sizeof cnt);
+    int bad = !out || (j->qgc_fd >= 0 && !gc);
+    while (!bad) {
+        pthread_mutex_lock(&j->lock);
+        const uint64_t at = j->next;
+        const int stop = j->failed || at >= j->n_entries;
+        if (!stop) j->next = at + QM2_PIECE_ENTRIES;
+        pthread_mutex_unlock(&j->lock);
+        if (stop) break;
+        const uint64_t m = j->n_entries - at < QM2_PIECE_ENTRIES ? j->n_entries - at : QM2_PIECE_ENTRIES;
+        if (qm2_chain_fetch(j->ctx, out, at, m)) { bad = 1; break; }
+        if (gc) {
+            size_t got = 0;                                                    /* :502-503; a short .qgc reads as zeros */
+            while (got < m * sizeof(uint16_t)) {
+                const ssize_t n = pread(j->qgc_fd, (char *)gc + got, m * sizeof(uint16_t) - got, (off_t)(at * sizeof(uint16_t) + got));
+                if (n < 0 && errno == EINTR) continue;
+                if (n <= 0) break;
+                got += (size_t)n;
+            }
+            if (got < m * sizeof(uint16_t)) memset((char *)gc + got, 0, m * sizeof(uint16_t) - got);
+            for (uint64_t i = 0; i < m; i++) {
+                const uint16_t gcv = gc[i];
+                if (gcv & 0x8000) {                          /* control-region k-mer (:504) */
+                    const uint32_t b = gcv & 0x1FF;
+                    if (b < 401) {
+                        const uint16_t v = out[i];
+                        sum[b] += v;
+                        cnt[b]++;
+                        /* the reference squares a promoted uint16 in `int` (:507): above 46340 that overflows, and
+                         * what its build does is wrap; pinned here without the undefined behaviour */
+                        sumsq[b] += (int32_t)((uint32_t)v * (uint32_t)v);
+                    }
+                }
+            }
+        }
+        size_t put = 0;                                                        /* :512, :517 */
+        while (put < m * sizeof(uint16_t)) {
+            const ssize_t n = pwrite(j->bin_fd, (const char *)out + put, m * sizeof(uint16_t) - put, (off_t)(at * sizeof(uint16_t) + put));
+            if (n < 0 && errno == EINTR) continue;
+            if (n <= 0) { bad = 1; break; }
+            put += (size_t)n;
+        }
+    }
+    pthread_mutex_lock(&j->lock);
+    if (bad) j->failed = 1;
+    for (int b = 0; b < 401; b++) { j->sum[b] += sum[b]; j->sumsq[b] += sumsq[b]; j->cnt[b] += cnt[b]; }
+    pthread_mutex_unlock(&j->lock);
+    free(out); free(gc);
+    return NULL;
+}
 
 int qm2_dict_open(const char *ref_prefix, qm2_dict_file *d)
 {
@@ -106,39 +186,28 @@ int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, co
         return 1;
     }
 
-    uint16_t *out = malloc(QM2_FLUSH_ENTRIES * sizeof(uint16_t));
-    uint16_t *gc = malloc(QM2_FLUSH_ENTRIES * sizeof(uint16_t));
-    if (!out || !gc) { puts("Memory allocation failed"); free(out); free(gc); free(path); return 1; }
     double sum[401], sumsq[401];
     uint32_t cnt[401];
-    memset(sum, 0, sizeof sum); memset(sumsq, 0, sizeof sumsq); memset(cnt, 0, sizeof cnt);
-
     int rc = 0;
-    for (uint64_t at = 0; at < n_entries && !rc; at += QM2_FLUSH_ENTRIES) {      /* :498-516, 2^20 at a time */
-        const uint64_t m = n_entries - at < QM2_FLUSH_ENTRIES ? n_entries - at : QM2_FLUSH_ENTRIES;
-        if (qm2_chain_fetch(ctx, out, at, m)) { rc = 1; break; }
-        if (qgc) {
-            size_t g = fread(gc, sizeof(uint16_t), m, qgc);                      /* :502-503 */
-            if (g < m) memset(gc + g, 0, (m - g) * sizeof(uint16_t));
-            for (uint64_t i = 0; i < m; i++) {
-                const uint16_t gcv = gc[i];
-                if (gcv & 0x8000) {                          /* control-region k-mer (:504) */
-                    const uint32_t b = gcv & 0x1FF;
-                    if (b < 401) {
-                        const uint16_t v = out[i];
-                        sum[b] += v;
-                        cnt[b]++;
-                        /* the reference squares a promoted uint16 in `int` (:507): above 46340 that overflows, and
-                         * what its build does is wrap; pinned here without the undefined behaviour */
-                        sumsq[b] += (double)(int32_t)((uint32_t)v * (uint32_t)v);
-                    }
-                }
-            }
-        }
-        if (fwrite(out, sizeof(uint16_t), m, bin) != m) { puts("Write to .bin failed"); rc = 1; }   /* :512, :517 */
+    {
+        out_job job;
+        memset(&job, 0, sizeof job);
+        job.ctx = ctx;
+        job.bin_fd = fileno(bin);
+        job.qgc_fd = qgc ? fileno(qgc) : -1;
+        job.n_entries = n_entries;
+        pthread_mutex_init(&job.lock, NULL);
+        pthread_t th[QM2_OUT_THREADS];
+        int n_th = 0;
+        const uint64_t pieces = (n_entries + QM2_PIECE_ENTRIES - 1) / QM2_PIECE_ENTRIES;
+        while (n_th < QM2_OUT_THREADS && (uint64_t)n_th < pieces && pthread_create(&th[n_th], NULL, out_worker, &job) == 0) n_th++;
+        if (n_th == 0) out_worker(&job);                                       /* no thread to be had: this one */
+        for (int t = 0; t < n_th; t++) pthread_join(th[t], NULL);
+        pthread_mutex_destroy(&job.lock);
+        if (job.failed) { puts("Write to .bin failed"); rc = 1; }
+        for (int b = 0; b < 401; b++) { sum[b] = (double)job.sum[b]; sumsq[b] = (double)job.sumsq[b]; cnt[b] = (uint32_t)job.cnt[b]; }
     }
-    fclose(bin);
-    free(out); free(gc);
+    if (fclose(bin) != 0 && !rc) { puts("Write to .bin failed"); rc = 1; }
     if (rc) { if (qgc) fclose(qgc); free(path); return 1; }
 
     if (qgc) {                                               /* :522-542 */

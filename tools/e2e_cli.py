@@ -51,6 +51,16 @@ with open(os.path.join(work, "ref.fa.qm"), "wb") as f:
     hk.tofile(f)
     chain.tofile(f)
 print("wrote .qm %.1f GB in %.1f s" % (os.path.getsize(os.path.join(work, "ref.fa.qm")) / 1e9, time.time() - t), flush=True)
+if os.environ.get("QM2_E2E_QGC", "1") != "0":
+    # a .qgc like `search` writes (one u16 per dictionary k-mer in chain order: GC bin 0..400, bit 15 = control region;
+    # QuicKmer.c:1023-1046): the epilogue's GC curve (.txt, :501-542) then has its real amount of work
+    rng = np.random.default_rng(7)
+    n_dict = len(occ)
+    g = rng.integers(120, 260, n_dict, dtype=np.uint16)
+    g |= (rng.integers(0, 10, n_dict, dtype=np.uint16) < 3).astype(np.uint16) << 15
+    g.tofile(os.path.join(work, "ref.fa.qgc"))
+    print("wrote .qgc %.1f GB (30 %% control k-mers)" % (g.nbytes / 1e9), flush=True)
+    del g
 del hk, chain, keys
 torch.cuda.empty_cache()
 # reads: made and framed on the device a piece at a time ("@r\n" seq "\n" "+\n" qual "\n" = 307 bytes a record)
