@@ -214,7 +214,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     p.buf_slots[1] = slots[1];
     p.n_cursors = 0;
     for (int l = 0; l < p.levels; l++) { p.cursor_off[l] = p.n_cursors; p.n_cursors += p.buckets[l] * (l == 0 ? p.subs0 : 1u); }
-    p.spill_cap = want / 4 + 4096;                                     /* 2 B of HBM per input byte */
+    p.spill_cap = std::min<uint64_t>(want / 4 + 4096, 0xFFFFFFFFull);  /* 2 B of HBM per input byte; places are 32-bit in sort_chunk's announcements */
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++)
         if (p.buf_slots[i]) { e = hipMalloc((void **)&p.buf[i], p.buf_slots[i] * sizeof(uint64_t)); c->prof.allocations++; }

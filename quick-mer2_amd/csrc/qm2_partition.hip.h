@@ -121,7 +121,7 @@ __device__ __forceinline__ uint64_t sub_region0(const SplitDst &d, uint32_t fan)
 }
 
 
-constexpr int kSpillRuns = 64;              /* overflowing runs of a chunk that the whole workgroup copies out together */
+constexpr int kSpillRuns = kMaxFan;         /* overflowing runs of a chunk that the whole workgroup copies out together: every child may */
 struct SplitLds {
     uint64_t sorted[kSplitSlots + 1];       /* the chunk sorted by child; last = trash slot          */
     uint32_t hist[kMaxFan + 1];             /* [kMaxFan] = trash bin of the empty slots (keeps the
@@ -133,7 +133,7 @@ struct SplitLds {
     uint32_t wsum[kMaxFan / kWave];
     uint32_t total;                         /* real k-mers in the sorted chunk                       */
     uint32_t spill_n;                       /* runs of this chunk that did not fit their child ...   */
-    uint4    spill_e[kSpillRuns];           /* ... {first element in sorted, how many, place in the spill list (lo, hi)} */
+    uint2    spill_e[kSpillRuns];           /* ... {first element in sorted | how many << 16, place in the spill list} */
 };
 static_assert(kMaxFan % kSplitThreads == 0 || kSplitThreads > kMaxFan, "whole children per thread");
 constexpr int kChildPerThread = kSplitThreads >= kMaxFan ? 1 : kMaxFan / kSplitThreads;
@@ -146,20 +146,15 @@ constexpr int kSplitWgPerCu = kSplitThreads >= 1024 ? 1 : 2;      /* what the LD
 
 /* The announced overflow runs of a chunk (sort_chunk), copied to the spill list by the whole workgroup.  Out of line:
  * inlined, its registers pushed values of the chunk loop into scratch and cost the loop 12 % — and it hardly ever runs. */
-__device__ __attribute__((noinline)) uint32_t copy_spills(const SplitLds &L, uint64_t *spill, uint64_t spill_cap)
+__device__ __attribute__((noinline)) void copy_spills(const SplitLds &L, uint64_t *spill)
 {
     /* (the destination by value: a reference to the kernel's SplitDst would move that whole struct into scratch) */
     const uint32_t ns = L.spill_n < (uint32_t)kSpillRuns ? L.spill_n : (uint32_t)kSpillRuns;
-    uint32_t over = 0;
     for (uint32_t r = 0; r < ns; r++) {
-        const uint4 e = L.spill_e[r];
-        const unsigned long long sb = ((unsigned long long)e.w << 32) | e.z;
-        for (uint32_t x = threadIdx.x; x < e.y; x += kSplitThreads) {
-            if (sb + x < spill_cap) spill[sb + x] = L.sorted[e.x + x];
-            else over++;
-        }
+        const uint2 e = L.spill_e[r];
+        const uint32_t first = e.x & 0xFFFFu, len = e.x >> 16;
+        for (uint32_t x = threadIdx.x; x < len; x += kSplitThreads) spill[(uint64_t)e.y + x] = L.sorted[first + x];
     }
-    return over;                /* k-mers beyond the end of the spill list: lost */
 }
 
 /* Sort one chunk by child in LDS.  Every thread holds kKpt k-mers km[j] with
@@ -240,19 +235,23 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
                 /* rare (skewed input: poly-A, a repeat family): the child is full; the rest of the run goes to the
                  * spill list, which the direct kernel probes at the end of the batch.  A flood puts thousands of
                  * k-mers of every chunk here, so the run is announced and the whole workgroup copies it (below);
-                 * one thread doing it alone made 0.5 % poly-A reads cost 30 ms per 50 M reads.  More than kSpillRuns
-                 * overflowing runs in one chunk (or no spill list: qm2_route_device) count as lost: the caller is
-                 * told / the batch is recounted by the direct kernel. */
-                const uint32_t e = d.spill_cap ? atomicAdd(&L.spill_n, 1u) : (uint32_t)kSpillRuns;
-                if (e < (uint32_t)kSpillRuns) {
+                 * one thread doing it alone made 0.5 % poly-A reads cost 30 ms per 50 M reads.  What does not fit the
+                 * spill list either (or there is none: qm2_route_device) counts as lost: the caller is told / the
+                 * batch is recounted by the direct kernel. */
+                uint32_t fits = 0;                                    /* ... of the run's rest, in the spill list */
+                if (d.spill_cap) {
                     const unsigned long long sb = atomicAdd(d.spill_count, (unsigned long long)(mine[i] - f[i]));
-                    L.spill_e[e] = make_uint4(off[i] + f[i], mine[i] - f[i], (uint32_t)sb, (uint32_t)(sb >> 32));
-                } else lost += mine[i] - f[i];
+                    if (sb < d.spill_cap) {                           /* (spill_cap < 2^32: a quarter of a batch of < 16 GiB) */
+                        fits = d.spill_cap - sb < mine[i] - f[i] ? (uint32_t)(d.spill_cap - sb) : mine[i] - f[i];
+                        L.spill_e[atomicAdd(&L.spill_n, 1u)] = make_uint2((off[i] + f[i]) | (fits << 16), (uint32_t)sb);
+                    }
+                }
+                lost += mine[i] - f[i] - fits;
             }
         }
     }
     lds_barrier();
-    if (L.spill_n) lost += copy_spills(L, d.spill, d.spill_cap);      /* workgroup-uniform, rare */
+    if (L.spill_n) copy_spills(L, d.spill);               /* workgroup-uniform, rare */
 }
 
 /* child of a k-mer at a level: `bits` bits of its home slot from bit `shift` on (shift + bits <= log2 H, so
