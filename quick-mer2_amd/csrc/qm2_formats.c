@@ -9,12 +9,13 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "qm2_host.h"
 
 #define QM2_PIECE_ENTRIES (1u << 22)    /* (the reference flushes .bin every 2^20 entries, :11, :511; here 8 MiB pieces, in parallel) */
-#define QM2_OUT_THREADS 8
+#define QM2_OUT_THREADS 12
 
 /* The loop of :498-516 over the counts in chain order — depth to .bin, and with a .qgc the sums of the GC curve —
  * split into pieces that worker threads take in turn: fetch from the device, pread the piece's GC values, add up,
@@ -170,12 +171,15 @@ int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, co
     /* the chain goes from the file to where the dead key table was on the device (:483, :490);
      * the walk of :494-516 is a parallel list ranking there */
     uint64_t n_entries = 0;
+    struct timespec t0, t1, t2;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     if (qm2_chain_gather_fd(ctx, fileno(d->fp), 24 + H * sizeof(uint64_t), d->first_idx, &n_entries)) {
         if (qgc) fclose(qgc);
         free(path);
         return 1;
     }
 
+    clock_gettime(CLOCK_MONOTONIC, &t1);
     memcpy(path, out_prefix, olen);
     memcpy(path + olen, ".bin", 5);                          /* :342-344 */
     FILE *bin = fopen(path, "wb");
@@ -208,6 +212,11 @@ int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, co
         for (int b = 0; b < 401; b++) { sum[b] = (double)job.sum[b]; sumsq[b] = (double)job.sumsq[b]; cnt[b] = (uint32_t)job.cnt[b]; }
     }
     if (fclose(bin) != 0 && !rc) { puts("Write to .bin failed"); rc = 1; }
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    if (getenv("QM2_TIMING"))
+        printf("QM2 epilogue: chain file -> device + list ranking %.3f s, .bin%s on %d threads %.3f s\n",
+               (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec), qgc ? " + GC sums" : "", QM2_OUT_THREADS,
+               (t2.tv_sec - t1.tv_sec) + 1e-9 * (t2.tv_nsec - t1.tv_nsec));
     if (rc) { if (qgc) fclose(qgc); free(path); return 1; }
 
     if (qgc) {                                               /* :522-542 */
