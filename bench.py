@@ -47,8 +47,8 @@ WORKLOADS = {
                desc="chr22-like 50.8 Mb synthetic reference, k=30, H=2^28; 10M x 150 bp reads per step"),
     "c3": dict(genome=3_100_000_000, lgH=32, reads=50_000_000, len_lo=150, len_hi=150, sub=0.005,
                desc="hg38-like 3.1 Gb synthetic reference, k=30, H=2^32; 50M x 150 bp reads per step"),
-    "c5": dict(genome=3_100_000_000, lgH=32, reads=240_000, len_lo=15_000, len_hi=20_000, sub=0.001,
-               desc="hg38-like dictionary (H=2^32), HiFi-like reads U(15k,20k) bp, 240k reads per step"),
+    "c5": dict(genome=3_100_000_000, lgH=32, reads=400_000, len_lo=15_000, len_hi=20_000, sub=0.001,
+               desc="hg38-like dictionary (H=2^32), HiFi-like reads U(15k,20k) bp, 400k reads per step"),
     "tiny": dict(genome=2_000_000, lgH=22, reads=200_000, len_lo=150, len_hi=150, sub=0.005,
                  desc="2 Mb synthetic reference, H=2^22 (plumbing check only)"),
 }
