@@ -192,6 +192,74 @@ def test_cli_devices_two_contexts_sum_to_the_reference(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(ol.ORACLE_DIR, "_ref", "quicKmer2")),
                     reason="real reference binary not shipped")
+def test_cli_epilogue_in_pieces_with_qgc(qm2, torch_cuda, tmp_path):
+    """The epilogue's loop over the counts in chain order (.bin, and with a .qgc the GC curve of the .txt,
+    QuicKmer.c:498-542) runs on worker threads that take 2^22-entry pieces; the reference vectors are all smaller
+    than one piece.  Here: a 10 M-k-mer dictionary built on the device (3 pieces), a random .qgc — once whole, once
+    cut short, which the reference reads as zeros (:503) — and `.bin` / `.txt` compared with the counts of the API
+    path and with the reference's arithmetic restated in numpy."""
+    torch = torch_cuda
+    n, H, k = 14_000_000, 1 << 26, 30
+    genome = torch.empty(n, dtype=torch.uint8, device="cuda")
+    qm2.tools.genome_generate(genome.data_ptr(), n, seed=91, n_blocks=[(0, 100_000)])
+    keys = torch.empty(H, dtype=torch.int64, device="cuda")
+    scratch = torch.empty(H, dtype=torch.int64, device="cuda")
+    qm2.tools.dict_build(genome.data_ptr(), n, k, keys.data_ptr(), H, scratch.data_ptr())
+    del scratch
+    n_reads, rl = 400_000, 150
+    reads = torch.empty(n_reads * (rl + 1), dtype=torch.uint8, device="cuda")
+    qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, n_reads, 0, rl, rl, 91)
+    lines = reads.cpu().numpy().tobytes()
+    hk = keys.cpu().numpy().view(np.uint64)
+    del genome, keys, reads
+    torch.cuda.empty_cache()
+    occ = np.flatnonzero(hk).astype(np.uint32)
+    assert len(occ) > 2 * (1 << 22)                                   # more than two pieces
+    chain = np.zeros(H, dtype=np.uint32)
+    chain[occ] = np.roll(occ, -1)
+    ref = str(tmp_path / "ref.fa")
+    with open(ref + ".qm", "wb") as f:
+        f.write(b"QM11" + bytes([k, 0, 100, 100]) + int(H).to_bytes(8, "little") + int(occ[0]).to_bytes(8, "little"))
+        hk.tofile(f)
+        chain.tofile(f)
+    fa = tmp_path / "reads.fa"
+    fa.write_bytes(b">r\n" + lines.replace(b"\n", b"\n>r\n")[:-3])       # a header line before every read
+    with qm2.Counter(hk, k=k) as c:
+        c.submit(lines)
+        depth, st = c.finish()
+    exp_bin = depth[occ]                                              # chain order = ascending slots here
+    rng = np.random.default_rng(4)
+    g = rng.integers(0, 420, len(occ), dtype=np.uint16)               # some bins beyond 400: ignored (:505)
+    g |= (rng.integers(0, 4, len(occ), dtype=np.uint16) == 0).astype(np.uint16) << 15
+    for cut in (0, 3_000_001):
+        gc = g[:len(g) - cut]
+        gc.tofile(ref + ".qgc")
+        out = str(tmp_path / ("o%d" % cut))
+        r = subprocess.run([CLI, "count", "-t", "4", ref, str(fa), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        txt = r.stdout.decode(errors="replace")
+        assert r.returncode == 0, txt
+        assert "total %d kmers" % st["n_kmers"] in txt
+        assert np.array_equal(np.fromfile(out + ".bin", dtype=np.uint16), exp_bin)
+        full = np.zeros(len(occ), dtype=np.uint16)
+        full[:len(gc)] = gc
+        ctrl = (full & 0x8000) != 0
+        b = (full & 0x1FF).astype(np.int64)
+        use = ctrl & (b < 401)
+        v = exp_bin[use].astype(np.int64)
+        cnt = np.bincount(b[use], minlength=401)
+        sm = np.bincount(b[use], weights=v.astype(np.float64), minlength=401)
+        sq = np.bincount(b[use], weights=((v * v).astype(np.uint32).view(np.int32)).astype(np.float64), minlength=401)
+        exp_txt = []
+        for i in range(401):
+            mean, var = sm[i], sq[i]
+            if cnt[i]:
+                mean = sm[i] / cnt[i]
+                var = sq[i] / cnt[i] - mean * mean
+            exp_txt.append("%.2f\t%f\t%d\t%f\n" % (i / 4.0, mean, cnt[i], var))
+        assert open(out + ".txt").read() == "".join(exp_txt), cut
+        assert "Mean sequencing depth: %.2f" % (sm.sum() / cnt.sum()) in txt
+
+
 def test_cli_c1_against_live_reference(tmp_path):
     """Config C1: dictionary by the real `search`, counts by the real `count`, vs the GPU CLI."""
     c1 = json.load(open(os.path.join(GOLD, "c1_manifest.json")))
