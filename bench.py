@@ -383,6 +383,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-binary", action="store_true", help="CPU leg: the oracle port only")
     ap.add_argument("--no-streamed", action="store_true", help="skip the host-fed (PCIe-inclusive) regions")
+    ap.add_argument("--no-geometry-check", action="store_true",
+                    help="skip the partitioned-vs-direct comparison of all counters at the benchmarked batch geometry")
     ap.add_argument("--streamed-steps", type=int, default=4)
     ap.add_argument("--feed-threads", type=int, default=8, help="host threads that fill the staging buffers in the streamed regions")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the -t 6 port sample")
@@ -561,6 +563,32 @@ def main():
         total = sum(int(counters[a:a + piece].sum(dtype=torch.int64)) for a in range(0, counters.numel(), piece))
         counts_conserved = bool(total == hits_all)
 
+    # ---- parity at the benchmarked geometry: batch 0 once more through the partitioned pipeline (the plan
+    #      the steps above ran with: sub-regions, bucket capacities, buffers all sized for THIS batch) and once
+    #      through the direct kernel, which shares nothing with it but the front end; all 2^lgH counters are
+    #      compared through a position-weighted 64-bit checksum (a k-mer lost, doubled or counted on another
+    #      slot changes it) plus the four statistics.  Every k-mer probed exactly once: QuicKmer.c:283-293. ----
+    geometry = None
+    if rank == 0 and not args.no_geometry_check and prof1["partitioned_batches"] - prof0["partitioned_batches"] > 0:
+        gbuf, gbytes, gbases = batches[0]
+        ctx.reset()
+        ctx.submit_device(gbuf.data_ptr(), gbytes)
+        _, gp = ctx.finish(want_depth=False)
+        gprof = ctx.profile()
+        cs_p = pyqm2.tools.checksum_u32(counters.data_ptr(), H)
+        ctx.reset()
+        dctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=pyqm2.FLAG_DIRECT, ext_keys=keys.data_ptr(),
+                             ext_counters=counters.data_ptr())
+        dctx.submit_device(gbuf.data_ptr(), gbytes)
+        _, gd = dctx.finish(want_depth=False)
+        dctx.close()
+        cs_d = pyqm2.tools.checksum_u32(counters.data_ptr(), H)
+        geometry = {"equal": bool(cs_p == cs_d and gp == gd and gprof["partitioned_batches"] == 1
+                                  and gprof["fallback_batches"] == 0 and gp["n_bases"] == gbases),
+                    "bytes": gbytes, "partitioned": {"checksum": "%016x" % cs_p[0], "sum": cs_p[1], "nonzero_slots": cs_p[2], **gp},
+                    "direct": {"checksum": "%016x" % cs_d[0], "sum": cs_d[1], "nonzero_slots": cs_d[2], **gd}}
+        assert geometry["equal"], geometry
+
     # ---- roofline: per-kernel HIP-event times (recorded on the stream the kernels run on) -----
     kern_ms = prof1["kernel_ms"] - prof0["kernel_ms"]
     cls_ms = {c: prof1["class_ms"][c] - prof0["class_ms"][c] for c in prof1["class_ms"]}
@@ -623,7 +651,10 @@ def main():
     # ---- SURVEY 8(d)'s wall-clock metric: the batches fed from HOST memory through the pinned staging
     #      buffers, first commit -> return of qm2_finish, allocations made beforehand ---------------------
     streamed = None
-    if rank == 0 and world == 1 and not args.no_streamed and wl["len_lo"] == wl["len_hi"]:
+    if not args.no_streamed and wl["len_lo"] == wl["len_hi"]:
+        # N > 1: every rank feeds its own GPU from host memory AT THE SAME TIME (one barrier in front of the timed
+        # region); the aggregate is all ranks' bases over the slowest rank's time — what N x PCIe + the host's
+        # memory system give together, which a single-rank figure times N would only guess
         rl = wl["len_lo"]
         nb = 2
         hosts = [batches[i % n_batches][0].cpu().numpy() for i in range(nb)]
@@ -636,21 +667,34 @@ def main():
             sctx.finish(want_depth=False)
             a0 = sctx.profile()["allocations"]
             _, s0 = sctx.finish(want_depth=False)
+            barrier()
             tA = time.perf_counter()
             moved = 0
             for i in range(steps):
                 moved += feed(i)
             _, s1 = sctx.finish(want_depth=False)
             sec = time.perf_counter() - tA
-            return s1["n_bases"] - s0["n_bases"], moved, sec, sctx.profile()["allocations"] - a0
+            nbases, allocs = s1["n_bases"] - s0["n_bases"], sctx.profile()["allocations"] - a0
+            per_rank = [round(moved / sec / 1e9, 2)]
+            if use_dist:                                              # sums, the slowest rank's time, every rank's own rate
+                tot = torch.tensor([nbases, moved, allocs], dtype=torch.int64, device=dev)
+                dist.all_reduce(tot)
+                tmax = torch.tensor([sec], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                rates = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+                dist.all_gather(rates, torch.tensor([moved / sec / 1e9], dtype=torch.float64, device=dev))
+                nbases, moved, allocs, sec = int(tot[0]), int(tot[1]), int(tot[2]), float(tmax.item())
+                per_rank = [round(float(r.item()), 2) for r in rates]
+            return nbases, moved, sec, allocs, per_rank
 
         def feed_lines(i):
             h = hosts[i % nb]
             sctx.feed_host(h.ctypes.data, h.size, rl + 1, threads=args.feed_threads)
             return h.size
 
-        nbases, moved, sec, allocs = run(feed_lines, args.streamed_steps)
+        nbases, moved, sec, allocs, per_rank = run(feed_lines, args.streamed_steps)
         streamed = {"streamed_bases_per_s": round(nbases / sec, 1), "h2d_GBps": round(moved / sec / 1e9, 2),
+                    "h2d_GBps_per_rank": per_rank, "ranks_feeding_concurrently": world,
                     "steps": args.streamed_steps, "seconds": round(sec, 3), "allocations_inside": allocs,
                     "feed": "%d host threads copy 64 MiB pieces into the pinned staging buffers (what the CLI's reader threads do "
                             "with pread), one thread commits them in order; timed from the first commit to the return of qm2_finish"
@@ -674,11 +718,12 @@ def main():
             return fq.size
 
         raw_steps = max(1, args.streamed_steps * 3 // 2)      # (6 x 6.1 GB by default: the drain of the last batch is then < 10 % of the region)
-        nbases, moved, sec, allocs = run(feed_fastq, raw_steps)
+        nbases, moved, sec, allocs, per_rank = run(feed_fastq, raw_steps)
         streamed.update({"streamed_raw_fastq_bases_per_s": round(nbases / sec, 1), "raw_fastq_h2d_GBps": round(moved / sec / 1e9, 2),
+                         "raw_fastq_h2d_GBps_per_rank": per_rank,
                          "raw_fastq_reads_per_step": m, "raw_fastq_steps": raw_steps, "raw_fastq_allocations_inside": allocs,
                          "raw_verdict": sctx.raw_verdict()})
-        assert nbases == raw_steps * m * rl and sctx.raw_verdict() == 0
+        assert nbases == world * raw_steps * m * rl and sctx.raw_verdict() == 0
         sctx.close()
         del fq
     batches = batches[:1]
@@ -698,8 +743,13 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
+            "value_is": "the count path with the read batches already resident in HBM when the timed region starts (the bench "
+                        "contract); SURVEY 8(d)'s host-fed wall-clock metric (first commit -> return of qm2_finish, PCIe "
+                        "included) is streamed_bases_per_s in this same line, raw FASTQ text: streamed.streamed_raw_fastq_bases_per_s",
             "config": {"workload": args.workload + ": " + wl["desc"], "k": k, "hash_size": H,
                        "dict_kmers": n_unique, "fill": round(n_unique / H, 4),
+                       "partitioned_equals_direct_at_bench_batch": geometry["equal"] if geometry else None,
+                       "geometry_check": geometry,
                        "reads_per_step_per_gpu": wl["reads"], "bases_per_step_per_gpu": batches[0][2],
                        "kmers_per_base": round(d["n_kmers"] / max(1, d["n_bases"]), 4),
                        "probes_per_kmer": round(d["n_probes"] / max(1, d["n_kmers"]), 4),

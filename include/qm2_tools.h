@@ -60,6 +60,13 @@ void qm2t_read_offsets(uint64_t *offsets, uint64_t n_reads, uint64_t first_read,
  *   mode 2: 8-byte load, then an atomic add on a second array at the same index */
 int qm2t_microbench(uint64_t slots, uint64_t n_ops, int mode, int repeats, double *ms_out);
 
+/* Parity tooling: out[0] = sum over i of c[i] * (splitmix64(i) | 1) mod 2^64 of the n u32 counters at
+ * d_counters (16-byte aligned; position-weighted, so a count that lands on another slot changes it),
+ * out[1] = plain sum, out[2] = non-zero slots.  Two runs over a 2^32-slot table are compared with it
+ * without holding two 16 GiB arrays (bench.py: partitioned pipeline vs the direct kernel at the batch
+ * geometry the number is measured on). */
+int qm2t_checksum_u32(const void *d_counters, uint64_t n, uint64_t out[3], void *stream);
+
 #ifdef __cplusplus
 }
 #endif

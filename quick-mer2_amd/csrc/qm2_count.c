@@ -133,7 +133,14 @@ int qm2_main_count(int argc, char **argv)
         case 'D':
             for (char *tok = strtok(optarg, ","); tok; tok = strtok(NULL, ",")) {
                 if (n_dev == QM2_MAX_DEVICES) { printf("At most %d devices\n", QM2_MAX_DEVICES); return 1; }
-                devices[n_dev++] = atoi(tok);
+                char *end = NULL;
+                const long v = strtol(tok, &end, 10);
+                if (end == tok || *end != '\0' || v < 0 || v > 1023) {
+                    /* (an ordinal the machine does not have is refused by qm2_open: "device N out of range") */
+                    printf("--devices: '%s' is not a device ordinal\n", tok);
+                    return 1;
+                }
+                devices[n_dev++] = (int)v;
             }
             break;
         case 'h': help_count(); return 1;

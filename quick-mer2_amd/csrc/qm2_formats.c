@@ -23,16 +23,52 @@
  * branchy accumulation each), most of a small run.  The sums are kept in 64-bit integers and converted at the end:
  * the reference adds into doubles, which is the same number as long as every partial sum is below 2^53 (SURVEY
  * Appendix B.9: depths would have to average > 4 x 10^6 over a GC bin for that to fail). */
+#define QM2_GC_BLOCK (1u << 20)          /* entries the reference freads from the .qgc at a time (buffer_size, :11, :502-503) */
+enum { QM2_OUT_OK = 0, QM2_OUT_ALLOC, QM2_OUT_FETCH, QM2_OUT_QGC, QM2_OUT_WRITE };
+
 typedef struct {
     qm2_ctx   *ctx;
     int        bin_fd, qgc_fd;                  /* qgc_fd < 0: no .qgc */
     uint64_t   n_entries;
+    uint64_t   n_qgc;                           /* entries the .qgc file really holds */
+    uint16_t  *stale;                           /* what the reference's gc_control[] holds once the file has run out (below) */
     uint64_t   next;                            /* next piece to hand out (under `lock`) */
-    int        failed;
+    int        failed;                          /* QM2_OUT_*: what went wrong first */
     pthread_mutex_t lock;
     int64_t    sum[401], sumsq[401];
     uint64_t   cnt[401];
 } out_job;
+
+static int pread_all(int fd, void *buf, size_t n, uint64_t off, size_t *got_out)
+{
+    size_t got = 0;
+    while (got < n) {
+        const ssize_t r = pread(fd, (char *)buf + got, n - got, (off_t)(off + got));
+        if (r < 0 && errno == EINTR) continue;
+        if (r < 0) return 1;
+        if (r == 0) break;
+        got += (size_t)r;
+    }
+    *got_out = got;
+    return 0;
+}
+
+/* A .qgc shorter than the dictionary.  The reference freads 2^20 entries into gc_control[] whenever its buffer index
+ * is 0 and never looks at what fread returned (:502-503): behind the end of the file the array simply keeps what the
+ * earlier reads left in it.  With n entries in the file, F = n / 2^20 full blocks and r = n % 2^20: entry e >= n reads
+ * position p = e % 2^20 of that array, which holds file entry F * 2^20 + p if p < r (the last, partial read), else
+ * file entry (F - 1) * 2^20 + p (the last full block).  With F = 0 the rest of the array is the reference's
+ * uninitialised stack: taken as zeros here (the one deliberate difference, on an input the reference leaves undefined). */
+static int stale_block(out_job *j)
+{
+    const uint64_t B = QM2_GC_BLOCK, F = j->n_qgc / B, r = j->n_qgc % B;
+    j->stale = calloc(B, sizeof(uint16_t));
+    if (!j->stale) return QM2_OUT_ALLOC;
+    size_t got = 0;
+    if (F && pread_all(j->qgc_fd, j->stale, B * sizeof(uint16_t), (F - 1) * B * sizeof(uint16_t), &got)) return QM2_OUT_QGC;
+    if (r && pread_all(j->qgc_fd, j->stale, r * sizeof(uint16_t), F * B * sizeof(uint16_t), &got)) return QM2_OUT_QGC;
+    return QM2_OUT_OK;
+}
 
 static void *out_worker(void *arg)
 {
@@ -42,7 +78,7 @@ static void *out_worker(void *arg)
     int64_t sum[401], sumsq[401];
     uint64_t cnt[401];
     memset(sum, 0, sizeof sum); memset(sumsq, 0, sizeof sumsq); memset(cnt, 0, sizeof cnt);
-    int bad = !out || (j->qgc_fd >= 0 && !gc);
+    int bad = !out || (j->qgc_fd >= 0 && !gc) ? QM2_OUT_ALLOC : QM2_OUT_OK;
     while (!bad) {
         pthread_mutex_lock(&j->lock);
         const uint64_t at = j->next;
@@ -51,16 +87,16 @@ static void *out_worker(void *arg)
         pthread_mutex_unlock(&j->lock);
         if (stop) break;
         const uint64_t m = j->n_entries - at < QM2_PIECE_ENTRIES ? j->n_entries - at : QM2_PIECE_ENTRIES;
-        if (qm2_chain_fetch(j->ctx, out, at, m)) { bad = 1; break; }
+        if (qm2_chain_fetch(j->ctx, out, at, m)) { bad = QM2_OUT_FETCH; break; }
         if (gc) {
-            size_t got = 0;                                                    /* :502-503; a short .qgc reads as zeros */
-            while (got < m * sizeof(uint16_t)) {
-                const ssize_t n = pread(j->qgc_fd, (char *)gc + got, m * sizeof(uint16_t) - got, (off_t)(at * sizeof(uint16_t) + got));
-                if (n < 0 && errno == EINTR) continue;
-                if (n <= 0) break;
-                got += (size_t)n;
+            /* :502-503: the piece's GC values; behind the end of a short .qgc, what the reference's array still holds */
+            const uint64_t have = at >= j->n_qgc ? 0 : (j->n_qgc - at < m ? j->n_qgc - at : m);
+            size_t got = 0;
+            if (have && (pread_all(j->qgc_fd, gc, have * sizeof(uint16_t), at * sizeof(uint16_t), &got) || got != have * sizeof(uint16_t))) {
+                bad = QM2_OUT_QGC;
+                break;
             }
-            if (got < m * sizeof(uint16_t)) memset((char *)gc + got, 0, m * sizeof(uint16_t) - got);
+            for (uint64_t i = have; i < m; i++) gc[i] = j->stale[(at + i) & (QM2_GC_BLOCK - 1)];
             for (uint64_t i = 0; i < m; i++) {
                 const uint16_t gcv = gc[i];
                 if (gcv & 0x8000) {                          /* control-region k-mer (:504) */
@@ -80,12 +116,12 @@ static void *out_worker(void *arg)
         while (put < m * sizeof(uint16_t)) {
             const ssize_t n = pwrite(j->bin_fd, (const char *)out + put, m * sizeof(uint16_t) - put, (off_t)(at * sizeof(uint16_t) + put));
             if (n < 0 && errno == EINTR) continue;
-            if (n <= 0) { bad = 1; break; }
+            if (n <= 0) { bad = QM2_OUT_WRITE; break; }
             put += (size_t)n;
         }
     }
     pthread_mutex_lock(&j->lock);
-    if (bad) j->failed = 1;
+    if (bad && !j->failed) j->failed = bad;
     for (int b = 0; b < 401; b++) { j->sum[b] += sum[b]; j->sumsq[b] += sumsq[b]; j->cnt[b] += cnt[b]; }
     pthread_mutex_unlock(&j->lock);
     free(out); free(gc);
@@ -192,7 +228,7 @@ int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, co
 
     double sum[401], sumsq[401];
     uint32_t cnt[401];
-    int rc = 0;
+    int rc = 0, n_th = 0;
     {
         out_job job;
         memset(&job, 0, sizeof job);
@@ -200,22 +236,35 @@ int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, co
         job.bin_fd = fileno(bin);
         job.qgc_fd = qgc ? fileno(qgc) : -1;
         job.n_entries = n_entries;
+        job.n_qgc = n_entries;
+        if (qgc) {
+            struct stat gsb;
+            if (fstat(job.qgc_fd, &gsb) == 0 && S_ISREG(gsb.st_mode) && (uint64_t)gsb.st_size / sizeof(uint16_t) < n_entries) {
+                job.n_qgc = (uint64_t)gsb.st_size / sizeof(uint16_t);
+                job.failed = stale_block(&job);
+            }
+        }
         pthread_mutex_init(&job.lock, NULL);
         pthread_t th[QM2_OUT_THREADS];
-        int n_th = 0;
         const uint64_t pieces = (n_entries + QM2_PIECE_ENTRIES - 1) / QM2_PIECE_ENTRIES;
-        while (n_th < QM2_OUT_THREADS && (uint64_t)n_th < pieces && pthread_create(&th[n_th], NULL, out_worker, &job) == 0) n_th++;
-        if (n_th == 0) out_worker(&job);                                       /* no thread to be had: this one */
+        while (!job.failed && n_th < QM2_OUT_THREADS && (uint64_t)n_th < pieces && pthread_create(&th[n_th], NULL, out_worker, &job) == 0) n_th++;
+        if (n_th == 0 && !job.failed) out_worker(&job);                        /* no thread to be had: this one */
         for (int t = 0; t < n_th; t++) pthread_join(th[t], NULL);
         pthread_mutex_destroy(&job.lock);
-        if (job.failed) { puts("Write to .bin failed"); rc = 1; }
+        free(job.stale);
+        if (job.failed) {
+            /* (a failed qm2_chain_fetch has printed the HIP error itself: qm2_last_error) */
+            puts(job.failed == QM2_OUT_ALLOC ? "Memory allocation failed" : job.failed == QM2_OUT_FETCH ? "Fetching the counts from the device failed"
+                 : job.failed == QM2_OUT_QGC ? "Reading the GC control file failed" : "Write to .bin failed");
+            rc = 1;
+        }
         for (int b = 0; b < 401; b++) { sum[b] = (double)job.sum[b]; sumsq[b] = (double)job.sumsq[b]; cnt[b] = (uint32_t)job.cnt[b]; }
     }
     if (fclose(bin) != 0 && !rc) { puts("Write to .bin failed"); rc = 1; }
     clock_gettime(CLOCK_MONOTONIC, &t2);
     if (getenv("QM2_TIMING"))
         printf("QM2 epilogue: chain file -> device + list ranking %.3f s, .bin%s on %d threads %.3f s\n",
-               (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec), qgc ? " + GC sums" : "", QM2_OUT_THREADS,
+               (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec), qgc ? " + GC sums" : "", n_th ? n_th : 1,
                (t2.tv_sec - t1.tv_sec) + 1e-9 * (t2.tv_nsec - t1.tv_nsec));
     if (rc) { if (qgc) fclose(qgc); free(path); return 1; }
 

@@ -676,10 +676,11 @@ extern "C" void *qm2_keys_device(qm2_ctx *c) { return c ? c->keys : nullptr; }
 
 static int batch_ready(qm2_ctx *c, Batch &b)
 {
+    /* (events first: b.dev marks the batch as complete, so a failure in between is retried whole) */
+    if (!b.done) HIP_OK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+    if (!b.copied) HIP_OK(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
     if (!b.dev) {
         HIP_OK(hipMalloc((void **)&b.dev, c->batch_bytes + kCarry + kDevPad));
-        HIP_OK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
         c->prof.allocations++;
     }
     if (b.busy) {
@@ -1267,6 +1268,7 @@ extern "C" int qm2_probe_slabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint6
     if (!c) return fail("qm2_probe_slabs_device: null context");
     if (n_slabs == 0 || slab_cap == 0) return 0;
     if (!d_slabs || !d_fill) return fail("qm2_probe_slabs_device: null buffer");
+    if (slab_cap > 0xFFFFFFFFull) return fail("qm2_probe_slabs_device: slab capacity must be below 2^32 (fills are 32-bit)");
     if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
     if (c->keys_consumed) return fail("qm2: the key table was overwritten by qm2_chain_gather; this context cannot count any more");
     if (use_device(c)) return 1;

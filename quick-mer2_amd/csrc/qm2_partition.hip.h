@@ -561,6 +561,10 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         const bool sh = shared != nullptr && ((shared[b >> 5] >> (b & 31)) & 1u) != 0;
         g.int_lo = (uint32_t)(own_lo - lo) + kHalo;
         g.int_len = sh ? 0u : (uint32_t)S - 2u * kHalo;
+#ifdef QM2_EXP_NO_EDGE_ATOMICS      /* timing experiment only (WRONG counts at bucket edges): the whole own range stored plainly */
+        g.int_lo = (uint32_t)(own_lo - lo);
+        g.int_len = (uint32_t)S;
+#endif
         return g;
     };
     auto fill_of = [&](uint32_t b) {
@@ -588,7 +592,11 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
 #pragma unroll
             for (int st = 0; st < kCntSteps; st++) {
                 const uint32_t i4 = tid + st * kLoaderThreads;
+#ifdef QM2_EXP_HALF_COUNTERS            /* ... and of the counter loads */
+                ov[st] = 4 * i4 - g.int_lo < g.int_len && (i4 & 1u) ? cp4[i4] : u32x4{0, 0, 0, 0};
+#else
                 ov[st] = 4 * i4 - g.int_lo < g.int_len ? cp4[i4] : u32x4{0, 0, 0, 0};
+#endif
             }
         };
         /* registers -> LDS buffer `bf`: keys, fingerprints, counter tile; mirrored when the bucket walks down */
@@ -640,7 +648,13 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                         cv = *reinterpret_cast<const u32x4 *>(&scnt[bf][i]);
                     }
                     if (i - g.int_lo < g.int_len) {
+#ifdef QM2_EXP_HALF_COUNTERS        /* timing experiment only (WRONG counts): half of the counter stores ... */
+                        if ((i >> 2) & 1u)
+#endif
                         *reinterpret_cast<u32x4 *>(cp + i) = cv;
+#ifdef QM2_EXP_NO_EDGE_ATOMICS
+                    } else if (true) {
+#endif
                     } else {
                         if (cv.x) atomicAdd(cp + i, cv.x);
                         if (cv.y) atomicAdd(cp + i + 1, cv.y);

@@ -395,3 +395,43 @@ extern "C" int qm2t_microbench(uint64_t slots, uint64_t n_ops, int mode, int rep
     if (ms_out) *ms_out = best;
     return 0;
 }
+
+/* ---- checksum of a counter array (parity tooling, not on the path) ------------------------------
+ * out[0] = sum of c[i] * (mix64(i) | 1) mod 2^64 (position-weighted: a count moved to another slot
+ * changes it), out[1] = plain sum, out[2] = slots that are not zero.  Lets bench.py and the full-size
+ * tests compare two runs over all 2^32 counters without a second 16 GiB array. */
+__global__ void checksum_u32_kernel(const uint32_t *c, uint64_t n, unsigned long long *out)
+{
+    unsigned long long w = 0, s = 0, nz = 0;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t n4 = n / 4, step = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) {
+        const u32x4 v = reinterpret_cast<const u32x4 *>(c)[i];
+        const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (e[j]) { w += (unsigned long long)e[j] * (mix64(4 * i + j) | 1ull); s += e[j]; nz++; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (uint64_t i = n4 * 4; i < n; i++)
+            if (c[i]) { w += (unsigned long long)c[i] * (mix64(i) | 1ull); s += c[i]; nz++; }
+    w = wave_sum(w); s = wave_sum(s); nz = wave_sum(nz);
+    if ((threadIdx.x & (kWave - 1)) == 0) { atomicAdd(&out[0], w); atomicAdd(&out[1], s); atomicAdd(&out[2], nz); }
+}
+
+extern "C" int qm2t_checksum_u32(const void *d_counters, uint64_t n, uint64_t out[3], void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!d_counters || !out || ((uintptr_t)d_counters & 15u)) { puts("qm2 tools: checksum needs a 16-byte aligned device array"); return 1; }
+    unsigned long long *d_out = nullptr;
+    T_OK(hipMalloc((void **)&d_out, 3 * sizeof(unsigned long long)));
+    T_OK(hipMemsetAsync(d_out, 0, 3 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(checksum_u32_kernel, dim3(4096), dim3(256), 0, s, (const uint32_t *)d_counters, n, d_out);
+    T_OK(hipGetLastError());
+    unsigned long long h[3];
+    T_OK(hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, s));
+    T_OK(hipStreamSynchronize(s));
+    T_OK(hipFree(d_out));
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    return 0;
+}

@@ -59,7 +59,7 @@ ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_probe
                "qm2_shard_span", "qm2_last_error",
                "qm2_abi_version"]
 TOOL_SYMBOLS = ["qm2t_genome_generate", "qm2t_dict_build", "qm2t_reads_generate",
-                "qm2t_read_offsets", "qm2t_microbench"]
+                "qm2t_read_offsets", "qm2t_microbench", "qm2t_checksum_u32"]
 
 _LIB = None
 
@@ -153,6 +153,8 @@ def lib():
     L.qm2t_read_offsets.argtypes = [vp, u64, u64, u32, u32, u64]
     L.qm2t_microbench.restype = C.c_int
     L.qm2t_microbench.argtypes = [u64, u64, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.qm2t_checksum_u32.restype = C.c_int
+    L.qm2t_checksum_u32.argtypes = [vp, u64, C.POINTER(u64 * 3), vp]
     _LIB = L
     return L
 
@@ -405,6 +407,13 @@ class tools:
         _check(lib().qm2t_reads_generate(d_genome, n, d_out, d_offsets, n_reads, first_read, len_lo, len_hi,
                                          seed, sub_rate, n_read_frac, fr, len(sample_from), stream),
                "qm2t_reads_generate")
+
+    @staticmethod
+    def checksum_u32(d_ptr, n, stream=None):
+        """-> (position-weighted checksum mod 2^64, plain sum, non-zero slots) of n u32 counters on the device"""
+        out = (C.c_uint64 * 3)()
+        _check(lib().qm2t_checksum_u32(d_ptr, n, C.byref(out), stream), "qm2t_checksum_u32")
+        return int(out[0]), int(out[1]), int(out[2])
 
     @staticmethod
     def microbench(slots, n_ops, mode, repeats=3):

@@ -196,8 +196,10 @@ def test_cli_epilogue_in_pieces_with_qgc(qm2, torch_cuda, tmp_path):
     """The epilogue's loop over the counts in chain order (.bin, and with a .qgc the GC curve of the .txt,
     QuicKmer.c:498-542) runs on worker threads that take 2^22-entry pieces; the reference vectors are all smaller
     than one piece.  Here: a 10 M-k-mer dictionary built on the device (3 pieces), a random .qgc — once whole, once
-    cut short, which the reference reads as zeros (:503) — and `.bin` / `.txt` compared with the counts of the API
-    path and with the reference's arithmetic restated in numpy."""
+    cut short in the middle of a 2^20-entry block — and `.bin` / `.txt` / the mean-depth line compared with what the
+    REFERENCE BINARY itself writes for the same files.  A short .qgc is not an error in the reference: fread's return
+    value is ignored (:502-503), so behind the end of the file its gc_control[] keeps the values of the last reads,
+    and those stale entries go on counting towards the curve; the CLI reproduces that (qm2_formats.c, stale_block)."""
     torch = torch_cuda
     n, H, k = 14_000_000, 1 << 26, 30
     genome = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -229,35 +231,29 @@ def test_cli_epilogue_in_pieces_with_qgc(qm2, torch_cuda, tmp_path):
         depth, st = c.finish()
     exp_bin = depth[occ]                                              # chain order = ascending slots here
     rng = np.random.default_rng(4)
-    g = rng.integers(0, 420, len(occ), dtype=np.uint16)               # some bins beyond 400: ignored (:505)
+    g = rng.integers(0, 401, len(occ), dtype=np.uint16)               # (a bin beyond 400 makes the reference write past its arrays, :505)
     g |= (rng.integers(0, 4, len(occ), dtype=np.uint16) == 0).astype(np.uint16) << 15
+    ref_bin = os.path.join(ol.ORACLE_DIR, "_ref", "quicKmer2")
+    texts = []
     for cut in (0, 3_000_001):
         gc = g[:len(g) - cut]
+        assert cut == 0 or (len(gc) >> 20 >= 1 and len(gc) % (1 << 20))   # ends inside a block, behind a full one
         gc.tofile(ref + ".qgc")
-        out = str(tmp_path / ("o%d" % cut))
+        out, rout = str(tmp_path / ("o%d" % cut)), str(tmp_path / ("r%d" % cut))
         r = subprocess.run([CLI, "count", "-t", "4", ref, str(fa), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         txt = r.stdout.decode(errors="replace")
         assert r.returncode == 0, txt
         assert "total %d kmers" % st["n_kmers"] in txt
         assert np.array_equal(np.fromfile(out + ".bin", dtype=np.uint16), exp_bin)
-        full = np.zeros(len(occ), dtype=np.uint16)
-        full[:len(gc)] = gc
-        ctrl = (full & 0x8000) != 0
-        b = (full & 0x1FF).astype(np.int64)
-        use = ctrl & (b < 401)
-        v = exp_bin[use].astype(np.int64)
-        cnt = np.bincount(b[use], minlength=401)
-        sm = np.bincount(b[use], weights=v.astype(np.float64), minlength=401)
-        sq = np.bincount(b[use], weights=((v * v).astype(np.uint32).view(np.int32)).astype(np.float64), minlength=401)
-        exp_txt = []
-        for i in range(401):
-            mean, var = sm[i], sq[i]
-            if cnt[i]:
-                mean = sm[i] / cnt[i]
-                var = sq[i] / cnt[i] - mean * mean
-            exp_txt.append("%.2f\t%f\t%d\t%f\n" % (i / 4.0, mean, cnt[i], var))
-        assert open(out + ".txt").read() == "".join(exp_txt), cut
-        assert "Mean sequencing depth: %.2f" % (sm.sum() / cnt.sum()) in txt
+        rr = subprocess.run([ref_bin, "count", "-t", "6", ref, str(fa), rout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        rtxt = rr.stdout.decode(errors="replace")
+        assert rr.returncode == 0, rtxt
+        assert open(out + ".bin", "rb").read() == open(rout + ".bin", "rb").read(), cut
+        assert open(out + ".txt").read() == open(rout + ".txt").read(), cut
+        mean = [l for l in rtxt.splitlines() if l.startswith("Mean sequencing depth")]
+        assert mean and mean[0] in txt, cut
+        texts.append(open(out + ".txt").read())
+    assert texts[0] != texts[1]                                       # the cut changed the curve, and both ways match the reference
 
 
 def test_cli_c1_against_live_reference(tmp_path):
@@ -1227,6 +1223,51 @@ def test_c3_scale_partitioned_equals_direct(qm2, torch_cuda, hg38_scale):
     sample = reads[:100_000 * (env["rl"] + 1)].cpu().numpy().tobytes()
     for flags in (qm2.FLAG_PARTITION, qm2.FLAG_DIRECT):
         _oracle_sample_equal(qm2, env, sample, flags)
+
+
+def test_c3_partitioned_equals_direct_at_the_cli_batch_geometry(qm2, torch_cuda, hg38_scale):
+    """The plan geometry the product really runs — the CLI's default device batch at hg38 scale, 6 GiB of
+    sequence lines = 42.6 M x 150 bp reads: 8192 level-1 sub-regions, 2^20 buckets, 58 + 64 + 13 GB of partition
+    buffers with more than 2^32 k-mer places — compared SLOT FOR SLOT with the direct kernel, which shares
+    nothing with the partitioned pipeline but the front end (every k-mer probed exactly once, QuicKmer.c:283-293).
+    The smaller C3 tests run plans an eighth of this size; bench.py makes the same comparison at its own batch
+    (50 M reads) through tools.checksum_u32, which is checked against torch here."""
+    torch, env = torch_cuda, hg38_scale
+    H, k, keys, genome, n, rl = env["H"], env["k"], env["keys"], env["genome"], env["n"], env["rl"]
+    free, _ = torch.cuda.mem_get_info()
+    batch_bytes = 6 << 30
+    if free < 190 * (1 << 30):
+        pytest.skip("needs ~190 GiB of free HBM (two counter arrays, a 6 GiB batch, 135 GB of partition buffers)")
+    n_reads = batch_bytes // (rl + 1)
+    reads = torch.empty(n_reads * (rl + 1), dtype=torch.uint8, device="cuda")
+    qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, n_reads, 7_000_000, rl, rl, 38)
+    a = torch.zeros(H, dtype=torch.int32, device="cuda")
+    b = torch.zeros(H, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=a.data_ptr(),
+                     flags=qm2.FLAG_DIRECT) as cd:
+        cd.submit_device(reads.data_ptr(), reads.numel())
+        _, sd = cd.finish(want_depth=False)
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), ext_counters=b.data_ptr(),
+                     flags=qm2.FLAG_TIMING) as cp:
+        cp.prepare(batch_bytes)                                   # what the CLI does before the dictionary streams in
+        cp.submit_device(reads.data_ptr(), reads.numel())
+        _, sp = cp.finish(want_depth=False)
+        pr = cp.profile()
+    assert pr["partitioned_batches"] == 1 and pr["fallback_batches"] == 0 and pr["direct_batches"] == 0
+    assert sp == sd and sd["n_bases"] == n_reads * rl and sd["n_hits"] > 0.7 * sd["n_kmers"]
+    assert torch.equal(a, b)
+    ca, cb = qm2.tools.checksum_u32(a.data_ptr(), H), qm2.tools.checksum_u32(b.data_ptr(), H)
+    assert ca == cb and ca[1] == sd["n_hits"] == int(sum(int(a[i:i + (1 << 28)].sum(dtype=torch.int64)) for i in range(0, H, 1 << 28)))
+    assert ca[2] == int(sum(int((a[i:i + (1 << 28)] != 0).sum()) for i in range(0, H, 1 << 28)))
+    # the checksum is position-weighted: one count moved to the neighbouring slot must change it
+    i = int(torch.nonzero(a[:1 << 20])[0])
+    b[i] -= 1
+    b[i + 1] += 1
+    cc = qm2.tools.checksum_u32(b.data_ptr(), H)
+    assert cc[1] == ca[1] and cc[0] != ca[0]
+    del a, b, reads
+    torch.cuda.empty_cache()
 
 
 def test_c3_scale_skew_overflows_the_sub_regions(qm2, torch_cuda, hg38_scale):
