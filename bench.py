@@ -293,17 +293,24 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
         dist.all_reduce(tot)
         n_bases, n_kmers, n_probes, n_hits, csum, hsum = [int(x) for x in tot]
         conserved = csum == hsum
+        spilled = job.ctx.profile()["spilled_kmers"]
         retries = job.retries
         par = "hash-range shards x%d: one per rank, k-mers routed by asynchronous RCCL all-to-all of fixed slabs" % world
         job.close()
     else:
         cap = (int(max_bytes / G * 1.3) + 4096) & ~1
-        router = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=pyqm2.FLAG_KEYS_LATER | flags, span=(0, 64))
+        # ONE stream for the router and all the logical shards: their kernels then run one after the other and the
+        # HIP-event time of a launch is its own run time.  (With a stream per context, as in round 2, the eight shards'
+        # launches queued behind each other's kernels and every tiny spill-list probe was charged ~1.4 ms of waiting:
+        # "probe 11.35 ms per step" in profiles/r02_c3/bench_sharded_8_logical_20M.json was that, not work.)
+        one = torch.cuda.Stream(device=dev)
+        router = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=pyqm2.FLAG_KEYS_LATER | flags, span=(0, 64),
+                               stream=one.cuda_stream)
         shards = []
         for own_lo, own_hi, lo, hi in spans:
             cnt = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
             c = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=flags, ext_keys=keys.data_ptr() + 8 * lo,
-                              ext_counters=cnt.data_ptr(), span=(lo, hi), own=(own_lo, own_hi))
+                              ext_counters=cnt.data_ptr(), span=(lo, hi), own=(own_lo, own_hi), stream=one.cuda_stream)
             c.prepare(cap)
             shards.append((c, cnt))
         slabs = torch.empty(G * cap, dtype=torch.int64, device=dev)
@@ -343,6 +350,7 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
         n_probes = sum(b["n_probes"] - a["n_probes"] for a, b in zip(s0, s1))
         n_hits = sum(b["n_hits"] - a["n_hits"] for a, b in zip(s0, s1))
         conserved = sum(sum64(torch, cnt) for _, cnt in shards) == sum(b["n_hits"] for b in s1)
+        spilled = sum(c.profile()["spilled_kmers"] for c, _ in shards)
         retries = 0
         par = "hash-range shards x%d, LOGICAL on one GPU (route + one partitioned probe per shard; the exchange is a no-op)" % G
         for c, _ in shards:
@@ -360,7 +368,7 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
         "config": {"workload": args.workload + ": " + wl["desc"], "k": k, "hash_size": H, "dict_kmers": n_unique,
                    "reads_per_step_per_gpu": wl["reads"], "parallelism": par, "shards": G,
                    "inputs": "resident in HBM", "setup_s": round(t_setup, 1), "counts_conserved": bool(conserved),
-                   "batches_cut_and_rerouted": retries},
+                   "batches_cut_and_rerouted": retries, "spilled_kmers_rank0_or_all_logical": spilled},
         "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                      "traffic": None, "what": "whole path per GPU: SURVEY 8(d) bytes / wall time of the timed steps (route + exchange + partition + count)",
                      "kernel_ms_per_step": {c: round(v / args.steps, 3) for c, v in t_class.items() if v},
@@ -758,7 +766,7 @@ def main():
                        if world > 1 else "1 GPU", "inputs": "resident in HBM (value); host-fed rates under `streamed`",
                        "setup_s": round(t_setup, 1),
                        "final_reduce_ms": round(reduce_ms, 2) if reduce_ms is not None else None,
-                       "counts_conserved": counts_conserved},
+                       "counts_conserved": counts_conserved, "spilled_kmers": prof1["spilled_kmers"] - prof0["spilled_kmers"]},
             "kernel_only_bases_per_s": roofline["kernel_only_bases_per_s"],
             "streamed_bases_per_s": streamed["streamed_bases_per_s"] if streamed else None,
             "h2d_GBps": streamed["h2d_GBps"] if streamed else None,

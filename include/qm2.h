@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define QM2_ABI_VERSION 2
+#define QM2_ABI_VERSION 3
 
 typedef struct qm2_ctx qm2_ctx;
 
@@ -66,6 +66,12 @@ typedef struct qm2_ctx qm2_ctx;
                                       default: chosen per batch from its size vs. H   */
 #define QM2_FLAG_KEYS_LATER  0x10u /* qm2_open(keys = NULL): allocate the device key
                                       table but fill it later with qm2_keys_from_fd   */
+#define QM2_FLAG_RAW_STRICT  0x20u /* raw text (qm2_staging_commit_raw / qm2_submit_raw_device): refuse a batch with ANY
+                                      FASTQ sequence-position line that starts with '>' (QM2_RAW_DESYNC) instead of
+                                      following up to 64 of them.  Such a line moves every later sequence line of the
+                                      TEXT on by one; a context that sees only some of the text's batches (one of
+                                      several replicas fed in turns, `--devices`) cannot know about those in the
+                                      batches it did not see, so there the caller takes the host path for such input */
 
 typedef struct {
     uint32_t struct_size;     /* = sizeof(qm2_opts); 0-filled fields = defaults  */
@@ -136,6 +142,8 @@ typedef struct {
     uint64_t allocations;      /* device / pinned-host allocations the counting pipeline made since
                                   qm2_open or the last qm2_reset (0 between the first submit and
                                   qm2_finish once qm2_prepare has run)                          */
+    uint64_t spilled_kmers;    /* partitioned batches: k-mers that did not fit their bucket and were probed from the
+                                  spill list by the direct path (skewed input; 0 on uniform reads)            */
 } qm2_profile;
 
 /* Create a counting context for a dictionary of `hash_size` slots (power of
@@ -202,6 +210,14 @@ int qm2_stats_peek(qm2_ctx *c, qm2_stats *st);
  * does its allocations up front too, QuicKmer.c:353-384). */
 #define QM2_PREPARE_HOST 1u
 #define QM2_PREPARE_RAW  2u
+/* the raw batches will be FASTQ text: at most half of a batch's bytes are sequence, so the partition buffers are
+ * sized for half a batch (22 -> 11 bytes of scratch per batch byte: the largest share of the load phase at hg38
+ * scale is allocating it).  Only a bound on memory: text that breaks it (qualities shorter than their sequences)
+ * overflows into the spill list or is recounted by the direct kernel, exact either way. */
+#define QM2_PREPARE_FASTQ 4u
+/* everything BUT the partition buffers; a second call without this flag makes them — e.g. from another thread while
+ * qm2_keys_from_fd streams the dictionary in (the two may run concurrently; nothing else of a context may) */
+#define QM2_PREPARE_NO_PART 8u
 int qm2_prepare(qm2_ctx *c, uint64_t batch_bytes, uint32_t what);
 
 /* Zero counters and statistics (a fresh calloc, :360). */

@@ -5,7 +5,9 @@
  * the end (:335, :338, :342), same stdout lines, same output files.
  */
 #define _GNU_SOURCE
+#include <fcntl.h>
 #include <getopt.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
@@ -67,55 +69,142 @@ static int out_commit_raw(void *user, char *buf, size_t offset, size_t n, int fa
     return qm2_raw_verdict((qm2_ctx *)user) ? 2 : 0;       /* refused: no point in reading on */
 }
 
+/* the context's default device batch: 1.5 bytes per table slot, 1..6 GiB (qm2_open) */
+static uint64_t default_batch_bytes(uint64_t hash_size)
+{
+    uint64_t bb = hash_size + hash_size / 2;
+    if (bb < (1ull << 30)) bb = 1ull << 30;
+    if (bb > (6ull << 30)) bb = 6ull << 30;
+    return bb;
+}
+
+/* What the reader will do with `reads`: a regular file goes to the device as raw text (unless QM2_READER_RAW=0) and
+ * its first byte says FASTQ or FASTA (:393-395); *size = its length, 0 for pipes. */
+static void sniff_input(const char *reads, int *regular, int *fastq, uint64_t *size)
+{
+    *regular = 0; *fastq = 0; *size = 0;
+    struct stat sb;
+    if (stat(reads, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size <= 0) return;
+    *regular = 1;
+    *size = (uint64_t)sb.st_size;
+    const int fd = open(reads, O_RDONLY);
+    if (fd < 0) return;
+    char first = 0;
+    if (pread(fd, &first, 1, 0) == 1 && first == '@') *fastq = 1;
+    close(fd);
+}
+
+/* The partition buffers (tens of GB of hipMalloc: seconds of driver time at hg38 scale) are allocated on a thread of
+ * their own while the calling thread streams the dictionary from the file to the device. */
+typedef struct { qm2_ctx *ctx; uint32_t what; int rc; } prepare_job;
+static void *prepare_main(void *arg)
+{
+    prepare_job *j = arg;
+    j->rc = qm2_prepare(j->ctx, 0, j->what);
+    return NULL;
+}
+
+/* qm2_prepare's partition part beside qm2_keys_from_fd, then the look at the key table's runs of occupied slots */
+static int load_keys_and_prepare(qm2_dict_file *d, qm2_ctx *ctx, uint32_t what, int print)
+{
+    prepare_job job = {ctx, what, 0};
+    pthread_t th;
+    const int threaded = pthread_create(&th, NULL, prepare_main, &job) == 0;
+    int rc = qm2_dict_load_keys_quiet(d, ctx, print);
+    if (threaded) pthread_join(th, NULL);
+    else job.rc = qm2_prepare(ctx, 0, what);
+    if (rc || job.rc) return 1;
+    return qm2_prepare(ctx, 0, what);          /* (everything is there: only the one-off look at the runs is left) */
+}
+
 /* --devices a,b,...: a replica of the dictionary on every listed GPU (the same ordinal may be listed
- * twice: two contexts on one GPU), one reader, the sequence lines dealt to the contexts a device batch at
- * a time (qm2_dispatch.c), the counters summed into the first context before the epilogue.  The host
- * strips the input here (the device line discipline numbers the lines of consecutive text, which turns
- * do not give it).  On return ctxs[0] holds the job's counters and *st its totals. */
+ * twice: two contexts on one GPU), one reader, the input dealt to the contexts a device batch at a time
+ * (qm2_dispatch.c), the counters summed into the first context before the epilogue.  Regular files go to the
+ * devices as raw text, like in the single-context path: a turn is a run of consecutive blocks with the line
+ * state at its first byte, so every batch of every context is consecutive text and the device line discipline
+ * applies unchanged.  The one thing a context cannot know is what the batches it did NOT see did to the line
+ * numbering — a FASTQ sequence-position line that starts with '>' (:398) moves all later sequence lines on by
+ * one — so the contexts refuse any such line (QM2_FLAG_RAW_STRICT) and the whole input then goes through the
+ * host line discipline instead, from zeroed counters: exact either way.  On return ctxs[0] holds the job's
+ * counters and *st its totals. */
 static int count_on_devices(qm2_dict_file *d, const char *reads, int n_strip, const int *devices, int n_dev,
                             qm2_ctx **ctxs, qm2_stats *st, int timing)
 {
     qm2_sink sinks[QM2_MAX_DEVICES];
     struct timespec ta, tb;
     clock_gettime(CLOCK_MONOTONIC, &ta);
-    size_t turn = 0;
+    int regular, fastq;
+    uint64_t in_size;
+    sniff_input(reads, &regular, &fastq, &in_size);
+    const char *raw_env = getenv("QM2_READER_RAW");
+    int want_raw = regular && n_strip > 0 && !(raw_env && strcmp(raw_env, "0") == 0);
+    const uint32_t what = QM2_PREPARE_HOST | (want_raw ? QM2_PREPARE_RAW : 0u) | (want_raw && fastq ? QM2_PREPARE_FASTQ : 0u);
     for (int i = 0; i < n_dev; i++) {
         qm2_opts o;
         memset(&o, 0, sizeof o);
         o.struct_size = sizeof o;
         o.device = devices[i];
-        o.flags = QM2_FLAG_KEYS_LATER;
+        o.flags = QM2_FLAG_KEYS_LATER | QM2_FLAG_RAW_STRICT;
         o.n_staging = (uint32_t)n_strip + 3;
         if (qm2_open(&ctxs[i], NULL, d->hash_size, d->k, &o)) return 1;
-        if (qm2_prepare(ctxs[i], 0, QM2_PREPARE_HOST)) return 1;
-        if (qm2_dict_load_keys_quiet(d, ctxs[i], i == 0)) return 1;
+        if (qm2_prepare(ctxs[i], 0, what | QM2_PREPARE_NO_PART)) return 1;
+        if (load_keys_and_prepare(d, ctxs[i], what, i == 0)) return 1;
         sinks[i].acquire = out_acquire; sinks[i].commit = out_commit; sinks[i].submit = out_submit;
-        sinks[i].flush = out_flush; sinks[i].user = ctxs[i];
+        sinks[i].flush = out_flush; sinks[i].user = ctxs[i]; sinks[i].commit_raw = out_commit_raw;
         progress_ctx[i] = ctxs[i];
     }
     progress_n = n_dev;
     clock_gettime(CLOCK_MONOTONIC, &tb);
     if (timing) printf("QM2 phase load-dictionary %.3f s (file -> %d devices)\n", (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec), n_dev);
-    /* a turn = one device batch (1.5 bytes per table slot, 1..6 GiB: qm2_open's default) */
-    {
-        uint64_t bb = d->hash_size + d->hash_size / 2;
-        if (bb < (1ull << 30)) bb = 1ull << 30;
-        if (bb > (6ull << 30)) bb = 6ull << 30;
-        const char *env = getenv("QM2_TURN_BYTES");           /* (tests: small turns on small inputs) */
-        turn = env ? (size_t)strtoull(env, NULL, 10) : (size_t)bb;
+    /* a turn = one device batch, a little less: the flush that ends the turn then launches the whole batch (a turn
+     * of exactly a batch is flushed by the context itself when it fills, and the turn's flush would launch the few
+     * bytes that were left over as a batch of their own) */
+    const uint64_t bb = default_batch_bytes(d->hash_size);
+    const char *env = getenv("QM2_TURN_BYTES");               /* (tests: small turns on small inputs) */
+    const size_t turn = env ? (size_t)strtoull(env, NULL, 10) : (size_t)(bb - bb / 16);
+    int rc = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        qm2_dispatch *disp = qm2_dispatch_new(sinks, n_dev, turn);
+        if (!disp) { puts("Memory allocation failed"); return 1; }
+        if (want_raw) {
+            /* raw blocks: whole blocks of the reader, as many as fit a batch with room for the line that ends each */
+            const size_t per_block = qm2_reader_block_bytes() + (1u << 20);
+            const char *tb_env = getenv("QM2_TURN_BLOCKS");
+            size_t blocks = tb_env ? (size_t)strtoull(tb_env, NULL, 10) : (size_t)(bb / per_block);
+            qm2_dispatch_raw_turn(disp, blocks ? blocks : 1);
+        }
+        qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, disp, want_raw ? qm2_dispatch_commit_raw : NULL};
+        rc = qm2_stream_reads(reads, &out, n_strip);
+        qm2_dispatch_free(disp);
+        memset(st, 0, sizeof *st);
+        uint32_t verdict = 0;
+        for (int i = 0; i < n_dev && rc != 1; i++) {
+            qm2_stats s1;
+            if (qm2_finish(ctxs[i], NULL, &s1)) { rc = 1; break; }
+            verdict |= qm2_raw_verdict(ctxs[i]);
+            st->n_bases += s1.n_bases; st->n_kmers += s1.n_kmers; st->n_probes += s1.n_probes; st->n_hits += s1.n_hits;
+        }
+        if (rc == 1 || !want_raw || (rc == 0 && verdict == 0)) break;
+        /* a raw block was refused (or did not fit a buffer): everything again through the host line discipline */
+        if (timing) printf("QM2 raw input refused (verdict %u): host line discipline\n", verdict);
+        want_raw = 0;
+        rc = 0;
+        for (int i = 0; i < n_dev && !rc; i++) rc = qm2_reset(ctxs[i]);
+        if (rc) break;
     }
-    qm2_dispatch *disp = qm2_dispatch_new(sinks, n_dev, turn);
-    if (!disp) { puts("Memory allocation failed"); return 1; }
-    qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, disp, NULL};
-    int rc = qm2_stream_reads(reads, &out, n_strip);
-    qm2_dispatch_free(disp);
-    memset(st, 0, sizeof *st);
-    for (int i = 0; i < n_dev && !rc; i++) {
-        qm2_stats s1;
-        rc = qm2_finish(ctxs[i], NULL, &s1);
-        st->n_bases += s1.n_bases; st->n_kmers += s1.n_kmers; st->n_probes += s1.n_probes; st->n_hits += s1.n_hits;
+    struct timespec tc;
+    clock_gettime(CLOCK_MONOTONIC, &tc);
+    if (timing && !rc) {
+        const double sec = (tc.tv_sec - tb.tv_sec) + 1e-9 * (tc.tv_nsec - tb.tv_nsec);
+        printf("QM2 phase count %.3f s (%.2f G bases/s) on %d contexts, %s\n", sec, st->n_bases / sec / 1e9, n_dev,
+               want_raw ? "raw blocks in turns" : "host line discipline");
     }
     for (int i = 1; i < n_dev && !rc; i++) rc = qm2_merge_counters(ctxs[0], ctxs[i]);
+    if (timing && !rc) {
+        struct timespec tm;
+        clock_gettime(CLOCK_MONOTONIC, &tm);
+        printf("QM2 phase merge-counters %.3f s\n", (tm.tv_sec - tc.tv_sec) + 1e-9 * (tm.tv_nsec - tc.tv_nsec));
+    }
     return rc;
 }
 
@@ -162,7 +251,7 @@ int qm2_main_count(int argc, char **argv)
      * the host threads that strip FASTA/FASTQ blocks into pinned staging (default 4). */
     /* default: 8 where the machine has the cores (FASTQ: 4.7 -> 6.0 G bases/s measured), else 4 */
     int n_strip = getopt_seen_t ? (int)thread_count : (sysconf(_SC_NPROCESSORS_ONLN) >= 16 ? 8 : 4);
-    if (n_strip > 16) n_strip = 16;
+    if (n_strip > 32) n_strip = 32;
 
     const int timing = getenv("QM2_TIMING") != NULL;   /* extra phase lines; off by default so that
                                                           stdout stays the reference's */
@@ -203,20 +292,18 @@ int qm2_main_count(int argc, char **argv)
     o.device = n_dev == 1 ? devices[0] : -1;
     o.flags = QM2_FLAG_KEYS_LATER;
     o.n_staging = (uint32_t)n_strip + 3;
-    {
+    int regular, fastq;
+    uint64_t in_size;
+    sniff_input(reads, &regular, &fastq, &in_size);
+    if (regular) {
         /* A regular file smaller than the default device batch (1.5 bytes per table slot, up to 6 GiB): one
          * batch of its size is enough, and qm2_prepare then allocates (and the driver clears) a fraction of the
-         * partition scratch — 22 bytes per batch byte, seconds of hipMalloc at the default against an hg38-scale
-         * table.  Pipes and larger files keep the default. */
-        struct stat sb;
-        if (stat(reads, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
-            uint64_t deflt = d.hash_size + d.hash_size / 2;
-            if (deflt < (1ull << 30)) deflt = 1ull << 30;
-            if (deflt > (6ull << 30)) deflt = 6ull << 30;
-            uint64_t need = ((uint64_t)sb.st_size + (256ull << 20)) & ~((256ull << 20) - 1);   /* (FASTQ: twice what it needs) */
-            if (need < (1ull << 30)) need = 1ull << 30;
-            if (need < deflt) o.batch_bytes = need;
-        }
+         * partition scratch — 22 bytes per batch byte (11 for FASTQ text), seconds of hipMalloc at the default
+         * against an hg38-scale table.  Pipes and larger files keep the default. */
+        const uint64_t deflt = default_batch_bytes(d.hash_size);
+        uint64_t need = (in_size + (256ull << 20)) & ~((256ull << 20) - 1);
+        if (need < (1ull << 30)) need = 1ull << 30;
+        if (need < deflt) o.batch_bytes = need;
     }
     clock_gettime(CLOCK_MONOTONIC, &ta);
     const char *raw_env = getenv("QM2_READER_RAW");
@@ -225,13 +312,15 @@ int qm2_main_count(int argc, char **argv)
     if (qm2_open(&ctx, NULL, d.hash_size, d.k, &o)) { qm2_dict_close(&d); return 1; }
     clock_gettime(CLOCK_MONOTONIC, &t_open);
     /* every buffer of the counting phase is allocated here, like the reference's mallocs and thread start-up
-     * ahead of its timed loop (:353-384): nothing but copies and kernels between the first block and the drain */
-    if (qm2_prepare(ctx, 0, QM2_PREPARE_HOST | (want_raw ? QM2_PREPARE_RAW : 0u))) { qm2_close(ctx); qm2_dict_close(&d); return 1; }
+     * ahead of its timed loop (:353-384): nothing but copies and kernels between the first block and the drain.
+     * The partition buffers — the slow part — are made while the dictionary streams in. */
+    const uint32_t what = QM2_PREPARE_HOST | (want_raw ? QM2_PREPARE_RAW : 0u) | (want_raw && regular && fastq ? QM2_PREPARE_FASTQ : 0u);
+    if (qm2_prepare(ctx, 0, what | QM2_PREPARE_NO_PART)) { qm2_close(ctx); qm2_dict_close(&d); return 1; }
     clock_gettime(CLOCK_MONOTONIC, &t_prep);
-    if (qm2_dict_load_keys(&d, ctx)) { qm2_close(ctx); qm2_dict_close(&d); return 1; }
+    if (load_keys_and_prepare(&d, ctx, what, 1)) { qm2_close(ctx); qm2_dict_close(&d); return 1; }
     clock_gettime(CLOCK_MONOTONIC, &tb);
     if (timing)
-        printf("QM2 phase load-dictionary %.3f s (file -> device; open %.3f + prepare %.3f + keys %.3f)\n",
+        printf("QM2 phase load-dictionary %.3f s (file -> device; open %.3f + staging and batches %.3f + keys beside the partition buffers %.3f)\n",
                (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec), (t_open.tv_sec - ta.tv_sec) + 1e-9 * (t_open.tv_nsec - ta.tv_nsec),
                (t_prep.tv_sec - t_open.tv_sec) + 1e-9 * (t_prep.tv_nsec - t_open.tv_nsec), (tb.tv_sec - t_prep.tv_sec) + 1e-9 * (tb.tv_nsec - t_prep.tv_nsec));
 

@@ -7,6 +7,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 #include "../../include/qm2.h"
@@ -118,6 +119,8 @@ struct qm2_ctx {
     uint64_t   *raw_wraps = nullptr;        /* where the uint16 run counter wraps (qm2_raw.hip.h), sorted */
     uint32_t    raw_shift = 0;              /* '>' lines at FASTQ sequence positions so far in this text, mod 4 */
     uint32_t    raw_verdict = 0;            /* sticky: a raw batch was refused (QM2_RAW_*); nothing raw is counted after it */
+    std::mutex  runs_mu;                    /* the one-off look at the runs of occupied slots: qm2_prepare on one thread,
+                                               qm2_keys_from_fd on another (QM2_PREPARE_NO_PART) */
     /* epilogue (qm2_epilogue.hip) */
     uint32_t   *chain = nullptr;            /* device copy of next[]; aliases keys when owned */
     bool        own_chain = false;

@@ -60,6 +60,7 @@ struct DevStats {
                                        their bucket nor the spill list => the batch is recounted by
                                        the direct kernel instead (exact either way)              */
     unsigned long long fallbacks;   /* batches that took that fallback                            */
+    unsigned long long spilled;     /* k-mers that went through the spill list, all batches       */
 };
 
 /* ---- SWAR helpers ---------------------------------------------------------- */

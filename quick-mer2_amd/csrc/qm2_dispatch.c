@@ -4,13 +4,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#define QM2_MAX_LENT 64
+#define QM2_MAX_LENT 128
 
 struct qm2_dispatch {
     qm2_sink *sinks;
     int n, cur;
     size_t per_turn, turn_bytes;
-    struct { char *buf; int sink; } lent[QM2_MAX_LENT];
+    size_t raw_per_turn;                   /* > 0: turns are counted in acquired buffers */
+    unsigned long acquired;                /* buffers handed out so far */
+    struct { char *buf; int sink; unsigned long seq; } lent[QM2_MAX_LENT];
 };
 
 qm2_dispatch *qm2_dispatch_new(const qm2_sink *sinks, int n_sinks, size_t bytes_per_turn)
@@ -24,6 +26,11 @@ qm2_dispatch *qm2_dispatch_new(const qm2_sink *sinks, int n_sinks, size_t bytes_
     d->n = n_sinks;
     d->per_turn = bytes_per_turn ? bytes_per_turn : 1;
     return d;
+}
+
+void qm2_dispatch_raw_turn(qm2_dispatch *d, size_t buffers_per_turn)
+{
+    d->raw_per_turn = buffers_per_turn ? buffers_per_turn : 1;
 }
 
 void qm2_dispatch_free(qm2_dispatch *d)
@@ -51,11 +58,21 @@ int qm2_dispatch_acquire(void *user, char **buf, size_t *capacity)
     int slot = -1;
     for (int i = 0; i < QM2_MAX_LENT; i++) if (!d->lent[i].buf) { slot = i; break; }
     if (slot < 0) { puts("qm2: too many staging buffers held at once"); return 1; }
-    qm2_sink *s = &d->sinks[d->cur];
+    const int owner = d->raw_per_turn ? (int)((d->acquired / d->raw_per_turn) % (unsigned long)d->n) : d->cur;
+    qm2_sink *s = &d->sinks[owner];
     if (s->acquire(s->user, buf, capacity)) return 1;
     d->lent[slot].buf = *buf;
-    d->lent[slot].sink = d->cur;
+    d->lent[slot].sink = owner;
+    d->lent[slot].seq = d->acquired++;
     return 0;
+}
+
+/* raw turns: the buffer that was acquired last in its turn closes the turn when it comes back */
+static int raw_turn_over(qm2_dispatch *d, int sink, unsigned long seq)
+{
+    if (d->n == 1 || (seq + 1) % d->raw_per_turn != 0) return 0;
+    qm2_sink *s = &d->sinks[sink];
+    return s->flush ? s->flush(s->user) : 0;
 }
 
 int qm2_dispatch_commit(void *user, char *buf, size_t n)
@@ -63,11 +80,32 @@ int qm2_dispatch_commit(void *user, char *buf, size_t n)
     qm2_dispatch *d = user;
     for (int i = 0; i < QM2_MAX_LENT; i++) {
         if (d->lent[i].buf != buf) continue;
-        qm2_sink *s = &d->sinks[d->lent[i].sink];
-        const int was_current = d->lent[i].sink == d->cur;
+        const int sink = d->lent[i].sink;
+        const unsigned long seq = d->lent[i].seq;
+        qm2_sink *s = &d->sinks[sink];
+        const int was_current = sink == d->cur;
         d->lent[i].buf = NULL;
         if (s->commit(s->user, buf, n)) return 1;
+        if (d->raw_per_turn) return raw_turn_over(d, sink, seq);     /* (a buffer given back unused: n = 0) */
         return was_current ? turn_over(d, n) : 0;
+    }
+    puts("qm2: commit of a buffer that was not acquired");
+    return 1;
+}
+
+int qm2_dispatch_commit_raw(void *user, char *buf, size_t offset, size_t n, int fastq, unsigned skip)
+{
+    qm2_dispatch *d = user;
+    for (int i = 0; i < QM2_MAX_LENT; i++) {
+        if (d->lent[i].buf != buf) continue;
+        const int sink = d->lent[i].sink;
+        const unsigned long seq = d->lent[i].seq;
+        qm2_sink *s = &d->sinks[sink];
+        d->lent[i].buf = NULL;
+        if (!s->commit_raw) { puts("qm2: raw commit to a sink that takes none"); return 1; }
+        const int rc = s->commit_raw(s->user, buf, offset, n, fastq, skip);
+        if (rc) return rc;
+        return raw_turn_over(d, sink, seq);
     }
     puts("qm2: commit of a buffer that was not acquired");
     return 1;

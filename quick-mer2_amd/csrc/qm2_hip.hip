@@ -279,7 +279,8 @@ struct PartSource {
     uint64_t slab_cap = 0;
     uint32_t n_slabs = 0;
     const uint32_t *fill = nullptr;
-    uint64_t n_upper = 0;           /* upper bound on the k-mers (text: its bytes) */
+    uint64_t n_upper = 0;           /* upper bound on the k-mers (text: its sequence bytes) */
+    uint64_t n_bytes = 0;           /* bytes launched (what kmers_per_byte is measured against) */
 };
 
 static int launch_partitioned(qm2_ctx *c, const PartSource &src)
@@ -349,7 +350,7 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
          * + 3 sigma of uniform hashing; k-mers per byte measured on earlier batches through an asynchronous
          * copy of the stats block) wastes the fewest rows */
         stats_peek_harvest(c);
-        const uint64_t per_bucket = (uint64_t)((double)src.n_upper * (src.sv ? c->kmers_per_byte : 1.0 / 1.3)) / n_buckets;
+        const uint64_t per_bucket = (uint64_t)((double)src.n_bytes * (src.sv ? c->kmers_per_byte : 1.0 / 1.3)) / n_buckets;
         int g = 4, lw = 3;
         {
             /* loader waves (3 or 4 of the 16) and group size: the fewest rows of 2 k-mers per prober thread that
@@ -408,7 +409,7 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
             if (time_end(c, &t, g + 1 == src.n_slabs)) return 1;
         }
     }
-    hipLaunchKernelGGL(part_end_kernel, dim3(1), dim3(64), 0, s, c->stats);
+    hipLaunchKernelGGL(part_end_kernel, dim3(1), dim3(64), 0, s, c->stats, p.spill_count);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -422,6 +423,7 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
 static int runs_fit(qm2_ctx *c, bool *ok)
 {
     PartPlan &p = c->part;
+    std::lock_guard<std::mutex> guard(c->runs_mu);
     if (p.runs == 0) {
         const uint64_t n_buckets = p.buckets[p.levels - 1];
         const size_t words = (size_t)((n_buckets + 31) / 32);
@@ -477,8 +479,9 @@ static void stats_peek_harvest(qm2_ctx *c)
     }
 }
 
+/* seq_bound: an upper bound on the batch's sequence bytes when it is smaller than n (raw FASTQ text: half), else 0 */
 static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry, const uint64_t *d_sup,
-                        uint64_t n_sup)
+                        uint64_t n_sup, uint64_t seq_bound = 0)
 {
     if (n == 0) return 0;
     if (c->keys_consumed)
@@ -495,12 +498,14 @@ static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry,
         if (runs_fit(c, &ok)) return 1;
         if (!ok) part = false;
     }
-    if (part && part_reserve(c, n)) part = false;                    /* no memory: direct */
+    const uint64_t bound = seq_bound && seq_bound < n ? seq_bound : (uint64_t)n;
+    if (part && part_reserve(c, bound)) part = false;                /* no memory: direct */
     if (part) {
         c->prof.partitioned_batches++;
         PartSource src;
         src.sv = &sv;
-        src.n_upper = sv.n_total;
+        src.n_upper = bound + 16;
+        src.n_bytes = sv.n_total;
         if (launch_partitioned(c, src)) return 1;
     } else {
         c->prof.direct_batches++;
@@ -938,7 +943,7 @@ static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint3
         HIP_OK(hipMemcpyAsync(&fl, c->raw_flags, sizeof fl, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
         if (fl.bits || fl.next_desync == ~0ull) break;
-        if (rv.n_desync == kRawMaxDesync) { fl.bits |= kRawDesync; break; }
+        if (rv.n_desync == kRawMaxDesync || (c->flags & QM2_FLAG_RAW_STRICT)) { fl.bits |= kRawDesync; break; }
         rv.desync[rv.n_desync++] = fl.next_desync;           /* found in ascending order: the list stays sorted */
     }
     if (time_end(c, &t)) return 1;
@@ -952,7 +957,8 @@ static int raw_classify_and_count(qm2_ctx *c, const void *d_raw, size_t n, uint3
         HIP_OK(hipMemcpy(c->raw_wraps, w.data(), w.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
     /* + the terminator raw_apply_kernel wrote at [n]; the wrap list plays the part of qm2_plan.h's */
-    return launch_batch(c, c->raw_out, n + 1, 0, n_wraps ? c->raw_wraps : nullptr, n_wraps);
+    /* FASTQ: a record's qualities are as long as its sequence, so at most half of the text is sequence (QM2_PREPARE_FASTQ) */
+    return launch_batch(c, c->raw_out, n + 1, 0, n_wraps ? c->raw_wraps : nullptr, n_wraps, fastq ? n / 2 + 64 : 0);
 }
 
 extern "C" int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fastq, uint32_t skip,
@@ -1108,10 +1114,12 @@ extern "C" int qm2_prepare(qm2_ctx *c, uint64_t batch_bytes, uint32_t what)
     if (what & QM2_PREPARE_RAW) {
         if (raw_reserve(c, bb + 1)) return 1;
     }
-    const bool want_part = !(c->flags & QM2_FLAG_DIRECT) && c->part.levels != 0 &&
+    const bool want_part = !(what & QM2_PREPARE_NO_PART) && !(c->flags & QM2_FLAG_DIRECT) && c->part.levels != 0 &&
                            ((c->flags & QM2_FLAG_PARTITION) || (bb >= (c->span_hi - c->span_lo) / 8 && bb >= (1u << 20)));
     if (want_part) {
-        (void)part_reserve(c, bb + kCarry + 64);           /* (no room: those batches take the direct kernel) */
+        /* (no room: those batches take the direct kernel) */
+        if (part_reserve(c, (what & QM2_PREPARE_FASTQ ? bb / 2 + 64 : bb) + kCarry + 64) && getenv("QM2_TIMING"))
+            printf("QM2 prepare: %s; batches of that size take the direct kernel\n", g_err);
         if (!c->keys_pending && !c->keys_consumed) {
             bool ok = false;
             if (runs_fit(c, &ok)) return 1;
@@ -1167,6 +1175,7 @@ extern "C" int qm2_get_profile(qm2_ctx *c, qm2_profile *p)
     DevStats st;
     HIP_OK(hipMemcpy(&st, c->stats, sizeof st, hipMemcpyDeviceToHost));
     c->prof.fallback_batches = st.fallbacks;
+    c->prof.spilled_kmers = st.spilled;
     *p = c->prof;
     return 0;
 }
@@ -1285,7 +1294,7 @@ extern "C" int qm2_probe_slabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint6
     if (part) {
         c->prof.partitioned_batches++;
         PartSource src;
-        src.slabs = d_slabs; src.slab_cap = slab_cap; src.n_slabs = n_slabs; src.fill = d_fill; src.n_upper = n_upper;
+        src.slabs = d_slabs; src.slab_cap = slab_cap; src.n_slabs = n_slabs; src.fill = d_fill; src.n_upper = n_upper; src.n_bytes = n_upper;
         return launch_partitioned(c, src);
     }
     c->prof.direct_batches++;

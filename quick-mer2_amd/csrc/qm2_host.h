@@ -60,6 +60,8 @@ typedef struct {
  * something it cannot pass on (a line longer than a buffer): nothing is printed, the caller
  * starts over without commit_raw. */
 int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads);
+/* bytes of text per block (= per acquired buffer) when a regular file is read block-wise */
+size_t qm2_reader_block_bytes(void);
 
 /* ---- the command ----------------------------------------------------------- */
 int qm2_main_count(int argc, char **argv);

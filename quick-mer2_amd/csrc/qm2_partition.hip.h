@@ -1029,9 +1029,12 @@ __global__ void part_begin_kernel(DevStats *stats, unsigned long long *spill_cou
     }
 }
 
-__global__ void part_end_kernel(DevStats *stats)
+__global__ void part_end_kernel(DevStats *stats, const unsigned long long *spill_count)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && stats->part_lost != 0) stats->fallbacks++;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (stats->part_lost != 0) stats->fallbacks++;
+        else stats->spilled += *spill_count;
+    }
 }
 
 }  // namespace qm2

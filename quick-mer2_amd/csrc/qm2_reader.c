@@ -38,7 +38,7 @@
 #define QM2_BLOCK   ((size_t)32 << 20)     /* bytes per read(2) block                          */
 #define QM2_RESERVE ((size_t)1 << 20)      /* room in front of a block for the unfinished line
                                               of the block before it                          */
-#define QM2_MAX_WORKERS 16
+#define QM2_MAX_WORKERS 32
 #define QM2_RING_MAX (QM2_MAX_WORKERS + 3)
 
 /* ---- the I/O thread -------------------------------------------------------- */
@@ -191,6 +191,18 @@ static void *strip_main(void *arg)
     }
 }
 
+/* Block size of the regular-file path: 32 MiB; QM2_BLOCK_BYTES (4 KiB .. 32 MiB) makes small test inputs span
+ * several blocks (and several turns of `--devices`). */
+size_t qm2_reader_block_bytes(void)
+{
+    const char *env = getenv("QM2_BLOCK_BYTES");
+    if (env) {
+        const unsigned long long v = strtoull(env, NULL, 10);
+        if (v >= 4096 && v <= QM2_BLOCK) return (size_t)v;
+    }
+    return QM2_BLOCK;
+}
+
 static size_t count_newlines(const char *p, size_t n)
 {
     size_t c = 0, i = 0;
@@ -220,6 +232,7 @@ static size_t count_newlines(const char *p, size_t n)
  * file go through the exact serial state machine. */
 typedef struct pf_shared {
     int     fd;
+    size_t  block;                         /* bytes per block (qm2_reader_block_bytes) */
     size_t  size, start;                   /* start: first byte after the consumed FASTQ header (or 0) */
     size_t  n_blocks;
     int     fastq;
@@ -262,8 +275,8 @@ static ssize_t pread_full(int fd, char *buf, size_t n, size_t off)
 static int pf_load(pf_worker *w)
 {
     pf_shared *sh = w->sh;
-    const size_t s = sh->start + w->block * QM2_BLOCK;
-    size_t e = s + QM2_BLOCK;
+    const size_t s = sh->start + w->block * sh->block;
+    size_t e = s + sh->block;
     if (e > sh->size) e = sh->size;
     const size_t base = w->block ? s - 1 : s;              /* the byte before tells whether a line starts at s */
     if (w->raw_mode) {                                      /* the pinned buffer itself; it cannot grow */
@@ -415,7 +428,8 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
     int rc = 0;
     out_state os = {out, NULL, 0, 0};
     const size_t body = size - sh.start;
-    sh.n_blocks = (body + QM2_BLOCK - 1) / QM2_BLOCK;
+    sh.block = qm2_reader_block_bytes();
+    sh.n_blocks = (body + sh.block - 1) / sh.block;
     sh.lines_before = calloc(sh.n_blocks + 2, sizeof(size_t));
     sh.known = calloc(sh.n_blocks + 2, sizeof(atomic_int));
     pf_worker *ws = calloc((size_t)n_threads, sizeof *ws);

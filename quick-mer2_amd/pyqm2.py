@@ -18,6 +18,7 @@ FLAG_NO_STATS = 0x2
 FLAG_DIRECT = 0x4
 FLAG_PARTITION = 0x8
 FLAG_KEYS_LATER = 0x10
+FLAG_RAW_STRICT = 0x20
 KERNEL_CLASSES = ["count_direct", "split_text", "split_kmer", "bucket_count", "probe", "encode", "lines", "-"]
 
 
@@ -41,7 +42,7 @@ class Profile(C.Structure):
     _fields_ = [("n_launches", C.c_uint64), ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double),
                 ("class_launches", C.c_uint64 * 8), ("class_ms", C.c_double * 8),
                 ("partitioned_batches", C.c_uint64), ("direct_batches", C.c_uint64), ("fallback_batches", C.c_uint64),
-                ("allocations", C.c_uint64)]
+                ("allocations", C.c_uint64), ("spilled_kmers", C.c_uint64)]
 
 
 class Range(C.Structure):
@@ -287,8 +288,9 @@ class Counter:
     def reset(self):
         _check(lib().qm2_reset(self._h), "qm2_reset")
 
-    def prepare(self, batch_bytes=0, host=False, raw=False):
-        _check(lib().qm2_prepare(self._h, int(batch_bytes), (1 if host else 0) | (2 if raw else 0)), "qm2_prepare")
+    def prepare(self, batch_bytes=0, host=False, raw=False, fastq=False, no_part=False):
+        what = (1 if host else 0) | (2 if raw else 0) | (4 if fastq else 0) | (8 if no_part else 0)
+        _check(lib().qm2_prepare(self._h, int(batch_bytes), what), "qm2_prepare")
 
     def flush(self):
         _check(lib().qm2_flush(self._h), "qm2_flush")
@@ -341,7 +343,8 @@ class Counter:
                 "class_launches": {KERNEL_CLASSES[i]: int(p.class_launches[i]) for i in range(7)},
                 "class_ms": {KERNEL_CLASSES[i]: float(p.class_ms[i]) for i in range(7)},
                 "partitioned_batches": int(p.partitioned_batches), "direct_batches": int(p.direct_batches),
-                "fallback_batches": int(p.fallback_batches), "allocations": int(p.allocations)}
+                "fallback_batches": int(p.fallback_batches), "allocations": int(p.allocations),
+                "spilled_kmers": int(p.spilled_kmers)}
 
     @property
     def counters_ptr(self):

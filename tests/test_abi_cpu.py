@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(pkg):
         assert hasattr(L, n), n
     assert sorted(pkg.pyqm2.ABI_SYMBOLS) == declared("qm2.h")
     assert sorted(pkg.pyqm2.TOOL_SYMBOLS) == declared("qm2_tools.h")
-    assert L.qm2_abi_version() == 2
+    assert L.qm2_abi_version() == 3
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "quick-mer2_amd", "libqm2_hip.so")],
                          stdout=subprocess.PIPE, check=True).stdout.decode()
     exported = set(re.findall(r" T (qm2t?_[a-z_0-9]+)", out))
@@ -199,7 +199,7 @@ int main(int argc, char **argv) {
   int n = atoi(argv[2]); size_t turn = (size_t)atol(argv[3]); Sink S[8]; qm2_sink sinks[8]; char name[512];
   LOG = fopen(argv[4], "w");
   for (int i = 0; i < n; i++) { snprintf(name, sizeof name, "%s.%d", argv[4], i); S[i].id = i; S[i].f = fopen(name, "wb"); S[i].lent = S[i].flushes = S[i].bytes = 0;
-    sinks[i].acquire = acq; sinks[i].commit = com; sinks[i].submit = sub; sinks[i].flush = flu; sinks[i].user = &S[i]; }
+    sinks[i].acquire = acq; sinks[i].commit = com; sinks[i].submit = sub; sinks[i].flush = flu; sinks[i].user = &S[i]; sinks[i].commit_raw = NULL; }
   qm2_dispatch *d = qm2_dispatch_new(sinks, n, turn);
   qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, d, NULL};
   int rc = qm2_stream_reads(argv[1], &out, atoi(argv[5]));
@@ -234,3 +234,88 @@ int main(int argc, char **argv) {
                     share += int(e[1])
         else:
             assert len(parts[0]) == len(exp) or n_sinks > 1
+
+
+def test_dispatcher_deals_raw_blocks_in_consecutive_turns(tmp_path):
+    """`--devices` with the line discipline on the devices: the reader's raw blocks go to the sinks in turns of a fixed
+    number of BLOCKS, decided when a buffer is acquired; a sink is flushed behind the last block of its turn.  What a
+    device then does with a batch — number its lines from the state at its first block on — must give exactly the
+    reader's sequence lines: restated here per batch (FASTQ: line L is a sequence line iff L >= skip and (L - skip) % 4
+    == 0, QuicKmer.c:451-455; FASTA: iff it does not start with '>', :398) and compared with the oracle's strip."""
+    src = os.path.join(ROOT, "quick-mer2_amd", "csrc")
+    harness = tmp_path / "r.c"
+    harness.write_text('''
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "qm2_dispatch.h"
+#include "qm2_host.h"
+typedef struct { int id; long lent; } Sink;
+static FILE *LOG, *DATA;
+static int acq(void *u, char **b, size_t *c) { Sink *s = u; *c = 1 << 20; *b = malloc(*c + 8); memcpy(*b, &s->id, sizeof s->id); *b += 8; s->lent++; return 0; }
+static int own(Sink *s, char *b) { int id; memcpy(&id, b - 8, sizeof id); if (id != s->id) { puts("commit to the wrong sink"); return 1; } return 0; }
+static int com(void *u, char *b, size_t n) { Sink *s = u; if (own(s, b)) return 1; if (n) { puts("stripped lines in raw mode"); return 1; } s->lent--; free(b - 8); return 0; }
+static int raw(void *u, char *b, size_t off, size_t n, int fastq, unsigned skip) { Sink *s = u; if (own(s, b)) return 1;
+  fprintf(LOG, "%d block %ld %zu %d %u\\n", s->id, ftell(DATA), n, fastq, skip); fwrite(b + off, 1, n, DATA); s->lent--; free(b - 8); return 0; }
+static int sub(void *u, const char *p, size_t n) { (void)u; (void)p; (void)n; puts("submit in raw mode"); return 1; }
+static int flu(void *u) { Sink *s = u; fprintf(LOG, "%d flush\\n", s->id); return 0; }
+int main(int argc, char **argv) {
+  int n = atoi(argv[2]); Sink S[8]; qm2_sink sinks[8]; char name[512];
+  LOG = fopen(argv[4], "w"); snprintf(name, sizeof name, "%s.data", argv[4]); DATA = fopen(name, "wb");
+  for (int i = 0; i < n; i++) { S[i].id = i; S[i].lent = 0;
+    sinks[i].acquire = acq; sinks[i].commit = com; sinks[i].submit = sub; sinks[i].flush = flu; sinks[i].user = &S[i]; sinks[i].commit_raw = raw; }
+  qm2_dispatch *d = qm2_dispatch_new(sinks, n, 1);
+  qm2_dispatch_raw_turn(d, (size_t)atol(argv[3]));
+  qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, d, qm2_dispatch_commit_raw};
+  int rc = qm2_stream_reads(argv[1], &out, atoi(argv[5]));
+  qm2_dispatch_free(d);
+  for (int i = 0; i < n; i++) if (S[i].lent) rc = 3;
+  fclose(LOG); fclose(DATA); return rc; }
+''')
+    exe = str(tmp_path / "r")
+    subprocess.run(["gcc", "-O1", "-pthread", "-I", src, "-o", exe, str(harness), os.path.join(src, "qm2_reader.c"),
+                    os.path.join(src, "qm2_dispatch.c")], check=True)
+    import oracle_lib as ol
+    import synth
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    for path in (rfq, rfa):
+        exp = ol.strip_reads(path)
+        whole = open(path, "rb").read()
+        for n_sinks, per_turn, thr, block in ((2, 3, 2, 8192), (3, 1, 4, 4096), (4, 5, 3, 20000), (1, 2, 1, 8192)):
+            log = str(tmp_path / "rlog")
+            subprocess.run([exe, path, str(n_sinks), str(per_turn), log, str(thr)], check=True,
+                           env=dict(os.environ, QM2_BLOCK_BYTES=str(block)))
+            data = open(log + ".data", "rb").read()
+            events = [l.split() for l in open(log).read().splitlines()]
+            blocks = [e for e in events if e[1] == "block"]
+            # the blocks, in commit order, are the file's text (minus the FASTQ header line the reader consumed)
+            assert data == (whole[whole.index(b"\n") + 1:] if whole[:1] == b"@" else whole)
+            # block j belongs to sink (j // per_turn) % n; a flush of that sink follows the last block of every full turn
+            got, pending, j = [], {}, 0
+            for e in events:
+                sink = int(e[0])
+                if e[1] == "block":
+                    assert sink == (j // per_turn) % n_sinks
+                    at, n, fastq, skip = int(e[2]), int(e[3]), int(e[4]), int(e[5])
+                    if n and sink not in pending:
+                        pending[sink] = [at, at, fastq, skip]           # a batch opens with the state of its first block
+                    if n:
+                        assert pending[sink][1] == at                    # ... and holds consecutive text
+                        pending[sink][1] = at + n
+                    j += 1
+                else:
+                    assert n_sinks > 1 and j % per_turn == 0 and sink == ((j - 1) // per_turn) % n_sinks
+                    if sink in pending:
+                        got.append(pending.pop(sink))
+            got += list(pending.values())
+            lines = []
+            for lo, hi, fastq, skip in got:                               # what a device makes of each batch
+                for L, line in enumerate(data[lo:hi].split(b"\n")[:-1]):
+                    if fastq:
+                        if L >= skip and (L - skip) % 4 == 0:
+                            lines.append(line)
+                    elif not line.startswith(b">"):
+                        lines.append(line)
+            assert sorted(lines) == sorted(exp.split(b"\n")[:-1])
+            if n_sinks > 1:
+                assert len({(k // per_turn) % n_sinks for k in range(j)}) == min(n_sinks, (j + per_turn - 1) // per_turn)

@@ -174,20 +174,71 @@ def test_cli_mini_fasta_fastq_and_pipe(tmp_path):
 
 def test_cli_devices_two_contexts_sum_to_the_reference(tmp_path):
     """`quicKmer2 count --devices 0,0`: two replicas of the dictionary (here on the one GPU of the box), one
-    reader, the reads dealt to the two contexts in turns (small ones, so that both really count), the
-    counters summed into the first before the epilogue: .bin / .txt are the reference's own, stdout too."""
+    reader, the input dealt to the contexts in turns (small ones, so that all of them really count), the
+    counters summed into the first before the epilogue: .bin / .txt are the reference's own, stdout too.
+    Regular files go to the contexts as RAW blocks (line discipline on the devices, turns of consecutive blocks);
+    `-t 0` and QM2_READER_RAW=0 strip on the host and deal bytes."""
     m = MAN["sets"]["mini"]
     fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
     ref_prefix = os.path.join(GOLD, "mini", "ref.fa")
-    for tag, reads, devs, thr in (("fa", rfa, "0,0", "2"), ("fq", rfq, "0,0,0", "0"), ("one", rfq, "0", "4")):
+    small = dict(os.environ, QM2_TURN_BYTES="100000", QM2_BLOCK_BYTES="16384", QM2_TURN_BLOCKS="3", QM2_TIMING="1")
+    for tag, reads, devs, thr, env in (("fa", rfa, "0,0", "2", small), ("fq", rfq, "0,0,0", "0", small), ("one", rfq, "0", "4", small),
+                                       ("fq_raw", rfq, "0,0,0", "3", small), ("fq_host", rfq, "0,0", "3", dict(small, QM2_READER_RAW="0")),
+                                       ("fq_default_turns", rfq, "0,0", "2", dict(os.environ, QM2_TIMING="1"))):
         out = str(tmp_path / tag)
         r = subprocess.run([CLI, "count", "-t", thr, "--devices", devs, ref_prefix, reads, out], stdout=subprocess.PIPE,
-                           timeout=300, env=dict(os.environ, QM2_TURN_BYTES="100000"))
+                           timeout=300, env=env)
         assert r.returncode == 0, r.stdout
         assert md5_file(out + ".bin") == m["bin_md5"] and md5_file(out + ".txt") == m["txt_md5"]
         text = r.stdout.decode()
         assert ("total %d kmers" % m["n_kmers"]) in text and text.count("Read 0x") == 1
+        assert "raw input refused" not in text
         assert text.rstrip().endswith("Exit quicK-mer2 count")
+    # a '>' line at a FASTQ sequence position (QuicKmer.c:398: skipped WITHOUT the three discards) shifts every later
+    # sequence line of the text; a replica that did not see that batch cannot know, so the contexts refuse it
+    # (QM2_FLAG_RAW_STRICT) and the CLI goes round again through the host line discipline: still the reference's counts
+    ref = synth.kat_reference().tobytes()
+    recs = [b"@r%d\n" % i + (b">oops\n" if i == 900 else b"") + ref[i:i + 120] + b"\n+\n" + b"I" * 120 + b"\n" for i in range(3000)]
+    p = tmp_path / "desync.fq"
+    p.write_bytes(b"".join(recs))
+    out = str(tmp_path / "desync")
+    r = subprocess.run([CLI, "count", "-t", "3", "--devices", "0,0", os.path.join(GOLD, "kat", "ref.fa"), str(p), out], env=small,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout
+    assert b"raw input refused" in r.stdout
+    exp_depth, exp_st = ol.count_lines(kat_qm()["keys"], 30, ol.strip_reads(str(p)))
+    assert ("total %d kmers" % exp_st["n_kmers"]).encode() in r.stdout
+    assert open(out + ".bin", "rb").read() == exp_depth[ol.chain_order(kat_qm())].astype("<u2").tobytes()
+    # bad ordinals are refused, not read as device 0
+    for devs in ("0,x", "-1", "0,,1x"):
+        r = subprocess.run([CLI, "count", "--devices", devs, ref_prefix, rfq, str(tmp_path / "bad")], stdout=subprocess.PIPE, timeout=60)
+        assert r.returncode != 0 and b"not a device ordinal" in r.stdout
+
+
+@pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="needs two GPUs (the peer-copy branch of qm2_merge_counters)")
+def test_cli_devices_on_two_physical_gpus(qm2, tmp_path):
+    """The cross-device paths (never run before round 3: every lease so far had one GPU): `--devices 0,1` — a replica
+    per GPU, raw blocks in turns, qm2_merge_counters through hipMemcpyPeerAsync — against the reference's vectors,
+    and the merge called directly on two contexts of different devices."""
+    m = MAN["sets"]["mini"]
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    ref_prefix = os.path.join(GOLD, "mini", "ref.fa")
+    env = dict(os.environ, QM2_BLOCK_BYTES="16384", QM2_TURN_BLOCKS="3")
+    for tag, reads in (("fa", rfa), ("fq", rfq)):
+        out = str(tmp_path / ("two_" + tag))
+        r = subprocess.run([CLI, "count", "-t", "3", "--devices", "0,1", ref_prefix, reads, out], stdout=subprocess.PIPE, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout
+        assert md5_file(out + ".bin") == m["bin_md5"] and md5_file(out + ".txt") == m["txt_md5"]
+    qm = ol.load_qm(ref_prefix + ".qm")
+    lines = ol.strip_reads(rfq)
+    exp_depth, exp_st = ol.count_lines(qm["keys"], qm["k"], lines)
+    half = lines.rfind(b"\n", 0, len(lines) // 2) + 1
+    with qm2.Counter(qm["keys"], k=qm["k"], device=0) as a, qm2.Counter(qm["keys"], k=qm["k"], device=1) as b:
+        a.submit(lines[:half])
+        b.submit(lines[half:])
+        a.merge_counters(b)
+        depth, _ = a.finish()
+    assert np.array_equal(depth, exp_depth)
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(ol.ORACLE_DIR, "_ref", "quicKmer2")),

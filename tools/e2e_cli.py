@@ -98,12 +98,25 @@ runs = [(f, t, e) for f in ("reads.fq", "reads.fa")
 reps = 4
 if scale == "c3":
     runs, reps = [("reads.fq", "8", {}), ("reads.fq", "12", {})], 2
+# QM2_E2E_RUNS="fq:12,fq:24,fq:12:0+0,fa:8::host": file : threads [: devices joined by '+'] [: host]
+if os.environ.get("QM2_E2E_RUNS"):
+    runs = []
+    for item in os.environ["QM2_E2E_RUNS"].split(","):
+        f = item.split(":") + ["", "", ""]
+        extra = {"QM2_READER_RAW": "0"} if f[3] == "host" else {}
+        if f[2]:
+            extra["_devices"] = f[2].replace("+", ",")
+        runs.append(("reads." + f[0], f[1], extra))
+reps = int(os.environ.get("QM2_E2E_REPS", reps))
 ok = True
 for name, thr, extra in runs:
     best, walls = None, []
+    extra = dict(extra)
+    devs = extra.pop("_devices", None)
     for rep in range(reps):
         t = time.time()
-        r = subprocess.run([cli, "count", "-t", thr, os.path.join(work, "ref.fa"), os.path.join(reads_dir, name), os.path.join(work, "out")],
+        r = subprocess.run([cli, "count", "-t", thr] + (["--devices", devs] if devs else []) +
+                           [os.path.join(work, "ref.fa"), os.path.join(reads_dir, name), os.path.join(work, "out")],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, QM2_TIMING="1", **extra))
         walls.append(time.time() - t)
         out = r.stdout.decode(errors="replace")
@@ -113,12 +126,14 @@ for name, thr, extra in runs:
     nk = re.search(r"total (\d+) kmers", out)
     prog = re.findall(r"^Read (\d+)G kmers$", out, flags=re.M)
     al = re.search(r"allocations inside it: (\d+)", out)
-    good = r.returncode == 0 and nk and [int(x) for x in prog] == list(range(1, (int(nk.group(1)) >> 30) + 1)) and al and int(al.group(1)) == 0
+    good = r.returncode == 0 and nk and [int(x) for x in prog] == list(range(1, (int(nk.group(1)) >> 30) + 1)) and ((al and int(al.group(1)) == 0) or devs)
+    load = re.search(r"QM2 phase load-dictionary.*", out)
     ok = ok and bool(good)
-    print("== %s -t %s %s rc=%d  count phase best: %.3f s = %.2f G bases/s; wall best %.2f s (incl. .qm load, upload, epilogue); "
-          "progress lines %d, allocations in the count phase %s%s" %
-          (name, thr, "host strip, read(2) stream" if "QM2_READER_STREAM" in extra else "host strip, pread blocks" if extra else "device line discipline",
-           r.returncode, best, n_reads * 150 / best / 1e9, min(walls), len(prog), al.group(1) if al else "?", "" if good else "  <-- CHECK FAILED"), flush=True)
+    print("== %s -t %s %s%s rc=%d  count phase best: %.3f s = %.2f G bases/s; wall best %.2f s (incl. .qm load, upload, epilogue); "
+          "progress lines %d, allocations in the count phase %s%s | %s" %
+          (name, thr, ("--devices %s " % devs) if devs else "", "host strip, read(2) stream" if "QM2_READER_STREAM" in extra else "host strip, pread blocks" if extra else "device line discipline",
+           r.returncode, best, n_reads * 150 / best / 1e9, min(walls), len(prog), al.group(1) if al else "?", "" if good else "  <-- CHECK FAILED",
+           load.group(0) if load else ""), flush=True)
 print(out)
 for d_ in {work, reads_dir}:
     shutil.rmtree(d_, ignore_errors=True)
