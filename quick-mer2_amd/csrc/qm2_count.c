@@ -249,8 +249,10 @@ int qm2_main_count(int argc, char **argv)
     const char *ref_prefix = argv[argc - 3], *reads = argv[argc - 2], *out_prefix = argv[argc - 1];
     /* -t sized the reference's probing workers (:372-384); those are GPU waves now.  Here it sizes
      * the host threads that strip FASTA/FASTQ blocks into pinned staging (default 4). */
-    /* default: 8 where the machine has the cores (FASTQ: 4.7 -> 6.0 G bases/s measured), else 4 */
-    int n_strip = getopt_seen_t ? (int)thread_count : (sysconf(_SC_NPROCESSORS_ONLN) >= 16 ? 8 : 4);
+    /* default: 16 where the machine has the cores, else 8 or 4 */
+    /* (hg38 scale, 30.7 GB of FASTQ from /dev/shm, 256-thread host: -t 12 / 16 / 24 / 32 -> 12.6 / 20.8 / 19.2 / 16.4 G bases/s) */
+    const long cores = sysconf(_SC_NPROCESSORS_ONLN);
+    int n_strip = getopt_seen_t ? (int)thread_count : (cores >= 32 ? 16 : cores >= 16 ? 8 : 4);
     if (n_strip > 32) n_strip = 32;
 
     const int timing = getenv("QM2_TIMING") != NULL;   /* extra phase lines; off by default so that

@@ -70,5 +70,20 @@ def test_without_control_bed_and_refusals(tmp_path):
     assert not os.path.exists(str(tmp_path / "ref.fa.qgc"))           # no -c: no .qgc (QuicKmer.c:1276-1279)
     r = subprocess.run([EXE, "-s", "16K", "-e", "2", str(tmp_path / "ref.fa")], stdout=subprocess.PIPE)
     assert r.returncode != 0 and b"only -e 0" in r.stdout
-    r = subprocess.run([EXE, "-s", "4K", "-e", "0", str(tmp_path / "ref.fa")], stdout=subprocess.PIPE)
-    assert r.returncode != 0 and b"larger -s" in r.stdout            # the reference would grow the table
+
+
+@pytest.mark.parametrize("size", ["64K", "16K"])
+def test_table_grows_like_the_reference(size, tmp_path):
+    """A table that passes 80 % fill is doubled and re-placed in place (QuicKmer.c:891-895, Resize_hash_table
+    :738-779): -s 64K on the mini reference doubles once, -s 16K three times; .qm / .qgc / .bed must be the bytes
+    the real reference wrote (tests/golden/growth_manifest.json, made by make_growth_golden.py) — the order of the
+    re-placement decides where colliding keys end up, so this pins it."""
+    g = json.load(open(os.path.join(GOLD, "growth_manifest.json")))["cases"][size]
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    out = subprocess.run([EXE, "-k", "30", "-s", size, "-e", "0", "-w", "1000", "-c", ctrl, fa], check=True,
+                         stdout=subprocess.PIPE).stdout.decode()
+    assert out.count("Resize ") == g["resizes"] and out.count("Allocation success") == g["resizes"]
+    assert os.path.getsize(fa + ".qm") == g["qm_bytes"]
+    assert md5_file(fa + ".qm") == g["qm_md5"]
+    assert md5_file(fa + ".qgc") == g["qgc_md5"]
+    assert md5_file(fa + ".bed") == g["bed_md5"]

@@ -18,8 +18,10 @@
  *   pass 2  dump_kmer_list :925-1073      genome-order chain, GC/control word per k-mer
  *                                         (.qgc), window table (.bed)
  *   write   main_search :1284-1299
- * Not supported (the reference would): edit-distance filtering (-e 1/2), growing
- * the table when it passes 80 % fill (:891-895) — give a large enough -s.
+ *   grow    hash_from_fasta :891-895,     a table that passes 80 % fill at the end of a FASTA line is doubled and
+ *           Resize_hash_table :738-779    re-placed in place, upper half of the old table first (downwards), then the
+ *                                         lower half (upwards): the order decides where colliding keys end up
+ * Not supported (the reference would): edit-distance filtering (-e 1/2).
  *
  * usage: qm2-mkdict [-k K] [-s SIZE[K|M|G]] [-w W] [-d D] [-c ctrl.bed] ref.fa
  */
@@ -69,10 +71,48 @@ static inline uint64_t roll_push(roll *r, unsigned char c)
     return r->run == g_k ? km : 0;
 }
 
+/* ---- growth (:738-779) ------------------------------------------------------ */
+
+/* Double the table and re-place every key under the new size, in the reference's order.  A key moves only if
+ * its walk in the doubled table does not end on itself (Find_hash returns the slot of the key or of the first
+ * empty slot on the way, :90-99); its occurrence count moves with it.  The reference leaves the new half of
+ * Kmer_occr to realloc (:749): fresh pages, i.e. zeros, stated here. */
+static int grow(uint8_t **occ_p)
+{
+    const uint64_t old = g_H, nw = old << 1;
+    printf("Resize %f\n", (float)nw / old);                        /* :739 */
+    if (nw > ((uint64_t)1 << 32)) { puts("hash size above 2^32 does not fit the uint32 chain"); return 1; }
+    uint64_t *nk = realloc(g_keys, nw * sizeof(uint64_t));
+    if (!nk) { puts("Realloc failed!\n"); return 1; }
+    g_keys = nk;
+    uint8_t *no = realloc(*occ_p, nw);
+    if (!no) { puts("Realloc failed!\n"); return 1; }
+    *occ_p = no;
+    puts("Allocation success");
+    memset(g_keys + old, 0, sizeof(uint64_t) * (nw - old));        /* :755 */
+    memset(no + old, 0, nw - old);
+    g_H = nw;
+    for (uint64_t index = old - 1; index >= (old >> 1); index--) {   /* :757-771 */
+        if (g_keys[index]) {
+            const uint64_t to = find_slot(g_keys[index], NULL);
+            if (to != index) { g_keys[to] = g_keys[index]; g_keys[index] = 0; no[to] = no[index]; no[index] = 0; }
+        }
+        if (index == 0) break;                                     /* (old = 1 cannot happen: H >= 2) */
+    }
+    for (uint64_t index = 0; index < (old >> 1); index++) {        /* :772-786 */
+        if (g_keys[index]) {
+            const uint64_t to = find_slot(g_keys[index], NULL);
+            if (to != index) { g_keys[to] = g_keys[index]; g_keys[index] = 0; no[to] = no[index]; no[index] = 0; }
+        }
+    }
+    return 0;
+}
+
 /* ---- pass 1 --------------------------------------------------------------- */
 
-static int pass1(FILE *fa, uint8_t *occ)
+static int pass1(FILE *fa, uint8_t **occ_p)
 {
+    uint8_t *occ = *occ_p;
     char line[200];
     roll r;
     roll_reset(&r);
@@ -103,9 +143,10 @@ static int pass1(FILE *fa, uint8_t *occ)
             }
             if (occ[i] < 255) occ[i]++;                            /* :888 */
         }
-        if ((double)distinct > 0.8 * (double)g_H) {                /* :891 — the reference doubles the table here */
-            puts("Table passed 80% fill: give a larger -s (this writer does not resize)");
-            return 1;
+        if ((double)distinct > 0.8 * (double)g_H) {                /* :891-895 */
+            if (grow(occ_p)) return 1;
+            occ = *occ_p;
+            hist_n = 0; hist_sum = 0; worst = 0;
         }
     }
     printf("Average %f, fill %f%% \n", hist_n ? hist_sum / (double)hist_n : 0.0, ((float)distinct * 100) / g_H);
@@ -357,7 +398,7 @@ int main(int argc, char **argv)
     if (!bed) { puts("Window creation failed"); return 1; }
     FILE *fa = fopen(ref, "r");
     if (!fa) { puts("Input open fail"); return 1; }
-    if (pass1(fa, occ)) return 1;
+    if (pass1(fa, &occ)) return 1;
     prune_and_rehash(occ);
     free(occ);
     FILE *qgc = NULL;
