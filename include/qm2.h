@@ -183,8 +183,10 @@ int qm2_submit_device(qm2_ctx *c, const void *d_seq_bytes, size_t n,
 
 /* Launch the batch that is being filled (qm2_submit / qm2_staging_commit*) without waiting for it: a
  * caller that feeds several contexts in turns (quicKmer2 count --devices) hands a context its share
- * and moves on.  qm2_merge_counters adds the counters of `src` — a replica of the same table, on the
- * same or on another device — into `dst` (both are synchronised first; src keeps its own counts). */
+ * and moves on.  qm2_merge_counters adds the counters of `src` — a replica of the same table, or a
+ * hash-range shard whose span lies inside dst's (its own slots and the overhang past its middle-facing
+ * edge alike: slot for slot), on the same or on another device — into `dst` (both are synchronised first;
+ * src keeps its own counts). */
 int qm2_flush(qm2_ctx *c);
 int qm2_merge_counters(qm2_ctx *dst, qm2_ctx *src);
 

@@ -5,8 +5,10 @@
  * the end (:335, :338, :342), same stdout lines, same output files.
  */
 #define _GNU_SOURCE
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <getopt.h>
+#include <libgen.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,6 +16,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include "../../include/qm2_shards.h"
 #include "qm2_dispatch.h"
 #include "qm2_host.h"
 
@@ -26,6 +29,8 @@ static void help_count(void)
     puts("-t [num]\tNumber of threads");
     puts("--devices a,b,..\tGPUs to count on (a replica of the dictionary on each, the reads dealt to them a device");
     puts("\t\tbatch at a time, the counts summed on the first); default: the current device");
+    puts("--shards a,b,..\tGPUs (a power of two of them) that each hold a hash range of the dictionary; the k-mers");
+    puts("\t\tof every batch are routed to their owners by RCCL (needs libqm2_shards.so beside this binary)");
 }
 
 /* The reference prints `Read %liG kmers` whenever its k-mer count reaches a multiple of 2^30 (:446).
@@ -208,6 +213,81 @@ static int count_on_devices(qm2_dict_file *d, const char *reads, int n_strip, co
     return rc;
 }
 
+/* --shards a,b,...: BASELINE config 4 (include/qm2_shards.h).  The driver lives in libqm2_shards.so, which brings
+ * RCCL with it: loaded here, on demand, so that nothing else of the CLI depends on it. */
+typedef struct {
+    void *lib;
+    int (*open)(qm2_shards **, int, uint64_t, uint32_t, const int *, int, uint64_t, uint32_t);
+    int (*acquire)(qm2_shards *, char **, size_t *);
+    int (*commit)(qm2_shards *, char *, size_t);
+    int (*submit)(qm2_shards *, const char *, size_t);
+    int (*finish)(qm2_shards *, qm2_stats *);
+    qm2_ctx *(*result)(qm2_shards *);
+    int (*get_info)(qm2_shards *, qm2_shards_info *);
+    void (*close)(qm2_shards *);
+} shards_api;
+
+static int shards_load(shards_api *a)
+{
+    char exe[4096], path[4200];
+    ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+    if (n <= 0) { puts("Cannot locate libqm2_shards.so"); return 1; }
+    exe[n] = 0;
+    snprintf(path, sizeof path, "%s/libqm2_shards.so", dirname(exe));
+    a->lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!a->lib) { printf("Cannot load %s: %s\n", path, dlerror()); return 1; }
+#define SHARDS_SYM(field, name) do { *(void **)&a->field = dlsym(a->lib, name); if (!a->field) { printf("%s lacks %s\n", path, name); return 1; } } while (0)
+    SHARDS_SYM(open, "qm2_shards_open"); SHARDS_SYM(acquire, "qm2_shards_acquire"); SHARDS_SYM(commit, "qm2_shards_commit");
+    SHARDS_SYM(submit, "qm2_shards_submit"); SHARDS_SYM(finish, "qm2_shards_finish"); SHARDS_SYM(result, "qm2_shards_result");
+    SHARDS_SYM(get_info, "qm2_shards_get_info"); SHARDS_SYM(close, "qm2_shards_close");
+#undef SHARDS_SYM
+    return 0;
+}
+
+static shards_api g_shards;
+static int sh_acquire(void *u, char **b, size_t *c) { return g_shards.acquire((qm2_shards *)u, b, c); }
+static int sh_commit(void *u, char *b, size_t n) { return g_shards.commit((qm2_shards *)u, b, n); }
+static int sh_submit(void *u, const char *p, size_t n) { return g_shards.submit((qm2_shards *)u, p, n); }
+
+static int count_on_shards(qm2_dict_file *d, const char *reads, int n_strip, const int *devices, int n_dev,
+                           const char *ref_prefix, const char *out_prefix, int timing)
+{
+    if (shards_load(&g_shards)) return 1;
+    struct timespec ta, tb, tc;
+    clock_gettime(CLOCK_MONOTONIC, &ta);
+    qm2_shards *S = NULL;
+    const char *bb_env = getenv("QM2_SHARDS_BATCH_BYTES");            /* (tests: small rounds on small inputs) */
+    int rc = g_shards.open(&S, fileno(d->fp), d->hash_size, d->k, devices, n_dev, bb_env ? strtoull(bb_env, NULL, 10) : 0,
+                           (uint32_t)n_strip + 3);
+    if (!rc) printf("Read 0x%lX hash\n", (unsigned long)d->hash_size);           /* :359 */
+    clock_gettime(CLOCK_MONOTONIC, &tb);
+    if (timing && !rc) printf("QM2 phase load-dictionary %.3f s (file -> %d hash-range shards)\n", (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec), n_dev);
+    qm2_stats st;
+    memset(&st, 0, sizeof st);
+    if (!rc) {
+        qm2_lines_out out = {sh_acquire, sh_commit, sh_submit, S, NULL};       /* sequence lines: the host line discipline */
+        rc = qm2_stream_reads(reads, &out, n_strip);
+        if (!rc) rc = g_shards.finish(S, &st);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &tc);
+    if (!rc) {
+        progress_printed_g = 0;
+        progress_upto(st.n_kmers);
+        printf("Counting elapse %u sec, total %lu kmers\n", (unsigned)(tc.tv_sec - tb.tv_sec), (unsigned long)st.n_kmers);   /* :481 */
+        if (timing) {
+            qm2_shards_info info;
+            memset(&info, 0, sizeof info);
+            (void)g_shards.get_info(S, &info);
+            const double sec = (tc.tv_sec - tb.tv_sec) + 1e-9 * (tc.tv_nsec - tb.tv_nsec);
+            printf("QM2 phase count %.3f s (%.2f G bases/s) on %d hash-range shards: %llu rounds, %llu cut and routed again, %.2f GB exchanged\n",
+                   sec, st.n_bases / sec / 1e9, n_dev, (unsigned long long)info.rounds, (unsigned long long)info.rerouted, info.exchanged_bytes / 1e9);
+        }
+        rc = qm2_write_outputs(d, g_shards.result(S), ref_prefix, out_prefix);
+    }
+    if (S) g_shards.close(S);
+    return rc;
+}
+
 int qm2_main_count(int argc, char **argv)
 {
     unsigned thread_count = 0;
@@ -216,9 +296,11 @@ int qm2_main_count(int argc, char **argv)
     int opt;
     optind = 1;
     int devices[QM2_MAX_DEVICES], n_dev = 0;
-    static const struct option long_opts[] = {{"devices", required_argument, NULL, 'D'}, {NULL, 0, NULL, 0}};
+    int shards = 0;
+    static const struct option long_opts[] = {{"devices", required_argument, NULL, 'D'}, {"shards", required_argument, NULL, 'S'}, {NULL, 0, NULL, 0}};
     while ((opt = getopt_long(argc, argv, "ht:", long_opts, NULL)) != -1) {        /* :314 (+ --devices) */
         switch (opt) {
+        case 'S': shards = 1; /* fall through */
         case 'D':
             for (char *tok = strtok(optarg, ","); tok; tok = strtok(NULL, ",")) {
                 if (n_dev == QM2_MAX_DEVICES) { printf("At most %d devices\n", QM2_MAX_DEVICES); return 1; }
@@ -226,7 +308,7 @@ int qm2_main_count(int argc, char **argv)
                 const long v = strtol(tok, &end, 10);
                 if (end == tok || *end != '\0' || v < 0 || v > 1023) {
                     /* (an ordinal the machine does not have is refused by qm2_open: "device N out of range") */
-                    printf("--devices: '%s' is not a device ordinal\n", tok);
+                    printf("--devices / --shards: '%s' is not a device ordinal\n", tok);
                     return 1;
                 }
                 devices[n_dev++] = (int)v;
@@ -268,6 +350,13 @@ int qm2_main_count(int argc, char **argv)
     /* (the reference's Kmer_hash and Kmer_depth, :353 and :360, live on the device: qm2_open allocates
      * both and zeroes the counters; the keys are streamed from the file, never held on the host) */
     qm2_ctx *ctx = NULL;
+    if (shards) {
+        const int rc = count_on_shards(&d, reads, n_strip, devices, n_dev, ref_prefix, out_prefix, timing);
+        qm2_dict_close(&d);
+        if (rc) return 1;
+        puts("Exit quicK-mer2 count");                        /* :543 */
+        return 0;
+    }
     if (n_dev > 1) {
         qm2_ctx *ctxs[QM2_MAX_DEVICES] = {NULL};
         qm2_stats st;

@@ -1059,13 +1059,17 @@ __global__ void add_counters_kernel(uint32_t *dst, const uint32_t *src, uint64_t
 extern "C" int qm2_merge_counters(qm2_ctx *dst, qm2_ctx *src)
 {
     if (!dst || !src || dst == src) return fail("qm2_merge_counters: two different contexts needed");
-    if (dst->H != src->H || dst->span_lo != src->span_lo || dst->span_hi != src->span_hi)
-        return fail("qm2_merge_counters: the contexts hold different tables");
+    /* replicas hold the same span; a hash-range shard's span (its own slots plus the overhang past its
+     * middle-facing edge) lies inside the whole table its counts are folded into */
+    if (dst->H != src->H || src->span_lo < dst->span_lo || src->span_hi > dst->span_hi)
+        return fail("qm2_merge_counters: the source's slots are not part of the destination's table");
     if (qm2_sync(src) || qm2_sync(dst)) return 1;
-    const uint64_t n = dst->span_hi - dst->span_lo;
+    if (use_device(dst)) return 1;
+    const uint64_t n = src->span_hi - src->span_lo;
+    uint32_t *const into = dst->counters + (src->span_lo - dst->span_lo);
     const int grid = dst->n_cu * 8;
     if (dst->device == src->device) {
-        hipLaunchKernelGGL(add_counters_kernel, dim3(grid), dim3(256), 0, dst->stream, dst->counters, src->counters, n);
+        hipLaunchKernelGGL(add_counters_kernel, dim3(grid), dim3(256), 0, dst->stream, into, src->counters, n);
         HIP_OK(hipGetLastError());
     } else {
         /* a piece at a time through a scratch buffer on the destination (peer access need not be enabled) */
@@ -1077,7 +1081,7 @@ extern "C" int qm2_merge_counters(qm2_ctx *dst, qm2_ctx *src)
             const uint64_t m = std::min(piece, n - at);
             e = hipMemcpyPeerAsync(scratch, dst->device, src->counters + at, src->device, m * sizeof(uint32_t), dst->stream);
             if (e != hipSuccess) break;
-            hipLaunchKernelGGL(add_counters_kernel, dim3(grid), dim3(256), 0, dst->stream, dst->counters + at, scratch, m);
+            hipLaunchKernelGGL(add_counters_kernel, dim3(grid), dim3(256), 0, dst->stream, into + at, scratch, m);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(dst->stream);

@@ -126,7 +126,9 @@ struct SplitLds {
     uint64_t sorted[kSplitSlots + 1];       /* the chunk sorted by child; last = trash slot          */
     uint32_t hist[kMaxFan + 1];             /* [kMaxFan] = trash bin of the empty slots (keeps the
                                                rank atomics and the scatter branch-free)             */
-    uint16_t off[kMaxFan];                  /* exclusive prefix of hist (< 2^16: a chunk has <= 16 K k-mers) */
+    uint16_t off[kMaxFan + 2];              /* exclusive prefix of hist (< 2^16: a chunk has <= 16 K k-mers); [kMaxFan] = the
+                                               chunk's total: the empty slots scatter behind the real k-mers, where the
+                                               copy-out never looks (total + empty slots = kSplitSlots exactly) */
     uint2    dl[kMaxFan];                   /* copy-out of the sorted chunk: element i of child c goes
                                                to slot i + dl.x of the child's region if i < dl.y
                                                (dl.x = reserved start - off, dl.y = off + what fits)  */
@@ -214,14 +216,13 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
             }
         }
         const uint32_t tot = __shfl(ws, kMaxFan / kWave - 1);
-        if (tid == 0) L.total = tot;
+        if (tid == 0) { L.total = tot; L.off[kMaxFan] = (uint16_t)tot; }
     }
     lds_barrier();
 #pragma unroll
     for (int j = 0; j < kKpt; j++) {
-        /* empty slots carry child id kMaxFan: they all land in the trash slot, no branch */
-        const uint32_t child = tag[j] >> 16;
-        const uint32_t pos = child >= kMaxFan ? (uint32_t)kSplitSlots : (uint32_t)L.off[child & (kMaxFan - 1)] + (tag[j] & 0xFFFFu);
+        /* empty slots carry child id kMaxFan: they land behind the chunk's last k-mer, no branch */
+        const uint32_t pos = (uint32_t)L.off[tag[j] >> 16] + (tag[j] & 0xFFFFu);
         L.sorted[pos] = km[j];
     }
     uint32_t f[C];
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
             const uint64_t out = pend ? copy_fetch<J>(L) : 0;    /* (its LDS latency hides behind the k-mer's own work) */ \
             km[J] = kmer_at<K30, J>(W, k);                                         \
             const uint32_t b = (W.emit & (0x8000u >> J)) ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
-            tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
+            tag[J] = (b << 16) | atomicAdd(&L.hist[b], 1u);      /* (a count: < 2^15) */ \
             if (pend) copy_store<J, SEG>(L, out, d, child0, shift, bits);          \
         }
         QM2_T(0) QM2_T(1) QM2_T(2) QM2_T(3) QM2_T(4) QM2_T(5) QM2_T(6) QM2_T(7)
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
         {                                                                          \
             const uint64_t out = pend ? copy_fetch<J>(L) : 0;                      \
             const uint32_t b = km[J] != kPad ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
-            tag[J] = (b << 16) | (atomicAdd(&L.hist[b], 1u) & 0xFFFFu);            \
+            tag[J] = (b << 16) | atomicAdd(&L.hist[b], 1u);      /* (a count: < 2^15) */ \
             if (pend) copy_store<J, DST_SEG>(L, out, d, child0, shift, bits);      \
         }
         QM2_K(0) QM2_K(1) QM2_K(2) QM2_K(3) QM2_K(4) QM2_K(5) QM2_K(6) QM2_K(7)

@@ -215,6 +215,74 @@ def test_cli_devices_two_contexts_sum_to_the_reference(tmp_path):
         assert r.returncode != 0 and b"not a device ordinal" in r.stdout
 
 
+def test_cli_shards_config4_from_the_c_host(tmp_path):
+    """`quicKmer2 count --shards ...` (include/qm2_shards.h, libqm2_shards.so: hash-range shards, route -> exchange ->
+    probe of the own span, fold into one table, epilogue) against the reference's vectors.  One rank runs the real path
+    end to end (nothing to exchange).  Two and four LOGICAL ranks on the one GPU run everything but RCCL itself:
+    QM2_SHARDS_FAKE_EXCHANGE=1 replaces the ncclSend / ncclRecv pairs by device-to-device copies; small rounds so that
+    every rank is fed, poly-A reads so that a round overflows an owner's slabs and is cut and routed again."""
+    m = MAN["sets"]["mini"]
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    ref_prefix = os.path.join(GOLD, "mini", "ref.fa")
+    fake = dict(os.environ, QM2_SHARDS_FAKE_EXCHANGE="1", QM2_SHARDS_BATCH_BYTES="100000", QM2_TIMING="1")
+    for tag, reads, devs, env in (("one_fa", rfa, "0", dict(os.environ, QM2_TIMING="1")), ("one_fq_small_rounds", rfq, "0", fake),
+                                  ("two", rfq, "0,0", fake), ("four", rfa, "0,0,0,0", fake)):
+        out = str(tmp_path / ("sh_" + tag))
+        r = subprocess.run([CLI, "count", "-t", "3", "--shards", devs, ref_prefix, reads, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           timeout=600, env=env)
+        text = r.stdout.decode(errors="replace")
+        assert r.returncode == 0, text
+        assert md5_file(out + ".bin") == m["bin_md5"] and md5_file(out + ".txt") == m["txt_md5"], tag
+        assert ("total %d kmers" % m["n_kmers"]) in text and text.count("Read 0x") == 1
+        assert text.rstrip().endswith("Exit quicK-mer2 count")
+        if env is fake:
+            rounds = int(text.split(" rounds,")[0].split()[-1])
+            assert rounds >= 2, text                                  # several rounds, every rank fed
+    # every KAT case through four logical shards of the 16 K-slot table (spans of 4 K slots + overhang)
+    for name, c in MAN["sets"]["kat"]["cases"].items():
+        rp = _reads_path("kat", name, str(tmp_path))
+        out = str(tmp_path / ("shk_" + name))
+        r = subprocess.run([CLI, "count", "-t", "2", "--shards", "0,0,0,0", os.path.join(GOLD, "kat", "ref.fa"), rp, out],
+                           env=dict(fake, QM2_SHARDS_BATCH_BYTES="600000"),      # (a staging buffer must hold the longest line: 140 kb here)
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0, (name, r.stdout)
+        assert ("total %d kmers" % c["n_kmers"]).encode() in r.stdout, name
+        assert open(out + ".bin", "rb").read() == open(os.path.join(GOLD, "kat", name + ".bin"), "rb").read(), name
+        assert md5_file(out + ".txt") == c["txt_md5"], name
+    # skew: 4000 poly-A reads in front of the mini reads send whole rounds to the owner of k-mer 0's home slot
+    qm = ol.load_qm(ref_prefix + ".qm")
+    lines = (b"A" * 150 + b"\n") * 4000 + ol.strip_reads(rfq)
+    p = tmp_path / "polya.fa"
+    p.write_bytes(b">r\n" + lines.replace(b"\n", b"\n>r\n")[:-3])
+    exp_depth, exp_st = ol.count_lines(qm["keys"], qm["k"], lines)
+    out = str(tmp_path / "sh_polya")
+    r = subprocess.run([CLI, "count", "-t", "2", "--shards", "0,0,0,0", ref_prefix, str(p), out], env=fake, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    text = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, text
+    assert ("total %d kmers" % exp_st["n_kmers"]) in text
+    assert int(text.split(" cut and routed again")[0].split()[-1]) >= 1, text
+    assert open(out + ".bin", "rb").read() == exp_depth[ol.chain_order(qm)].astype("<u2").tobytes()
+    # the same GPU twice is refused when the exchange is RCCL's
+    r = subprocess.run([CLI, "count", "--shards", "0,0", ref_prefix, rfq, str(tmp_path / "dup")], stdout=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"listed twice" in r.stdout
+
+
+@pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="needs two GPUs: RCCL between two ranks")
+def test_cli_shards_on_two_physical_gpus(tmp_path):
+    """Config 4 over the wire: `--shards 0,1` (ncclSend / ncclRecv between two GPUs) against the reference's vectors."""
+    m = MAN["sets"]["mini"]
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    ref_prefix = os.path.join(GOLD, "mini", "ref.fa")
+    env = dict(os.environ, QM2_SHARDS_BATCH_BYTES="300000", QM2_TIMING="1")
+    for tag, reads in (("fa", rfa), ("fq", rfq)):
+        out = str(tmp_path / ("sh2_" + tag))
+        r = subprocess.run([CLI, "count", "-t", "3", "--shards", "0,1", ref_prefix, reads, out], stdout=subprocess.PIPE, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout
+        assert md5_file(out + ".bin") == m["bin_md5"] and md5_file(out + ".txt") == m["txt_md5"]
+        assert b"GB exchanged" in r.stdout
+
+
 @pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="needs two GPUs (the peer-copy branch of qm2_merge_counters)")
 def test_cli_devices_on_two_physical_gpus(qm2, tmp_path):
     """The cross-device paths (never run before round 3: every lease so far had one GPU): `--devices 0,1` — a replica

@@ -98,7 +98,7 @@ runs = [(f, t, e) for f in ("reads.fq", "reads.fa")
 reps = 4
 if scale == "c3":
     runs, reps = [("reads.fq", "8", {}), ("reads.fq", "12", {})], 2
-# QM2_E2E_RUNS="fq:12,fq:24,fq:12:0+0,fa:8::host": file : threads [: devices joined by '+'] [: host]
+# QM2_E2E_RUNS="fq:12,fq:24,fq:12:0+0,fa:8::host,fa:12:s0": file : threads [: devices joined by '+' (s0+1 = --shards 0,1)] [: host]
 if os.environ.get("QM2_E2E_RUNS"):
     runs = []
     for item in os.environ["QM2_E2E_RUNS"].split(","):
@@ -115,7 +115,7 @@ for name, thr, extra in runs:
     devs = extra.pop("_devices", None)
     for rep in range(reps):
         t = time.time()
-        r = subprocess.run([cli, "count", "-t", thr] + (["--devices", devs] if devs else []) +
+        r = subprocess.run([cli, "count", "-t", thr] + ((["--shards", devs[1:]] if devs.startswith("s") else ["--devices", devs]) if devs else []) +
                            [os.path.join(work, "ref.fa"), os.path.join(reads_dir, name), os.path.join(work, "out")],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, QM2_TIMING="1", **extra))
         walls.append(time.time() - t)
