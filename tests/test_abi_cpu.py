@@ -41,6 +41,22 @@ def test_every_declared_symbol_is_exported(pkg):
     assert set(names) <= exported
 
 
+def test_shards_library_exports_its_header(pkg):
+    """libqm2_shards.so (config 4 from the C host: include/qm2_shards.h) exports every symbol its header declares and
+    is built on the C-ABI of libqm2_hip.so + RCCL; the plain CLI does not link it (it is loaded by --shards)."""
+    lib = os.path.join(ROOT, "quick-mer2_amd", "libqm2_shards.so")
+    assert os.path.exists(lib), "make -C quick-mer2_amd builds it"
+    names = declared("qm2_shards.h")
+    assert sorted(names) == ["qm2_shards_acquire", "qm2_shards_close", "qm2_shards_commit", "qm2_shards_finish", "qm2_shards_get_info",
+                             "qm2_shards_open", "qm2_shards_result", "qm2_shards_submit"]
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert set(names) <= set(re.findall(r" T (qm2_[a-z_0-9]+)", out))
+    needed = subprocess.run(["readelf", "-d", lib], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert "libqm2_hip.so" in needed and "librccl" in needed
+    cli = subprocess.run(["readelf", "-d", os.path.join(ROOT, "quick-mer2_amd", "quicKmer2")], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert "librccl" not in cli and "libqm2_shards" not in cli
+
+
 def test_no_cpu_fallback(pkg):
     import torch
     if torch.cuda.is_available():
