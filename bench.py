@@ -18,7 +18,7 @@ Workloads (BASELINE.json `configs`):
 
   c3  (default; BASELINE.json's metric is quoted on the hg38 k=30 dictionary, which fits one
       GPU) hg38-like dictionary: 3.1 Gb synthetic reference, k=30, H=2^32, 2.27 G unique
-      k-mers (32 GiB keys + 16 GiB u32 counters), batches of 50 M x 150 bp reads
+      k-mers (32 GiB keys + 16 GiB u32 counters), batches of 60 M x 150 bp reads
   c2  chr22-like dictionary: 50.8 Mb synthetic reference, k=30, H=2^28
       (2 GiB keys + 1 GiB counters), batches of 10 M x 150 bp reads
   c5  c3's dictionary, HiFi-like reads U(15k, 20k) bp
@@ -45,8 +45,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WORKLOADS = {
     "c2": dict(genome=50_818_468, lgH=28, reads=10_000_000, len_lo=150, len_hi=150, sub=0.005,
                desc="chr22-like 50.8 Mb synthetic reference, k=30, H=2^28; 10M x 150 bp reads per step"),
-    "c3": dict(genome=3_100_000_000, lgH=32, reads=50_000_000, len_lo=150, len_hi=150, sub=0.005,
-               desc="hg38-like 3.1 Gb synthetic reference, k=30, H=2^32; 50M x 150 bp reads per step"),
+    "c3": dict(genome=3_100_000_000, lgH=32, reads=60_000_000, len_lo=150, len_hi=150, sub=0.005,
+               desc="hg38-like 3.1 Gb synthetic reference, k=30, H=2^32; 60M x 150 bp reads per step"),
     "c5": dict(genome=3_100_000_000, lgH=32, reads=400_000, len_lo=15_000, len_hi=20_000, sub=0.001,
                desc="hg38-like dictionary (H=2^32), HiFi-like reads U(15k,20k) bp, 400k reads per step"),
     "tiny": dict(genome=2_000_000, lgH=22, reads=200_000, len_lo=150, len_hi=150, sub=0.005,
@@ -481,8 +481,11 @@ def main():
             import torch.distributed as dist
             dist.destroy_process_group()
         return
+    # what the CLI derives from the head of its input file (qm2_count.c, estimate_kmers_per_kib): k-mers per KiB of sequence
+    # lines, 5 % on top — it sizes the partition buffers (a 60 M-read batch then fits beside the table and four resident batches)
+    kib_hint = min(1023, int(1024.0 * (wl["len_lo"] - k + 1) / (wl["len_lo"] + 1) * 1.05 + 8)) if wl["len_lo"] == wl["len_hi"] else 0
     ctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=pyqm2.FLAG_TIMING | mode_flag,
-                        ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr())
+                        ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr(), kmers_per_kib=kib_hint)
     ctx.prepare(max(b[1] for b in batches))
 
     def barrier():

@@ -87,7 +87,11 @@ typedef struct {
                                  per batch, so batches should be large against it */
     uint32_t part_max_bits;   /* partitioned pipeline: radix bits per level, 1..10
                                  (default 10); smaller values only make sense in tests */
-    uint32_t reserved0;
+    uint32_t kmers_per_kib;   /* what the caller expects of its input: k-mers per 1024 bytes of sequence lines
+                                 (150-base reads at k = 30: 1024 x 121 / 151 = 820), 0 = 1024 (every byte may end a
+                                 k-mer).  Only sizes the partition buffers (22 bytes of scratch per expected k-mer
+                                 byte); input that yields more overflows into the spill list or is recounted by the
+                                 direct kernel — exact either way */
     void    *ext_keys;        /* optional: device pointer to H x u64 keys that are
                                  ALREADY resident (then `keys` may be NULL)      */
     void    *ext_counters;    /* optional: device pointer to H x u32 counters

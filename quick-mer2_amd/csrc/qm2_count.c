@@ -99,6 +99,37 @@ static void sniff_input(const char *reads, int *regular, int *fastq, uint64_t *s
     close(fd);
 }
 
+/* k-mers per 1024 bytes of sequence lines, from the head of a regular input file (qm2_opts.kmers_per_kib): a line of
+ * L bases and its newline yield at most L - k + 1 k-mers, so 150-base reads fill 0.8 of what their bytes would allow
+ * and the partition buffers can be that much smaller.  An estimate, 5 % on top; reads that turn out longer further
+ * down only cost speed (spill list / recount), never counts.  0 = no hint. */
+static uint32_t estimate_kmers_per_kib(const char *reads, uint32_t k, int fastq)
+{
+    const int fd = open(reads, O_RDONLY);
+    if (fd < 0) return 0;
+    static char head[1 << 20];
+    const ssize_t got = pread(fd, head, sizeof head, 0);
+    close(fd);
+    if (got <= 0) return 0;
+    uint64_t bytes = 0, kmers = 0, line_no = 0;
+    ssize_t at = 0;
+    while (at < got) {
+        const char *nl = memchr(head + at, '\n', (size_t)(got - at));
+        if (!nl) break;                                        /* an unfinished line: not counted */
+        const uint64_t len = (uint64_t)(nl - (head + at));
+        const int is_seq = fastq ? (line_no & 3u) == 1u : head[at] != '>';
+        if (is_seq) {
+            bytes += len + 1;
+            if (len >= k) kmers += len - k + 1;
+        }
+        line_no++;
+        at += (ssize_t)len + 1;
+    }
+    if (bytes < 4096) return 0;                                /* (one huge line, or hardly any text: no hint) */
+    const double per_kib = 1024.0 * (double)kmers / (double)bytes * 1.05 + 8.0;
+    return per_kib >= 1024.0 ? 0u : (uint32_t)per_kib;
+}
+
 /* The partition buffers (tens of GB of hipMalloc: seconds of driver time at hg38 scale) are allocated on a thread of
  * their own while the calling thread streams the dictionary from the file to the device. */
 typedef struct { qm2_ctx *ctx; uint32_t what; int rc; } prepare_job;
@@ -151,6 +182,7 @@ static int count_on_devices(qm2_dict_file *d, const char *reads, int n_strip, co
         o.device = devices[i];
         o.flags = QM2_FLAG_KEYS_LATER | QM2_FLAG_RAW_STRICT;
         o.n_staging = (uint32_t)n_strip + 3;
+        if (regular) o.kmers_per_kib = estimate_kmers_per_kib(reads, d->k, fastq);
         if (qm2_open(&ctxs[i], NULL, d->hash_size, d->k, &o)) return 1;
         if (qm2_prepare(ctxs[i], 0, what | QM2_PREPARE_NO_PART)) return 1;
         if (load_keys_and_prepare(d, ctxs[i], what, i == 0)) return 1;
@@ -386,6 +418,7 @@ int qm2_main_count(int argc, char **argv)
     int regular, fastq;
     uint64_t in_size;
     sniff_input(reads, &regular, &fastq, &in_size);
+    if (regular) o.kmers_per_kib = estimate_kmers_per_kib(reads, d.k, fastq);
     if (regular) {
         /* A regular file smaller than the default device batch (1.5 bytes per table slot, up to 6 GiB): one
          * batch of its size is enough, and qm2_prepare then allocates (and the driver clears) a fraction of the

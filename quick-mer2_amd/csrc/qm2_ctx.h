@@ -96,6 +96,7 @@ struct qm2_ctx {
     uint64_t    peek_bytes = 0, peek_bytes_pending = 0, bytes_launched = 0;
     qm2::DevStats peek = {};                /* latest snapshot that has landed (qm2_stats_peek) */
     double      kmers_per_byte = 1.0;
+    double      kappa_hint = 1.0;           /* qm2_opts.kmers_per_kib / 1024: sizes the partition buffers */
     hipStream_t stream = nullptr;           /* every kernel of this context runs here, in order */
     bool        own_stream = false;
     hipStream_t copy_stream = nullptr;      /* H2D staging copies */

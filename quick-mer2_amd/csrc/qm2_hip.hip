@@ -182,7 +182,9 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     HIP_OK(hipStreamSynchronize(c->stream));                          /* buffers may be in use */
     const uint64_t want = std::max<uint64_t>(n + n / 16, 1u << 20);   /* grow with some slack */
     qm2_part_free(p);
-    double mean = (double)want;
+    /* k-mers expected of `want` bytes (the caller's hint; 1 per byte without one) */
+    const double want_kmers = std::max((double)want * c->kappa_hint, 1048576.0);
+    double mean = want_kmers;
     uint64_t slots[kMaxLevels] = {0, 0, 0};
     for (int l = 0; l < p.levels; l++) {
         /* every level from the batch's own bound (its bytes bound its k-mers; 150-bp reads use 0.8 of it):
@@ -191,7 +193,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
          * from the CAPACITY of the one above — 1.12 x 1.22 compounded, 96 instead of 79 GB for the finest level
          * of a 7.55 GB batch — because the smaller stride had measured 10 % slower in split_kmer; with the
          * per-XCD sub-regions above it the difference is 1.5 %: 21.2 vs 20.8 ms.) */
-        mean = (double)want / (double)p.buckets[l];
+        mean = want_kmers / (double)p.buckets[l];
         const double capd = mean * 1.12 + 8.0 * std::sqrt(mean + 1.0) + 128.0;
         if (capd > 4.0e9) return fail("qm2: batch too large for the partition plan");
         p.cap[l] = ((uint32_t)capd + 63u) & ~63u;          /* whole sectors */
@@ -214,7 +216,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     p.buf_slots[1] = slots[1];
     p.n_cursors = 0;
     for (int l = 0; l < p.levels; l++) { p.cursor_off[l] = p.n_cursors; p.n_cursors += p.buckets[l] * (l == 0 ? p.subs0 : 1u); }
-    p.spill_cap = std::min<uint64_t>(want / 4 + 4096, 0xFFFFFFFFull);  /* 2 B of HBM per input byte; places are 32-bit in sort_chunk's announcements */
+    p.spill_cap = std::min<uint64_t>((uint64_t)want_kmers / 4 + 4096, 0xFFFFFFFFull);  /* 2 B of HBM per input byte; places are 32-bit in sort_chunk's announcements */
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++)
         if (p.buf_slots[i]) { e = hipMalloc((void **)&p.buf[i], p.buf_slots[i] * sizeof(uint64_t)); c->prof.allocations++; }
@@ -231,8 +233,8 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     }
     p.reserved = want;
     if (getenv("QM2_PLAN_PRINT"))
-        fprintf(stderr, "QM2 plan for %llu bytes: levels %d, bits %u+%u+%u, sub-regions %u%s, cap %u / %u / %u k-mers, buffers %.1f + %.1f GB, spill %.1f GB, %llu cursors\n",
-                (unsigned long long)n, p.levels, p.bits[0], p.bits[1], p.bits[2], p.subs0, p.seg0 ? " segmented" : "", p.cap[0], p.cap[1], p.cap[2],
+        fprintf(stderr, "QM2 plan for %llu bytes (%.0f k-mers expected): levels %d, bits %u+%u+%u, sub-regions %u%s, cap %u / %u / %u k-mers, buffers %.1f + %.1f GB, spill %.1f GB, %llu cursors\n",
+                (unsigned long long)n, want_kmers, p.levels, p.bits[0], p.bits[1], p.bits[2], p.subs0, p.seg0 ? " segmented" : "", p.cap[0], p.cap[1], p.cap[2],
                 p.buf_slots[0] * 8e-9, p.buf_slots[1] * 8e-9, p.spill_cap * 8e-9, (unsigned long long)p.n_cursors);
     return 0;
 }
@@ -629,6 +631,7 @@ extern "C" int qm2_open(qm2_ctx **out, const uint64_t *keys, uint64_t hash_size,
                                    : (size_t)std::min<uint64_t>(std::max<uint64_t>(hash_size + hash_size / 2, 1ull << 30), 6ull << 30);
     if (c->batch_bytes < 64) c->batch_bytes = 64;
     c->slots.resize(o.n_staging ? std::max<uint32_t>(o.n_staging, 2) : 4);   /* allocated lazily */
+    if (o.kmers_per_kib) c->kappa_hint = std::min(1.0, std::max(0.05, (double)o.kmers_per_kib / 1024.0));
     part_init(c, o.part_max_bits >= 1 && o.part_max_bits <= 10 ? (int)o.part_max_bits : 10);
 #undef OPEN_OK
     *out = c;

@@ -25,7 +25,7 @@ KERNEL_CLASSES = ["count_direct", "split_text", "split_kmer", "bucket_count", "p
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("n_staging", C.c_uint32), ("staging_bytes", C.c_uint64), ("batch_bytes", C.c_uint64),
-                ("part_max_bits", C.c_uint32), ("reserved0", C.c_uint32),
+                ("part_max_bits", C.c_uint32), ("kmers_per_kib", C.c_uint32),
                 ("ext_keys", C.c_void_p), ("ext_counters", C.c_void_p), ("stream", C.c_void_p),
                 ("span_lo", C.c_uint64), ("span_hi", C.c_uint64), ("own_lo", C.c_uint64), ("own_hi", C.c_uint64)]
 
@@ -173,7 +173,8 @@ class Counter:
     """One counting context (qm2_ctx).  keys: host uint64[H] (or None with ext_keys)."""
 
     def __init__(self, keys, hash_size=None, k=30, device=-1, flags=0, n_staging=0, staging_bytes=0,
-                 batch_bytes=0, part_max_bits=0, ext_keys=None, ext_counters=None, stream=None, span=None, own=None):
+                 batch_bytes=0, part_max_bits=0, ext_keys=None, ext_counters=None, stream=None, span=None, own=None,
+                 kmers_per_kib=0):
         L = lib()
         self._h = C.c_void_p()
         o = Opts()
@@ -184,6 +185,7 @@ class Counter:
         o.staging_bytes = staging_bytes
         o.batch_bytes = batch_bytes
         o.part_max_bits = part_max_bits
+        o.kmers_per_kib = int(kmers_per_kib)
         o.ext_keys = ext_keys
         o.ext_counters = ext_counters
         o.stream = stream
