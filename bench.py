@@ -298,7 +298,16 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
         par = "hash-range shards x%d: one per rank, k-mers routed by asynchronous RCCL all-to-all of fixed slabs" % world
         job.close()
     else:
-        cap = (int(max_bytes / G * 1.3) + 4096) & ~1
+        # the senders' 10-bit route (default): G owners x 1024 / G sub-slabs, so that what a shard receives is already the
+        # first level of its own partition (qm2_probe_subslabs_device); --flat-slabs: one slab per owner, split again
+        # on the receiving side (qm2_probe_slabs_device, rounds 1-2)
+        n_subs = 1 if args.flat_slabs else max(1, 1024 // G)
+        xcd = 8 if n_subs > 1 else 1        # the router's output in one sub-region per XCD and region (qm2_route_xcd_device)
+        if n_subs > 1:
+            mean = max_bytes * 0.85 / (G * n_subs * xcd)
+            cap = (int(mean * 1.12 + 8 * mean ** 0.5) + 256) & ~1
+        else:
+            cap = (int(max_bytes / G * 1.3) + 4096) & ~1
         # ONE stream for the router and all the logical shards: their kernels then run one after the other and the
         # HIP-event time of a launch is its own run time.  (With a stream per context, as in round 2, the eight shards'
         # launches queued behind each other's kernels and every tiny spill-list probe was charged ~1.4 ms of waiting:
@@ -311,10 +320,11 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
             cnt = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
             c = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=flags, ext_keys=keys.data_ptr() + 8 * lo,
                               ext_counters=cnt.data_ptr(), span=(lo, hi), own=(own_lo, own_hi), stream=one.cuda_stream)
-            c.prepare(cap)
+            if n_subs == 1:
+                c.prepare(cap)
             shards.append((c, cnt))
-        slabs = torch.empty(G * cap, dtype=torch.int64, device=dev)
-        fill = torch.zeros(G, dtype=torch.int32, device=dev)
+        slabs = torch.empty(xcd * G * n_subs * cap, dtype=torch.int64, device=dev)
+        fill = torch.zeros(xcd * G * n_subs, dtype=torch.int32, device=dev)
         call = torch.zeros(3, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
 
@@ -322,10 +332,18 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
             buf, nbytes, _ = batches[i % n_batches]
             fill.zero_()
             torch.cuda.synchronize()
-            router.route_device(buf.data_ptr(), nbytes, slabs.data_ptr(), cap, G, fill.data_ptr(), call.data_ptr())
+            if n_subs > 1:
+                router.route_xcd_device(buf.data_ptr(), nbytes, slabs.data_ptr(), cap, G * n_subs, fill.data_ptr(), call.data_ptr())
+            else:
+                router.route_device(buf.data_ptr(), nbytes, slabs.data_ptr(), cap, G, fill.data_ptr(), call.data_ptr())
             router.sync()
             for g, (c, _) in enumerate(shards):
-                c.probe_slabs_device(slabs.data_ptr() + 8 * g * cap, cap, 1, fill.data_ptr() + 4 * g)
+                if n_subs > 1:
+                    # owner g's part of the x-major output: 8 "peers" (the sender's XCD sub-regions) G * n_subs regions apart
+                    c.probe_subslabs_device(slabs.data_ptr() + 8 * g * n_subs * cap, cap, xcd, n_subs, fill.data_ptr() + 4 * g * n_subs,
+                                            kmers_bound=int(nbytes * 0.85 / G * 1.1), peer_stride=G * n_subs)
+                else:
+                    c.probe_slabs_device(slabs.data_ptr() + 8 * g * cap, cap, 1, fill.data_ptr() + 4 * g)
             for c, _ in shards:
                 c.sync()
 
@@ -352,7 +370,8 @@ def sharded_bench(args, wl, pyqm2, torch, np, dev, local, rank, world, use_dist,
         conserved = sum(sum64(torch, cnt) for _, cnt in shards) == sum(b["n_hits"] for b in s1)
         spilled = sum(c.profile()["spilled_kmers"] for c, _ in shards)
         retries = 0
-        par = "hash-range shards x%d, LOGICAL on one GPU (route + one partitioned probe per shard; the exchange is a no-op)" % G
+        par = ("hash-range shards x%d, LOGICAL on one GPU (route + one partitioned probe per shard; the exchange is a no-op); %s"
+               % (G, "10-bit route: %d sub-slabs per owner, the receivers split once" % n_subs if n_subs > 1 else "one slab per owner, the receivers split twice"))
         for c, _ in shards:
             c.close()
         router.close()
@@ -408,6 +427,7 @@ def main():
                          "BASELINE config 4: the table range-partitioned by home slot over the ranks, k-mers routed by "
                          "all-to-all (N = 1: --shards logical shards on the one GPU, the exchange a no-op)")
     ap.add_argument("--shards", type=int, default=8, help="--parallelism sharded on one GPU: logical shards")
+    ap.add_argument("--flat-slabs", action="store_true", help="--parallelism sharded on one GPU: one slab per owner (rounds 1-2) instead of the 10-bit route")
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "partition"],
                     help="count pipeline: auto = chosen per batch from its size vs. H")
     args = ap.parse_args()

@@ -273,6 +273,28 @@ int qm2_route_device(qm2_ctx *c, const void *d_seq_bytes, size_t n, const uint64
 int qm2_probe_slabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_slabs,
                            const uint32_t *d_fill);
 
+/* The same when the senders have already partitioned what they route: qm2_route_device called with
+ * n_owners x n_subs "owners" (<= 1024 in all) cuts every owner's slab into n_subs sub-slabs by the next
+ * log2(n_subs) bits of the home slot, and what a shard then receives — d_slabs = [n_peers][n_subs] sub-slabs of
+ * sub_cap k-mers (peer p's sub-slab 0 lies peer_stride regions behind peer p - 1's; 0 = n_subs: side by side), d_fill
+ * their fills in the same order — IS the first level of its own partition (the sender takes
+ * the place the XCD has in the text level's sub-regions), so the slab split of qm2_probe_slabs_device falls away:
+ * text -> 10-bit route -> exchange -> ONE split -> count, as many passes as an unsharded table takes.
+ * kmers_bound: an upper estimate of the k-mers in the call (sizes the partition buffers; 0 = every sub-slab full).
+ * Needs a context with an own range at least two levels deep behind the sub-slabs; otherwise an error message. */
+int qm2_probe_subslabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint64_t sub_cap, uint32_t n_peers,
+                              uint32_t n_subs, uint32_t peer_stride, const uint32_t *d_fill, uint64_t kmers_bound);
+
+/* qm2_route_device with the text level's per-XCD sub-regions: every one of the n_regions
+ * (<= 1024) regions is cut into 8, one per XCD, so that a 128-byte line of the output only ever passes through one L2
+ * (with hundreds of regions the plain layout writes a third of its lines as two masked pieces: 8.9 - 11.9 ms instead
+ * of 7.4 per 20 M reads at C3).  Layout x-major: sub-region x of region r = region x * n_regions + r of d_slabs, each of
+ * region_cap k-mers; d_fill has 8 * n_regions entries in the same order.  A receiver takes owner g's part of it as
+ * qm2_probe_subslabs_device(ctx, d_slabs + g * n_subs * region_cap, region_cap, 8 * n_peers, n_subs,
+ * peer_stride = n_regions, d_fill + g * n_subs, ...): the 8 sub-regions of a sender count as 8 peers. */
+int qm2_route_xcd_device(qm2_ctx *c, const void *d_seq_bytes, size_t n, const uint64_t *d_suppress, uint64_t n_suppress,
+                         uint64_t *d_slabs, uint64_t region_cap, uint32_t n_regions, uint32_t *d_fill, uint64_t *d_call);
+
 /* Probe + increment for an array of canonical k-mers already on this device
  * (QuicKmer.c:283-293: the worker's batch loop).  d_n (device u64, may be
  * NULL) overrides n with a device-side count (avoids a host round trip after

@@ -54,6 +54,8 @@ struct PartPlan {                           /* how a batch is radix-partitioned 
     uint64_t reserved = 0;
     uint64_t refused = 0;                   /* smallest batch whose buffers did not fit in HBM */
     uint32_t cap[kMaxLevels] = {0, 0, 0};
+    bool     ext0 = false;                  /* level 0 comes from outside (qm2_probe_subslabs_device: the sub-slabs a shard received ARE its level 0) */
+    int      max_bits = 10;
     uint32_t subs0 = 1;                     /* level 0: sub-regions per child (qm2_partition.hip.h, sub_region0) */
     bool     seg0 = false;                  /* level 0's buffer is segmented (qm2_partition.hip.h, SplitDst) */
     uint64_t *buf[2] = {nullptr, nullptr};

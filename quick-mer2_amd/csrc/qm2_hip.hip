@@ -137,21 +137,28 @@ static int harvest_timing(qm2_ctx *c)
 
 /* ---- partition plan --------------------------------------------------------- */
 
-static void part_init(qm2_ctx *c, int max_bits)
+/* first_bits > 0: level 0 is given from outside with that many bits (qm2_probe_subslabs_device); the levels behind it
+ * share the rest */
+static void part_init(qm2_ctx *c, int max_bits, int first_bits = 0)
 {
     PartPlan &p = c->part;
     p.levels = 0;
+    p.ext0 = first_bits > 0;
+    p.max_bits = max_bits;
     if (c->own_hi == 0) return;               /* a span without its own range: probed directly */
     p.lg_range = 0;
     while ((1ull << p.lg_range) < c->own_hi - c->own_lo) p.lg_range++;
     const int nb = (int)p.lg_range - kLgS;                           /* bits of the finest bucket id */
     if (nb < 1 || c->lgH <= (uint32_t)kLgS) return;   /* fewer than two buckets: counted by the direct kernel */
-    p.levels = nb <= max_bits ? 1 : (nb + max_bits - 1) / max_bits;
+    if (first_bits) {
+        if (nb - first_bits < 1) return;                             /* nothing left to split behind the given level */
+        p.levels = 1 + (nb - first_bits + max_bits - 1) / max_bits;
+    } else p.levels = nb <= max_bits ? 1 : (nb + max_bits - 1) / max_bits;
     if (p.levels > kMaxLevels) { p.levels = 0; return; }             /* cannot happen for H <= 2^32 */
     int left = nb, cum = 0;
     for (int l = 0; l < p.levels; l++) {
         /* the smaller shares go first (the text level is VALU-bound); hg38: 10 + 10 */
-        const int b = left / (p.levels - l);
+        const int b = first_bits && l == 0 ? first_bits : left / (p.levels - l);
         p.bits[l] = (uint32_t)b;
         cum += b;
         left -= b;
@@ -197,6 +204,10 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
         const double capd = mean * 1.12 + 8.0 * std::sqrt(mean + 1.0) + 128.0;
         if (capd > 4.0e9) return fail("qm2: batch too large for the partition plan");
         p.cap[l] = ((uint32_t)capd + 63u) & ~63u;          /* whole sectors */
+        if (l == 0 && p.ext0) {                                  /* the caller's buffer: nothing of ours */
+            p.subs0 = 1; p.seg0 = false; p.cap[0] = 0;
+            continue;
+        }
         if (l == 0) {
             /* a level that another split reads: one sub-region per XCD and child (sub_region0), each with the
              * Poisson room of its own, smaller, fill */
@@ -215,7 +226,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     p.buf_slots[0] = std::max(slots[0], slots[2]);
     p.buf_slots[1] = slots[1];
     p.n_cursors = 0;
-    for (int l = 0; l < p.levels; l++) { p.cursor_off[l] = p.n_cursors; p.n_cursors += p.buckets[l] * (l == 0 ? p.subs0 : 1u); }
+    for (int l = 0; l < p.levels; l++) { p.cursor_off[l] = p.n_cursors; p.n_cursors += l == 0 && p.ext0 ? 0 : p.buckets[l] * (l == 0 ? p.subs0 : 1u); }
     p.spill_cap = std::min<uint64_t>((uint64_t)want_kmers / 4 + 4096, 0xFFFFFFFFull);  /* 2 B of HBM per input byte; places are 32-bit in sort_chunk's announcements */
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++)
@@ -281,6 +292,8 @@ struct PartSource {
     uint64_t slab_cap = 0;
     uint32_t n_slabs = 0;
     const uint32_t *fill = nullptr;
+    uint32_t n_subs = 0;            /* > 0: the slabs are [peer][sub][slab_cap]: a shard's level 0, partitioned by its senders */
+    uint32_t peer_stride = 0;       /* ... regions from one peer's sub-slab 0 to the next one's (0 = n_subs) */
     uint64_t n_upper = 0;           /* upper bound on the k-mers (text: its sequence bytes) */
     uint64_t n_bytes = 0;           /* bytes launched (what kmers_per_byte is measured against) */
 };
@@ -295,7 +308,7 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
 
     TimedLaunch t;
     /* level 1: text or slabs -> buckets[0] */
-    {
+    if (!src.n_subs) {
         uint32_t lg_subs = 0;
         while ((1u << lg_subs) < p.subs0) lg_subs++;
         SplitDst d = {p.buf[0], p.cursors + p.cursor_off[0], p.cap[0], p.spill, p.spill_count, p.spill_cap,
@@ -337,7 +350,17 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
                            0, s, p.buf[(l - 1) & 1], p.cursors + p.cursor_off[l - 1], (uint64_t)p.cap[l - 1],         \
                            p.bits[0] + lg_subs + kSegLg, (uint32_t)p.buckets[l - 1] - 1u, p.shift[l], p.bits[l], chunks, \
                            n_parents, d, c->stats)
-        if (l == 1 && p.seg0) QM2_LAUNCH_LEVEL(true); else QM2_LAUNCH_LEVEL(false);
+        if (l == 1 && src.n_subs) {
+            /* the received sub-slabs are the parents: region (peer, sub) feeds the children of sub — the layout of the
+             * per-XCD sub-regions with the sender in the XCD's place */
+            const uint32_t np = src.n_slabs * src.n_subs;
+            const uint32_t ch = std::max<uint32_t>(1u, (uint32_t)(((src.slab_cap + kSplitSlots - 1) / kSplitSlots + 3) / 4));
+            uint32_t lg_ns = 0;
+            while ((1u << lg_ns) < src.n_subs) lg_ns++;
+            hipLaunchKernelGGL((split_kmer_kernel<false, false, false>), dim3(ch * np), dim3(kSplitThreads), 0, s, src.slabs, src.fill,
+                               src.slab_cap, lg_ns, src.n_subs - 1u, p.shift[l], p.bits[l], ch, np, d, c->stats,
+                               src.peer_stride && src.peer_stride != src.n_subs ? src.peer_stride : 0u);
+        } else if (l == 1 && p.seg0) QM2_LAUNCH_LEVEL(true); else QM2_LAUNCH_LEVEL(false);
 #undef QM2_LAUNCH_LEVEL
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
@@ -401,8 +424,17 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
     if (src.sv) {
         if (launch_direct(c, *src.sv, &c->stats->part_lost, false, true)) return 1;
     } else {
+        const uint64_t groups = (src.slab_cap + (uint64_t)kWave * kNJ - 1) / ((uint64_t)kWave * kNJ);
+        if (src.n_subs) {
+            /* (hundreds of regions: ONE launch that goes over them, instead of one each) */
+            if (time_begin(c, &t, QM2_K_PROBE)) return 1;
+            hipLaunchKernelGGL(probe_regions_kernel, dim3(grid_for(c, std::min<uint64_t>(groups * src.n_subs * src.n_slabs, 1u << 16))), dim3(kBlock), 0, s,
+                               src.slabs, src.slab_cap, src.n_slabs, src.n_subs, src.peer_stride ? src.peer_stride : src.n_subs, src.fill,
+                               table_view(c), c->stats, &c->stats->part_lost);
+            HIP_OK(hipGetLastError());
+            if (time_end(c, &t, true)) return 1;
+        } else
         for (uint32_t g = 0; g < src.n_slabs; g++) {
-            const uint64_t groups = (src.slab_cap + (uint64_t)kWave * kNJ - 1) / ((uint64_t)kWave * kNJ);
             if (time_begin(c, &t, QM2_K_PROBE)) return 1;
             hipLaunchKernelGGL(probe_kernel, dim3(grid_for(c, groups)), dim3(kBlock), 0, s, src.slabs + g * src.slab_cap,
                                src.slab_cap, (const unsigned long long *)nullptr, src.fill + g, table_view(c), c->stats,
@@ -1249,8 +1281,23 @@ extern "C" int qm2_probe_device(qm2_ctx *c, const uint64_t *d_kmers, uint64_t n,
     return time_end(c, &t, true);
 }
 
+static int route_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup, uint64_t n_sup,
+                        uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t xcd_subs, uint32_t *d_fill, uint64_t *d_call);
+
 extern "C" int qm2_route_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup, uint64_t n_sup,
                                 uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t *d_fill, uint64_t *d_call)
+{
+    return route_device(c, d_seq, n, d_sup, n_sup, d_slabs, slab_cap, n_owners, 1, d_fill, d_call);
+}
+
+extern "C" int qm2_route_xcd_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup, uint64_t n_sup,
+                                    uint64_t *d_slabs, uint64_t region_cap, uint32_t n_regions, uint32_t *d_fill, uint64_t *d_call)
+{
+    return route_device(c, d_seq, n, d_sup, n_sup, d_slabs, region_cap, n_regions, 8, d_fill, d_call);
+}
+
+static int route_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup, uint64_t n_sup,
+                        uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t xcd_subs, uint32_t *d_fill, uint64_t *d_call)
 {
     if (!c) return fail("qm2_route_device: null context");
     if (n == 0) return 0;
@@ -1263,7 +1310,7 @@ extern "C" int qm2_route_device(qm2_ctx *c, const void *d_seq, size_t n, const u
     const SeqView sv = seq_view((const uint8_t *)d_seq, n, 0, d_sup, n_sup);
     uint32_t lgG = 0;
     while ((1u << lgG) < n_owners) lgG++;
-    SplitDst d = {d_slabs, d_fill, (uint32_t)slab_cap, nullptr, nullptr, 0, 0, 1};
+    SplitDst d = {d_slabs, d_fill, (uint32_t)slab_cap, nullptr, nullptr, 0, 0, xcd_subs};
     const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
     const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * kSplitWgPerCu);
     TimedLaunch t;
@@ -1316,6 +1363,56 @@ extern "C" int qm2_probe_slabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint6
         if (time_end(c, &t, g + 1 == n_slabs)) return 1;
     }
     return 0;
+}
+
+extern "C" int qm2_probe_subslabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint64_t sub_cap, uint32_t n_peers, uint32_t n_subs,
+                                         uint32_t peer_stride, const uint32_t *d_fill, uint64_t kmers_bound)
+{
+    if (peer_stride && peer_stride < n_subs) return fail("qm2_probe_subslabs_device: peers closer together than their sub-slabs");
+    if (!peer_stride) peer_stride = n_subs;
+    if (!c) return fail("qm2_probe_subslabs_device: null context");
+    if (n_peers == 0 || n_subs == 0 || sub_cap == 0) return 0;
+    if (!d_slabs || !d_fill) return fail("qm2_probe_subslabs_device: null buffer");
+    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
+    if (c->keys_consumed) return fail("qm2: the key table was overwritten by qm2_chain_gather; this context cannot count any more");
+    if ((n_subs & (n_subs - 1)) || n_subs > (uint32_t)kMaxFan || (sub_cap & 1u) || sub_cap > 0xFFFFFFFFull || ((uintptr_t)d_slabs & 15u))
+        return fail("qm2_probe_subslabs_device: sub-slabs must be a power of two of them (<= %d), 16-byte aligned, of an even capacity below 2^32", kMaxFan);
+    if (c->own_hi == 0) return fail("qm2_probe_subslabs_device: the context has no own range (qm2_opts.own_lo / own_hi)");
+    if (use_device(c)) return 1;
+    uint32_t lg_subs = 0;
+    while ((1u << lg_subs) < n_subs) lg_subs++;
+    /* the plan: level 0 = the sub-slabs (its children are the senders' sub-regions), the rest as usual */
+    PartPlan &p = c->part;
+    if (!p.ext0 || p.levels == 0 || p.bits[0] != lg_subs) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        qm2_part_free(p);
+        if (p.shared) { (void)hipFree(p.shared); p.shared = nullptr; }
+        p.runs = 0;
+        p.refused = 0;
+        part_init(c, p.max_bits, (int)lg_subs);
+    }
+    if (p.levels < 2 || (c->flags & QM2_FLAG_DIRECT))
+        return fail("qm2_probe_subslabs_device: %u sub-slabs leave this context's range nothing to split (or QM2_FLAG_DIRECT is set): use qm2_probe_slabs_device", n_subs);
+    bool ok = false;
+    if (runs_fit(c, &ok)) return 1;
+    const uint64_t bound = kmers_bound ? kmers_bound : sub_cap * n_subs * (uint64_t)n_peers;
+    c->bytes_launched += bound;
+    if (!ok || part_reserve(c, bound)) {
+        /* a table with hopelessly long runs of occupied slots, or no memory: every region probed directly */
+        c->prof.direct_batches++;
+        const uint64_t groups = (sub_cap + (uint64_t)kWave * kNJ - 1) / ((uint64_t)kWave * kNJ);
+        TimedLaunch t;
+        if (time_begin(c, &t, QM2_K_PROBE)) return 1;
+        hipLaunchKernelGGL(probe_regions_kernel, dim3(grid_for(c, std::min<uint64_t>(groups * n_subs * n_peers, 1u << 16))), dim3(kBlock), 0, c->stream,
+                           d_slabs, sub_cap, n_peers, n_subs, peer_stride, d_fill, table_view(c), c->stats, (const unsigned long long *)nullptr);
+        HIP_OK(hipGetLastError());
+        return time_end(c, &t, true);
+    }
+    c->prof.partitioned_batches++;
+    PartSource src;
+    src.slabs = d_slabs; src.slab_cap = sub_cap; src.n_slabs = n_peers; src.n_subs = n_subs; src.peer_stride = peer_stride; src.fill = d_fill;
+    src.n_upper = bound; src.n_bytes = bound;
+    return launch_partitioned(c, src);
 }
 
 /* ---- pure host helper ------------------------------------------------------ */

@@ -246,6 +246,44 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const uint64_t *kmers, ui
     }
 }
 
+/* The same over many regions of one buffer (a shard's received sub-slabs: region r = kmers + r * cap, fills[r]
+ * k-mers in it; peer p's sub-slab s is region p * peer_stride + s): only ever the exact fallback of the partitioned pipeline (only_if: the batch lost k-mers) or the
+ * path of a table the partition cannot take, so plain — every k-mer probed and counted on its own. */
+__global__ __launch_bounds__(kBlock) void probe_regions_kernel(const uint64_t *kmers, uint64_t cap, uint32_t n_peers, uint32_t n_subs,
+                                                               uint32_t peer_stride, const uint32_t *fills, TableView tv, DevStats *stats,
+                                                               const unsigned long long *only_if)
+{
+    if (only_if && *only_if == 0) return;
+    const uint32_t n_regions = n_peers * n_subs;
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x, n_threads = (uint64_t)gridDim.x * kBlock;
+    const int lane = threadIdx.x & (kWave - 1);
+    unsigned long long n_probes = 0, n_hits = 0;
+    for (uint32_t q = 0; q < n_regions; q++) {
+        const uint64_t r = (uint64_t)(q / n_subs) * peer_stride + q % n_subs;       /* sub-slab q % n_subs of peer q / n_subs */
+        const uint64_t n = fills[r] < cap ? fills[r] : cap;
+        const uint64_t *src = kmers + r * cap;
+        for (uint64_t i = gid; i < n; i += n_threads) {
+            const uint64_t km = src[i];
+            if (km == ~0ull) continue;
+            const uint32_t home = djb32(km) & tv.hmask;
+            const uint32_t step = (home & tv.hhalf) ? 0xFFFFFFFFu : 1u;     /* :93-95 */
+            uint32_t idx = home - (uint32_t)tv.span_lo;
+            for (;;) {
+                const uint64_t v = tv.keys[idx];
+                n_probes++;
+                if (v == km) { atomicAdd(&tv.counters[idx], 1u); n_hits++; break; }   /* :98, :291 */
+                if (v == 0) break;
+                idx += step;                                                 /* :97 */
+            }
+        }
+    }
+    n_probes = wave_sum(n_probes); n_hits = wave_sum(n_hits);
+    if (lane == 0 && stats) {
+        atomicAdd(&stats->n_probes, n_probes);
+        atomicAdd(&stats->n_hits, n_hits);
+    }
+}
+
 /* u32 accumulators -> the reference's uint16 counters (mod 65536, :23/:291). */
 __global__ __launch_bounds__(kBlock) void narrow_kernel(const uint32_t *in, uint16_t *out, uint64_t n)
 {

@@ -386,7 +386,7 @@ template <bool FLAT, bool SRC_SEG, bool DST_SEG>
 __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_kernel(const uint64_t *src, const uint32_t *src_cursors,
                                                                    uint64_t src_cap, uint32_t src_lg_row, uint32_t parent_mask, uint32_t shift, uint32_t bits,
                                                                    uint32_t wgs_per_parent, uint32_t n_parents,
-                                                                   SplitDst d, DevStats *stats)
+                                                                   SplitDst d, DevStats *stats, uint32_t src_peer_stride = 0)
 {
     const uint32_t fan = 1u << bits;
     __shared__ SplitLds L;
@@ -401,7 +401,13 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
         parent = (uint64_t)(q / wgs_per_parent) * 8u + r;
         bx = q % wgs_per_parent;
     } else { parent = blockIdx.x / wgs_per_parent; bx = blockIdx.x % wgs_per_parent; }
-    uint64_t n = src_cursors[parent];
+    /* where parent P lies in the source buffer.  Normally region P; a shard's received sub-slabs may lie [peer] x
+     * peer_stride + [sub] (the senders' per-XCD sub-regions, x-major: qm2_probe_subslabs_device), parents still
+     * numbered peer * 2^src_lg_row + sub */
+    uint64_t region = parent;
+    if (!FLAT && !SRC_SEG && src_peer_stride)
+        region = (parent >> src_lg_row) * (uint64_t)src_peer_stride + (parent & ((1u << src_lg_row) - 1u));
+    uint64_t n = src_cursors[region];
     if (n > src_cap) n = src_cap;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     unsigned long long lost = 0;
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
         for (int j = 0; j < kKpt / 2; j++) {
             const uint64_t at = first + 2u * ((uint64_t)j * kSplitThreads + tid);
             /* (at is even and so is every segment's length: both k-mers of a load lie in one segment) */
-            nxt[j] = at < n ? *reinterpret_cast<const u32x4 *>(src + slot_of<SRC_SEG>(parent, (uint32_t)at, (uint32_t)src_cap, src_lg_row))
+            nxt[j] = at < n ? *reinterpret_cast<const u32x4 *>(src + slot_of<SRC_SEG>(region, (uint32_t)at, (uint32_t)src_cap, src_lg_row))
                             : u32x4{~0u, ~0u, ~0u, ~0u};
         }
     };

@@ -54,7 +54,7 @@ class Dup(C.Structure):
 
 
 # every symbol include/qm2.h and include/qm2_tools.h declare
-ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_probe_slabs_device", "qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
+ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_probe_slabs_device", "qm2_probe_subslabs_device", "qm2_route_xcd_device", "qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
                "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_submit_raw_device", "qm2_staging_commit_raw", "qm2_raw_verdict",
                "qm2_shard_span", "qm2_last_error",
@@ -124,6 +124,10 @@ def lib():
     L.qm2_route_device.argtypes = [vp, vp, C.c_size_t, vp, u64, vp, u64, u32, vp, vp]
     L.qm2_probe_slabs_device.restype = C.c_int
     L.qm2_probe_slabs_device.argtypes = [vp, vp, u64, u32, vp]
+    L.qm2_probe_subslabs_device.restype = C.c_int
+    L.qm2_probe_subslabs_device.argtypes = [vp, vp, u64, u32, u32, u32, vp, u64]
+    L.qm2_route_xcd_device.restype = C.c_int
+    L.qm2_route_xcd_device.argtypes = [vp, vp, C.c_size_t, vp, u64, vp, u64, u32, vp, vp]
     L.qm2_chain_gather.restype = C.c_int
     L.qm2_chain_gather.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.qm2_submit_raw_device.restype = C.c_int
@@ -274,6 +278,14 @@ class Counter:
 
     def probe_slabs_device(self, slabs_ptr, slab_cap, n_slabs, fill_ptr):
         _check(lib().qm2_probe_slabs_device(self._h, slabs_ptr, slab_cap, n_slabs, fill_ptr), "qm2_probe_slabs_device")
+
+    def probe_subslabs_device(self, slabs_ptr, sub_cap, n_peers, n_subs, fill_ptr, kmers_bound=0, peer_stride=0):
+        _check(lib().qm2_probe_subslabs_device(self._h, slabs_ptr, sub_cap, n_peers, n_subs, peer_stride, fill_ptr, int(kmers_bound)),
+               "qm2_probe_subslabs_device")
+
+    def route_xcd_device(self, ptr, n, slabs_ptr, region_cap, n_regions, fill_ptr, call_ptr, suppress_ptr=None, n_suppress=0):
+        _check(lib().qm2_route_xcd_device(self._h, ptr, n, suppress_ptr, n_suppress, slabs_ptr, region_cap, n_regions, fill_ptr,
+                                          call_ptr), "qm2_route_xcd_device")
 
     def probe_device(self, kmers_ptr, n, n_ptr=None):
         _check(lib().qm2_probe_device(self._h, kmers_ptr, n, n_ptr), "qm2_probe_device")

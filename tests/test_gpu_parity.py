@@ -1054,6 +1054,124 @@ def test_route_then_probe_slabs_equals_fused(qm2, torch_cuda, tmp_path):
     assert int(fill.sum()) == n0 and int(call[2]) == n0 - 2 * small and int(call[1]) == n0
 
 
+def test_route_by_sub_slabs_is_the_receivers_first_level(qm2, torch_cuda, tmp_path):
+    """qm2_route_device with n_owners x n_subs "owners" + qm2_probe_subslabs_device: the senders cut every owner's slab
+    by the next bits of the home slot, and what a shard receives is the first level of its own partition (no slab split
+    on the receiving side).  1 / 2 / 4 / 8 logical shards of the mini table, two senders, every feasible width of the
+    sub-slab level: counters, hits and probes equal the oracle's, and the partitioned pipeline really ran."""
+    torch = torch_cuda
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    keys, H = qm["keys"], len(qm["keys"])
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    blob = ol.strip_reads(rfa)
+    half = blob.rfind(b"\n", 0, len(blob) // 2) + 1
+    dparts = [torch.frombuffer(bytearray(x), dtype=torch.uint8).cuda() for x in (blob[:half], blob[half:])]
+    exp_kmers, nb = ol.extract(blob, 30)
+    exp_depth, exp_st = ol.count_lines(keys, 30, blob)
+    lgH = H.bit_length() - 1
+    for G in (1, 2, 4, 8):
+        lg_range = lgH - (G.bit_length() - 1)
+        widest = lg_range - 12 - 1                        # buckets are 2^12 slots; one bit at least must be left to split
+        spans = [qm2.shard_span(keys, G, g) for g in range(G)]
+        for lg_subs in sorted({1, widest}):
+            n_subs = 1 << lg_subs
+            cap = (len(exp_kmers) // (G * n_subs) * 2 + 4096) & ~1
+            routed = []
+            with qm2.Counter(None, hash_size=H, k=30, flags=qm2.FLAG_KEYS_LATER, span=(0, 64)) as router:
+                for d in dparts:
+                    slabs = torch.zeros(G * n_subs * cap, dtype=torch.int64, device="cuda")
+                    fill = torch.zeros(G * n_subs, dtype=torch.int32, device="cuda")
+                    call = torch.zeros(3, dtype=torch.int64, device="cuda")
+                    torch.cuda.synchronize()
+                    router.route_device(d.data_ptr(), d.numel(), slabs.data_ptr(), cap, G * n_subs, fill.data_ptr(), call.data_ptr())
+                    router.sync()
+                    assert int(call[2]) == 0
+                    routed.append((slabs, fill))
+            total = np.zeros(H, dtype=np.uint64)
+            hits = probes = 0
+            for g, (own_lo, own_hi, lo, hi) in enumerate(spans):
+                a, b = g * n_subs, (g + 1) * n_subs
+                recv = torch.cat([r[0][a * cap:b * cap] for r in routed])            # [sender][sub][cap]
+                rfill = torch.cat([r[1][a:b] for r in routed]).contiguous()
+                torch.cuda.synchronize()
+                with qm2.Counter(keys[lo:hi], hash_size=H, k=30, span=(lo, hi), own=(own_lo, own_hi), flags=qm2.FLAG_TIMING) as pc:
+                    pc.probe_subslabs_device(recv.data_ptr(), cap, len(routed), n_subs, rfill.data_ptr())
+                    d, st = pc.finish()
+                    prof = pc.profile()
+                    assert prof["partitioned_batches"] == 1 and prof["class_launches"]["bucket_count"] == 1 and prof["fallback_batches"] == 0
+                    assert prof["class_launches"]["split_kmer"] == 1                 # one split behind the received level, none of the slabs
+                    # a second call on the same plan, and the old entry point on the same context (it re-plans)
+                    pc.probe_subslabs_device(recv.data_ptr(), cap, len(routed), n_subs, rfill.data_ptr())
+                    d2, st2 = pc.finish()
+                    assert np.array_equal(d2.astype(np.uint32), 2 * d.astype(np.uint32)) and st2["n_hits"] == 2 * st["n_hits"]
+                total[lo:hi] += d
+                hits += st["n_hits"]
+                probes += st["n_probes"]
+            assert hits == exp_st["n_hits"] and probes == exp_st["n_probes"], (G, lg_subs)
+            assert np.array_equal(total.astype(np.uint16), exp_depth), (G, lg_subs)
+    # the router's output in per-XCD sub-regions (qm2_route_xcd_device, x-major): a sender's 8 sub-regions count as 8 peers,
+    # G * n_subs regions apart
+    G, n_subs = 4, 4
+    spans = [qm2.shard_span(keys, G, g) for g in range(G)]
+    cap = (len(exp_kmers) // (G * n_subs * 8) * 3 + 4096) & ~1
+    routed = []
+    with qm2.Counter(None, hash_size=H, k=30, flags=qm2.FLAG_KEYS_LATER, span=(0, 64)) as router:
+        for d in dparts:
+            slabs = torch.zeros(8 * G * n_subs * cap, dtype=torch.int64, device="cuda")
+            fill = torch.zeros(8 * G * n_subs, dtype=torch.int32, device="cuda")
+            call = torch.zeros(3, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            router.route_xcd_device(d.data_ptr(), d.numel(), slabs.data_ptr(), cap, G * n_subs, fill.data_ptr(), call.data_ptr())
+            router.sync()
+            assert int(call[2]) == 0 and int(fill.sum()) == int(call[1])
+            routed.append((slabs, fill))
+    total = np.zeros(H, dtype=np.uint64)
+    hits = probes = 0
+    for g, (own_lo, own_hi, lo, hi) in enumerate(spans):
+        for slabs, fill in routed:                       # one call per sender: its 8 sub-regions are the peers
+            pass
+        with qm2.Counter(keys[lo:hi], hash_size=H, k=30, span=(lo, hi), own=(own_lo, own_hi), flags=qm2.FLAG_TIMING) as pc:
+            for slabs, fill in routed:
+                pc.probe_subslabs_device(slabs.data_ptr() + 8 * g * n_subs * cap, cap, 8, n_subs, fill.data_ptr() + 4 * g * n_subs,
+                                         peer_stride=G * n_subs)
+            d, st = pc.finish()
+            assert pc.profile()["partitioned_batches"] == len(routed)
+        total[lo:hi] += d
+        hits += st["n_hits"]
+        probes += st["n_probes"]
+    assert hits == exp_st["n_hits"] and probes == exp_st["n_probes"]
+    assert np.array_equal(total.astype(np.uint16), exp_depth)
+    # skew through sub-slabs: 120 k poly-A reads put ~14 M copies of k-mer 0 into ONE sub-slab; the receiving shard's bucket and
+    # its spill list overflow, and the whole call is recounted region by region (probe_regions_kernel), decided on the device
+    flood = (b"A" * 150 + b"\n") * 120_000 + blob[:blob.rfind(b"\n", 0, 200_000) + 1]
+    fexp_depth, fexp_st = ol.count_lines(keys, 30, flood)
+    d_flood = torch.frombuffer(bytearray(flood), dtype=torch.uint8).cuda()
+    n_subs = 2
+    cap = (fexp_st["n_kmers"] + 4096) & ~1
+    slabs = torch.zeros(n_subs * cap, dtype=torch.int64, device="cuda")
+    fill = torch.zeros(n_subs, dtype=torch.int32, device="cuda")
+    call = torch.zeros(3, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    with qm2.Counter(None, hash_size=H, k=30, flags=qm2.FLAG_KEYS_LATER, span=(0, 64)) as router:
+        router.route_device(d_flood.data_ptr(), d_flood.numel(), slabs.data_ptr(), cap, n_subs, fill.data_ptr(), call.data_ptr())
+        router.sync()
+    assert int(call[2]) == 0 and int(call[1]) == fexp_st["n_kmers"]
+    with qm2.Counter(keys, hash_size=H, k=30, own=(0, H), span=(0, H), flags=qm2.FLAG_TIMING) as pc:
+        pc.probe_subslabs_device(slabs.data_ptr(), cap, 1, n_subs, fill.data_ptr())
+        d, st = pc.finish()
+        prof = pc.profile()
+    assert prof["fallback_batches"] == 1, prof
+    assert st["n_hits"] == fexp_st["n_hits"] and st["n_probes"] == fexp_st["n_probes"]
+    assert np.array_equal(d, fexp_depth)
+    # a sub-slab level that leaves nothing to split is refused with a message, not miscounted
+    own_lo, own_hi, lo, hi = qm2.shard_span(keys, 8, 0)
+    with qm2.Counter(keys[lo:hi], hash_size=H, k=30, span=(lo, hi), own=(own_lo, own_hi)) as pc:
+        z = torch.zeros(8 * 64, dtype=torch.int64, device="cuda")
+        f = torch.zeros(8, dtype=torch.int32, device="cuda")
+        with pytest.raises(qm2.Qm2Error):
+            pc.probe_subslabs_device(z.data_ptr(), 64, 1, 8, f.data_ptr())
+
+
 def test_multi_drivers_on_the_gpu_single_rank(qm2, torch_cuda, tmp_path):
     """quick-mer2_amd/multi.py with the real HipEngine and the RCCL backend (world size 1 is all a
     one-GPU box allows; ranks > 1 run under gloo in tests/test_multi_gloo.py): init, all_reduce,
@@ -1505,6 +1623,39 @@ def test_c4_eight_logical_shards_at_hg38_scale(qm2, torch_cuda, hg38_scale):
         hits += s["n_hits"]
         probes += s["n_probes"]
         # owned slots and overhang alike: slot lo + i of the table (the fold of ShardedJob.finish)
+        full[lo:hi] += cnt
+        del cnt
+    assert hits == sd["n_hits"] and probes == sd["n_probes"]
+    assert torch.equal(full, truth)
+    # the same with the senders' 10-bit route: 8 owners x 128 sub-slabs, every shard's 128 sub-slabs are the first level
+    # of its partition (qm2_probe_subslabs_device): one split + count per shard instead of two splits + count
+    del slabs, fill, full
+    torch.cuda.empty_cache()
+    n_subs = 1024 // G
+    mean = n_km / 1024
+    sub_cap = (int(mean * 1.12 + 8 * mean ** 0.5) + 256) & ~1
+    slabs = torch.empty(1024 * sub_cap, dtype=torch.int64, device="cuda")
+    fill = torch.zeros(1024, dtype=torch.int32, device="cuda")
+    call.zero_()
+    torch.cuda.synchronize()
+    with qm2.Counter(None, hash_size=H, k=k, flags=qm2.FLAG_KEYS_LATER, span=(0, 64)) as router:
+        router.route_device(reads.data_ptr(), reads.numel(), slabs.data_ptr(), sub_cap, 1024, fill.data_ptr(), call.data_ptr())
+        router.sync()
+    assert [int(x) for x in call] == [sd["n_bases"], n_km, 0]
+    full = torch.zeros(H, dtype=torch.int32, device="cuda")
+    hits = probes = 0
+    for g, (own_lo, own_hi, lo, hi) in enumerate(spans):
+        cnt = torch.zeros(hi - lo, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr() + 8 * lo, ext_counters=cnt.data_ptr(),
+                         span=(lo, hi), own=(own_lo, own_hi), flags=qm2.FLAG_TIMING) as pc:
+            pc.probe_subslabs_device(slabs.data_ptr() + 8 * g * n_subs * sub_cap, sub_cap, 1, n_subs, fill.data_ptr() + 4 * g * n_subs,
+                                     kmers_bound=n_subs * sub_cap)
+            _, s = pc.finish(want_depth=False)
+            prof = pc.profile()
+        assert prof["partitioned_batches"] == 1 and prof["fallback_batches"] == 0 and prof["class_launches"]["split_kmer"] == 1
+        hits += s["n_hits"]
+        probes += s["n_probes"]
         full[lo:hi] += cnt
         del cnt
     assert hits == sd["n_hits"] and probes == sd["n_probes"]
