@@ -342,8 +342,11 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
         const uint32_t n_parents = (uint32_t)p.buckets[l - 1] * (l == 1 ? p.subs0 : 1u);
         uint32_t lg_subs = 0;
         while ((1u << lg_subs) < p.subs0) lg_subs++;
-        /* ~4 chunks per workgroup so that the prefetch has something to hide behind */
-        const uint32_t chunks = std::max<uint32_t>(1u, ((p.cap[l - 1] + kSplitSlots - 1) / kSplitSlots + 3) / 4);
+        /* ~2 chunks of the parent's CAPACITY per workgroup (a parent is ~2/3 full, so most workgroups take one or two):
+         * C3, 60 M reads per launch, same box: 1 / 2 / 3 / 4 / 8 / 16 -> 25.6 / 24.4 / 24.6 / 25.7-26.4 / 28.4 / 28.3 ms
+         * (profiles/r03_c3/split_kmer_chunks_per_workgroup.txt); no difference at 50 M reads or at chr22 scale */
+        static const uint32_t per_wg = getenv("QM2_SPLIT_CHUNKS_PER_WG") ? std::max(1, atoi(getenv("QM2_SPLIT_CHUNKS_PER_WG"))) : 2u;
+        const uint32_t chunks = std::max<uint32_t>(1u, ((p.cap[l - 1] + kSplitSlots - 1) / kSplitSlots + per_wg - 1) / per_wg);
         if (time_begin(c, &t, QM2_K_SPLIT_KMER)) return 1;
 #define QM2_LAUNCH_LEVEL(SRC_SEG_)                                                                                       \
         hipLaunchKernelGGL((split_kmer_kernel<false, SRC_SEG_, false>), dim3(chunks * n_parents), dim3(kSplitThreads),  \
