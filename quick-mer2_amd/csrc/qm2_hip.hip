@@ -378,7 +378,9 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
          * + 3 sigma of uniform hashing; k-mers per byte measured on earlier batches through an asynchronous
          * copy of the stats block) wastes the fewest rows */
         stats_peek_harvest(c);
-        const uint64_t per_bucket = (uint64_t)((double)src.n_bytes * (src.sv ? c->kmers_per_byte : 1.0 / 1.3)) / n_buckets;
+        /* (before the first snapshot has landed: the caller's hint, against the part of the bytes that can be sequence) */
+        const double kpb = c->peek_bytes ? c->kmers_per_byte : c->kappa_hint * (double)src.n_upper / (double)std::max<uint64_t>(src.n_bytes, 1);
+        const uint64_t per_bucket = (uint64_t)((double)src.n_bytes * (src.sv ? kpb : 1.0 / 1.3)) / n_buckets;
         int g = 4, lw = 3;
         {
             /* loader waves (3 or 4 of the 16) and group size: the fewest rows of 2 k-mers per prober thread that
