@@ -143,14 +143,43 @@ static void *prepare_main(void *arg)
 /* qm2_prepare's partition part beside qm2_keys_from_fd, then the look at the key table's runs of occupied slots */
 static int load_keys_and_prepare(qm2_dict_file *d, qm2_ctx *ctx, uint32_t what, int print)
 {
-    prepare_job job = {ctx, what, 0};
+    /* the thread makes the partition buffers and nothing else: the staging buffers and device batches (made before, by
+     * the QM2_PREPARE_NO_PART call) are what qm2_keys_from_fd streams the dictionary through at this very moment */
+    prepare_job job = {ctx, what & QM2_PREPARE_FASTQ, 0};
     pthread_t th;
     const int threaded = pthread_create(&th, NULL, prepare_main, &job) == 0;
     int rc = qm2_dict_load_keys_quiet(d, ctx, print);
     if (threaded) pthread_join(th, NULL);
-    else job.rc = qm2_prepare(ctx, 0, what);
+    else job.rc = qm2_prepare(ctx, 0, job.what);
     if (rc || job.rc) return 1;
     return qm2_prepare(ctx, 0, what);          /* (everything is there: only the one-off look at the runs is left) */
+}
+
+typedef struct {
+    qm2_dict_file *d;
+    int device, n_strip;
+    uint32_t kmers_per_kib, what;
+    int print;
+    qm2_ctx *ctx;
+    int rc;
+} device_load;
+
+static void *device_load_main(void *arg)
+{
+    device_load *j = arg;
+    qm2_opts o;
+    memset(&o, 0, sizeof o);
+    o.struct_size = sizeof o;
+    o.device = j->device;
+    o.flags = QM2_FLAG_KEYS_LATER | QM2_FLAG_RAW_STRICT;
+    o.n_staging = (uint32_t)j->n_strip + 3;
+    o.kmers_per_kib = j->kmers_per_kib;
+    j->rc = 1;
+    if (qm2_open(&j->ctx, NULL, j->d->hash_size, j->d->k, &o)) return NULL;
+    if (qm2_prepare(j->ctx, 0, j->what | QM2_PREPARE_NO_PART)) return NULL;
+    if (load_keys_and_prepare(j->d, j->ctx, j->what, j->print)) return NULL;
+    j->rc = 0;
+    return NULL;
 }
 
 /* --devices a,b,...: a replica of the dictionary on every listed GPU (the same ordinal may be listed
@@ -175,17 +204,35 @@ static int count_on_devices(qm2_dict_file *d, const char *reads, int n_strip, co
     const char *raw_env = getenv("QM2_READER_RAW");
     int want_raw = regular && n_strip > 0 && !(raw_env && strcmp(raw_env, "0") == 0);
     const uint32_t what = QM2_PREPARE_HOST | (want_raw ? QM2_PREPARE_RAW : 0u) | (want_raw && fastq ? QM2_PREPARE_FASTQ : 0u);
+    /* one loader thread per replica: each reads the .qm through the page cache and feeds its own GPU over its own
+     * PCIe link, so N replicas load in about the time of one (the contexts share nothing but the file descriptor,
+     * read with pread) */
+    device_load jobs[QM2_MAX_DEVICES];
+    pthread_t th[QM2_MAX_DEVICES];
+    int started[QM2_MAX_DEVICES];
+    const uint32_t kpk = regular ? estimate_kmers_per_kib(reads, d->k, fastq) : 0;
+    int distinct = 1;                                          /* (two contexts on ONE GPU load one after the other: the
+                                                                * first takes the partition buffers it needs, the second
+                                                                * what is left, rather than both failing half-way) */
+    for (int i = 0; i < n_dev; i++)
+        for (int j = 0; j < i; j++) distinct &= devices[i] != devices[j];
+    const char *lt = getenv("QM2_LOAD_THREADS");               /* (tests: the threaded loaders on a one-GPU box) */
+    if (lt) distinct = strcmp(lt, "0") != 0;
     for (int i = 0; i < n_dev; i++) {
-        qm2_opts o;
-        memset(&o, 0, sizeof o);
-        o.struct_size = sizeof o;
-        o.device = devices[i];
-        o.flags = QM2_FLAG_KEYS_LATER | QM2_FLAG_RAW_STRICT;
-        o.n_staging = (uint32_t)n_strip + 3;
-        if (regular) o.kmers_per_kib = estimate_kmers_per_kib(reads, d->k, fastq);
-        if (qm2_open(&ctxs[i], NULL, d->hash_size, d->k, &o)) return 1;
-        if (qm2_prepare(ctxs[i], 0, what | QM2_PREPARE_NO_PART)) return 1;
-        if (load_keys_and_prepare(d, ctxs[i], what, i == 0)) return 1;
+        jobs[i] = (device_load){d, devices[i], n_strip, kpk, what, i == 0, NULL, 0};
+        started[i] = distinct && i > 0 && pthread_create(&th[i], NULL, device_load_main, &jobs[i]) == 0;
+    }
+    for (int i = 0; i < n_dev; i++) {
+        if (started[i]) pthread_join(th[i], NULL);
+        else device_load_main(&jobs[i]);                       /* (the first one, and any whose thread did not start) */
+    }
+    int load_rc = 0;
+    for (int i = 0; i < n_dev; i++) {
+        ctxs[i] = jobs[i].ctx;                                 /* (the caller closes what was opened, failed or not) */
+        load_rc |= jobs[i].rc;
+    }
+    if (load_rc) return 1;
+    for (int i = 0; i < n_dev; i++) {
         sinks[i].acquire = out_acquire; sinks[i].commit = out_commit; sinks[i].submit = out_submit;
         sinks[i].flush = out_flush; sinks[i].user = ctxs[i]; sinks[i].commit_raw = out_commit_raw;
         progress_ctx[i] = ctxs[i];

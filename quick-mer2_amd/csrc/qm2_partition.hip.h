@@ -48,7 +48,10 @@ constexpr int kSplitTextBytes = kSplitWaves * kTileBytes;   /* 15872 sequence by
 constexpr int kMaxFan        = 1024;                 /* children per split: hg38-scale tables (20 bucket bits) take 2 levels */
 constexpr uint64_t kPad      = ~0ull;                /* never a k-mer (k <= 31 uses at most 62 bits);
                                                         fills unused input slots                         */
-constexpr int kHalo          = 256;                  /* table slots staged past a bucket's
+#ifndef QM2_HALO
+#define QM2_HALO 256
+#endif
+constexpr int kHalo          = QM2_HALO;             /* table slots staged past a bucket's
                                                         middle-facing edge                      */
 constexpr int kCountThreads  = QM2_COUNT_THREADS;
 #ifndef QM2_COUNT_SET

@@ -184,7 +184,10 @@ def test_cli_devices_two_contexts_sum_to_the_reference(tmp_path):
     small = dict(os.environ, QM2_TURN_BYTES="100000", QM2_BLOCK_BYTES="16384", QM2_TURN_BLOCKS="3", QM2_TIMING="1")
     for tag, reads, devs, thr, env in (("fa", rfa, "0,0", "2", small), ("fq", rfq, "0,0,0", "0", small), ("one", rfq, "0", "4", small),
                                        ("fq_raw", rfq, "0,0,0", "3", small), ("fq_host", rfq, "0,0", "3", dict(small, QM2_READER_RAW="0")),
-                                       ("fq_default_turns", rfq, "0,0", "2", dict(os.environ, QM2_TIMING="1"))):
+                                       ("fq_default_turns", rfq, "0,0", "2", dict(os.environ, QM2_TIMING="1")),
+                                       # (the replicas of distinct GPUs are loaded by one thread each: forced here on the one GPU)
+                                       ("fq_threaded_loaders", rfq, "0,0,0", "3", dict(small, QM2_LOAD_THREADS="1")),
+                                       ("fa_serial_loaders", rfa, "0,0", "2", dict(small, QM2_LOAD_THREADS="0"))):
         out = str(tmp_path / tag)
         r = subprocess.run([CLI, "count", "-t", thr, "--devices", devs, ref_prefix, reads, out], stdout=subprocess.PIPE,
                            timeout=300, env=env)
@@ -579,6 +582,33 @@ def test_skewed_input_spills_and_falls_back(qm2):
         assert st2 == s2 and np.array_equal(depth2, e2), name
     z = ol.zero_slot(keys)
     assert exp_depth[z] == (12000 * 121) % 65536       # k-mer 0 lands on the empty slot (QuicKmer.c:96-98)
+
+
+def test_a_wrong_kmers_per_kib_hint_costs_speed_not_counts(qm2, torch_cuda):
+    """qm2_opts.kmers_per_kib sizes the partition buffers from what the caller expects of its input (the CLI reads it off
+    the head of the file).  It is only a bound on memory: reads that yield more k-mers than announced overflow their
+    buckets into the spill list, and past that the batch is recounted by the direct kernel — the counters and statistics
+    are the oracle's whatever the hint says, and the profile shows which way it went."""
+    torch = torch_cuda
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    keys = qm["keys"]
+    ref = synth.kat_reference().tobytes()
+    rng = np.random.default_rng(11)
+    blob = b"".join(ref[int(p):int(p) + 150] + b"\n" for p in rng.integers(0, 4800, 60000))      # 9 MB, k-mers per byte 0.8
+    exp_depth, exp_st = ol.count_lines(keys, 30, blob)
+    seen = {}
+    for hint in (0, 840, 400, 100, 52):                 # none, right (0.82), half, an eighth, the minimum the library takes
+        with qm2.Counter(keys, k=30, flags=qm2.FLAG_PARTITION | qm2.FLAG_TIMING, kmers_per_kib=hint) as c:
+            c.submit(blob)
+            depth, st = c.finish()
+            pr = c.profile()
+        assert st == exp_st, hint
+        assert np.array_equal(depth, exp_depth), hint
+        assert pr["partitioned_batches"] == 1
+        seen[hint] = (pr["spilled_kmers"], pr["fallback_batches"])
+    assert seen[0] == (0, 0) and seen[840] == (0, 0)                       # a right hint: nothing spills
+    assert seen[400][0] > 0 or seen[400][1] == 1                           # half the room: the spill list (or the recount) takes the rest
+    assert seen[52][1] == 1 or seen[52][0] > 0
 
 
 def test_long_occupied_runs(qm2):
