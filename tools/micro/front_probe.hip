@@ -55,6 +55,30 @@ __global__ __launch_bounds__(1024) void fronts_kernel(uint64_t *buf, uint32_t *c
     }
 }
 
+// The other way round: thread t owns front (rot + t) of the chunk and writes its whole run itself, one k-mer (wide = 1) or
+// two (wide = 2: 16-byte stores; run lengths padded to even, so every run starts 16-byte aligned) per store — every lane
+// of a store instruction in a different 128-byte line, the pieces of a line arriving in consecutive instructions of
+// one wave.  (What a copy-out without the per-element child lookup would look like.)
+template <int WIDE>
+__global__ __launch_bounds__(1024) void lanes_kernel(uint64_t *buf, uint32_t *cursors, Layout L, uint32_t chunks, uint32_t run, uint32_t ragged)
+{
+    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+    for (uint32_t c = 0; c < chunks; c++) {
+        const uint32_t rot = (blockIdx.x * 37u + c * 101u) & 1023u;
+        const uint32_t i = threadIdx.x;
+        const uint32_t raw = run / 2u + ((i * 0x9E3779B1u + c * 0x85EBCA6Bu + blockIdx.x * 0xC2B2AE35u) >> 20) % (run / 2u + 1u);
+        const uint32_t len = ragged ? (raw + ragged - 1u) / ragged * ragged : run;
+        const uint32_t sub = L.mode == 3 ? (blockIdx.x & 7u) << 10 : 0u;
+        const uint32_t f = sub + ((rot + i) & 1023u);
+        const uint32_t base = atomicAdd(&cursors[f], len);
+        uint64_t *dst = buf + place(L, f, base);
+        for (uint32_t e = 0; e < len; e += WIDE) {
+            if (WIDE == 2) *reinterpret_cast<u64x2 *>(dst + e) = u64x2{((uint64_t)f << 32) | e, e + 1u};
+            else dst[e] = ((uint64_t)f << 32) | e;
+        }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int reps = argc > 1 ? atoi(argv[1]) : 2;
@@ -69,7 +93,14 @@ int main(int argc, char **argv)
     OK(hipMalloc((void **)&cur, 32768));
     printf("buffer %p, %.1f GB; %llu k-mers per launch (%.1f GB), cap %llu per front\n", (void *)buf, 1024.0 * cap * 8 / 1e9,
            (unsigned long long)total, total * 8 / 1e9, (unsigned long long)cap);
-    struct { const char *name; Layout L; uint32_t run; uint32_t ragged; } cfg[] = {
+    struct { const char *name; Layout L; uint32_t run; uint32_t ragged; int lanes; } cfg[] = {
+        {"per-XCD RAGGED 8..16 (rows)  ", {3, 0, cap}, 16, 1},
+        {"per-XCD 8..16 lane-per-run 8B", {3, 0, cap}, 16, 1, 1},
+        {"per-XCD 8..16 pad2, rows     ", {3, 0, cap}, 16, 2},
+        {"per-XCD 8..16 pad2, lane 16B ", {3, 0, cap}, 16, 2, 2},
+        {"per-XCD 16..32 (rows)        ", {3, 0, cap}, 32, 1},
+        {"per-XCD 16..32 lane-per-run 8B", {3, 0, cap}, 32, 1, 1},
+        {"per-XCD 16..32 pad2 lane 16B ", {3, 0, cap}, 32, 2, 2},
         {"child-major stride=cap      ", {0, 0, cap}, 16},
         {"child-major stride=cap+64   ", {0, 0, cap + 64}, 16},
         {"child-major stride=cap+1088 ", {0, 0, cap + 1088}, 16},
@@ -109,6 +140,10 @@ int main(int argc, char **argv)
             }
             OK(hipMemset(cur, 0, 32768));
             OK(hipEventRecord(a));
+            // (lane-per-run: a chunk is 1024 runs whatever their length; the k-mers written are counted below)
+            if (c.lanes == 1) hipLaunchKernelGGL(lanes_kernel<1>, dim3(wgs), dim3(1024), 0, 0, buf, cur, c.L, chunks * 16u / c.run, c.run, c.ragged);
+            else if (c.lanes == 2) hipLaunchKernelGGL(lanes_kernel<2>, dim3(wgs), dim3(1024), 0, 0, buf, cur, c.L, chunks * 16u / c.run, c.run, c.ragged);
+            else
             hipLaunchKernelGGL(fronts_kernel, dim3(wgs), dim3(1024), 0, 0, buf, cur, c.L, chunks, c.run, c.ragged);
             OK(hipEventRecord(b));
             OK(hipEventSynchronize(b));
