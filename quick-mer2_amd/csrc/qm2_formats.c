@@ -14,7 +14,9 @@
 
 #include "qm2_host.h"
 
+#ifndef QM2_PIECE_ENTRIES                /* (tests build small pieces: many of them on a small dictionary) */
 #define QM2_PIECE_ENTRIES (1u << 22)    /* (the reference flushes .bin every 2^20 entries, :11, :511; here 8 MiB pieces, in parallel) */
+#endif
 #define QM2_OUT_THREADS 12
 
 /* The loop of :498-516 over the counts in chain order — depth to .bin, and with a .qgc the sums of the GC curve —
