@@ -360,6 +360,20 @@ uint32_t qm2_raw_verdict(qm2_ctx *c);
 int qm2_keys_from_fd(qm2_ctx *c, int fd, uint64_t file_offset);
 int qm2_chain_gather_fd(qm2_ctx *c, int fd, uint64_t file_offset, uint64_t first_idx, uint64_t *n_out);
 
+/* The sums of the GC curve (QuicKmer.c:504-509) over the gathered counts, on the device: the .qgc
+ * (one u16 per dictionary k-mer in chain order: bit 15 = control region, bits 0..8 = GC bin) is read
+ * from `fd` (offset 0) like the two arrays above, and for every control-region entry e with bin b < 401
+ *   cnt[b] += 1,  sum[b] += depth[e],  sumsq[b] += (int32)(depth[e] * depth[e])
+ * — exact 64-bit integers (the reference adds the same numbers into doubles; equal while every partial
+ * sum stays below 2^53), the square wrapped to int32 as the reference's `int` product does (:507).
+ * n_file = entries the file holds; when it is shorter than the gathered counts, entry e >= n_file takes
+ * stale[e mod 2^20] (2^20 values: what the reference's buffer still holds behind the end of the file,
+ * :502-503 never looks at fread's return; the caller works them out).  sum, sumsq, cnt: 401 each.
+ * At hg38 scale (2.27 G entries) this replaces 5 s of host thread time by a 4.5 GB upload. */
+#define QM2_GC_BINS 401
+int qm2_chain_gc_sums_fd(qm2_ctx *c, int fd, uint64_t n_file, const uint16_t *stale,
+                         int64_t *sum, int64_t *sumsq, uint64_t *cnt);
+
 /* Pure host helper (no device needed): the slot range shard g of n_shards
  * OWNS, [*own_lo, *own_hi) = [g*H/G, (g+1)*H/G), and the range it must hold,
  * [*span_lo, *span_hi): the owned range extended on its middle-facing side

@@ -204,6 +204,88 @@ extern "C" int qm2_chain_gather_fd(qm2_ctx *c, int fd, uint64_t file_offset, uin
     return chain_gather(c, nullptr, fd, file_offset, first_idx, n_out);
 }
 
+namespace {
+
+constexpr uint32_t kGcBlock = 1u << 20;      /* entries the reference freads from the .qgc at a time (:11, :502) */
+
+/* QuicKmer.c:504-509 over entries [0, n): workgroup-private sums in LDS (the control k-mers of a genome
+ * crowd into a hundred GC bins: 64-bit LDS atomics take that at a few cycles each), then one global add
+ * per bin and workgroup.  acc = sum[401] | sumsq[401] | cnt[401]. */
+__global__ __launch_bounds__(256) void gc_sums_kernel(const uint16_t *depth, const uint16_t *gc, uint64_t n, uint64_t n_file,
+                                                      const uint16_t *stale, unsigned long long *acc)
+{
+    __shared__ unsigned long long s_sum[QM2_GC_BINS], s_sq[QM2_GC_BINS];
+    __shared__ unsigned int s_cnt[QM2_GC_BINS];          /* (a workgroup sees n / gridDim.x entries: < 2^32) */
+    for (int b = threadIdx.x; b < QM2_GC_BINS; b += blockDim.x) { s_sum[b] = 0; s_sq[b] = 0; s_cnt[b] = 0; }
+    __syncthreads();
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t g = e < n_file ? gc[e] : stale[e & (kGcBlock - 1u)];
+        if (g & 0x8000u) {                                                   /* :504 */
+            const uint32_t b = g & 0x1FFu;
+            if (b < QM2_GC_BINS) {
+                const uint32_t v = depth[e];
+                atomicAdd(&s_sum[b], (unsigned long long)v);                 /* :505 */
+                atomicAdd(&s_cnt[b], 1u);                                    /* :506 */
+                atomicAdd(&s_sq[b], (unsigned long long)(long long)(int32_t)(v * v));   /* :507: an `int` product, wrapped */
+            }
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < QM2_GC_BINS; b += blockDim.x) {
+        if (s_cnt[b] == 0) continue;
+        atomicAdd(&acc[b], s_sum[b]);
+        atomicAdd(&acc[QM2_GC_BINS + b], s_sq[b]);
+        atomicAdd(&acc[2 * QM2_GC_BINS + b], (unsigned long long)s_cnt[b]);
+    }
+}
+
+}  // namespace
+
+extern "C" int qm2_chain_gc_sums_fd(qm2_ctx *c, int fd, uint64_t n_file, const uint16_t *stale,
+                                    int64_t *sum, int64_t *sumsq, uint64_t *cnt)
+{
+    if (!c || !sum || !sumsq || !cnt) return qm2_fail("qm2_chain_gc_sums_fd: null argument");
+    if (!c->gathered) return qm2_fail("qm2_chain_gc_sums_fd: call qm2_chain_gather first");
+    if (fd < 0) return qm2_fail("qm2_chain_gc_sums_fd: bad file descriptor");
+    const uint64_t n = c->n_gathered;
+    if (n_file < n && !stale) return qm2_fail("qm2_chain_gc_sums_fd: a short GC control file needs the stale block");
+    HIP_OK(hipSetDevice(c->device));
+    const uint64_t n_up = std::min(n_file, n);
+    uint16_t *d_gc = nullptr, *d_stale = nullptr;
+    unsigned long long *d_acc = nullptr;
+    int rc = 0;
+    auto release = [&]() { (void)hipFree(d_gc); (void)hipFree(d_stale); (void)hipFree(d_acc); };
+    if (hipMalloc((void **)&d_gc, std::max<uint64_t>(n_up, 1) * sizeof(uint16_t)) != hipSuccess ||
+        hipMalloc((void **)&d_stale, (size_t)kGcBlock * sizeof(uint16_t)) != hipSuccess ||
+        hipMalloc((void **)&d_acc, 3 * QM2_GC_BINS * sizeof(unsigned long long)) != hipSuccess) {
+        release();
+        return qm2_fail("Memory allocation failed");
+    }
+    if (n_up && qm2_stream_fd(c, fd, 0, d_gc, n_up * sizeof(uint16_t), "GC control file")) { release(); return 1; }
+    hipStream_t s = c->stream;
+    std::vector<unsigned long long> acc(3 * QM2_GC_BINS);
+    if (hipMemsetAsync(d_acc, 0, acc.size() * sizeof(unsigned long long), s) != hipSuccess ||
+        (stale ? hipMemcpyAsync(d_stale, stale, (size_t)kGcBlock * sizeof(uint16_t), hipMemcpyHostToDevice, s)
+               : hipMemsetAsync(d_stale, 0, (size_t)kGcBlock * sizeof(uint16_t), s)) != hipSuccess)
+        rc = qm2_fail("qm2_chain_gc_sums_fd: upload failed");
+    if (!rc && n) {
+        const int grid = (int)std::min<uint64_t>((n + 255) / 256, (uint64_t)c->n_cu * 8);
+        hipLaunchKernelGGL(gc_sums_kernel, dim3(grid), dim3(256), 0, s, c->gathered, d_gc, n, n_up, d_stale, d_acc);
+        if (hipGetLastError() != hipSuccess) rc = qm2_fail("qm2_chain_gc_sums_fd: launch failed");
+    }
+    if (!rc && (hipMemcpyAsync(acc.data(), d_acc, acc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess))
+        rc = qm2_fail("qm2_chain_gc_sums_fd: the sums did not come back (%s)", hipGetErrorString(hipGetLastError()));
+    release();
+    if (rc) return rc;
+    for (int b = 0; b < QM2_GC_BINS; b++) {
+        sum[b] = (int64_t)acc[b];
+        sumsq[b] = (int64_t)acc[QM2_GC_BINS + b];
+        cnt[b] = (uint64_t)acc[2 * QM2_GC_BINS + b];
+    }
+    return 0;
+}
+
 extern "C" int qm2_chain_fetch(qm2_ctx *c, uint16_t *out, uint64_t offset, uint64_t count)
 {
     if (!c || !out) return qm2_fail("qm2_chain_fetch: null argument");

@@ -19,27 +19,32 @@
 #endif
 #define QM2_OUT_THREADS 12
 
-/* The loop of :498-516 over the counts in chain order — depth to .bin, and with a .qgc the sums of the GC curve —
- * split into pieces that worker threads take in turn: fetch from the device, pread the piece's GC values, add up,
- * pwrite.  At hg38 scale the serial loop took 7 s with a .qgc (2.27 G entries through fread / fwrite and one
- * branchy accumulation each), most of a small run.  The sums are kept in 64-bit integers and converted at the end:
- * the reference adds into doubles, which is the same number as long as every partial sum is below 2^53 (SURVEY
+/* The loop of :498-516 over the counts in chain order, split in two.  Depth to .bin: pieces that worker threads take
+ * in turn (fetch from the device, pwrite).  The sums of the GC curve (:504-509): on the device, where the counts
+ * are (qm2_chain_gc_sums_fd: the .qgc goes up like the chain did, 4.5 GB at hg38 scale), while the workers write.
+ * (Round 2 did the sums in the workers: 5.2 s of thread time of the 6.3 s the whole loop took at hg38 scale, 1.2 - 1.4 s
+ * on 12 threads; the serial loop of the reference's shape: 7 s.)  The sums are exact 64-bit integers, converted at the
+ * end: the reference adds into doubles, which is the same number as long as every partial sum is below 2^53 (SURVEY
  * Appendix B.9: depths would have to average > 4 x 10^6 over a GC bin for that to fail). */
 #define QM2_GC_BLOCK (1u << 20)          /* entries the reference freads from the .qgc at a time (buffer_size, :11, :502-503) */
 enum { QM2_OUT_OK = 0, QM2_OUT_ALLOC, QM2_OUT_FETCH, QM2_OUT_QGC, QM2_OUT_WRITE };
 
 typedef struct {
     qm2_ctx   *ctx;
-    int        bin_fd, qgc_fd;                  /* qgc_fd < 0: no .qgc */
+    int        bin_fd;
     uint64_t   n_entries;
-    uint64_t   n_qgc;                           /* entries the .qgc file really holds */
-    uint16_t  *stale;                           /* what the reference's gc_control[] holds once the file has run out (below) */
     uint64_t   next;                            /* next piece to hand out (under `lock`) */
     int        failed;                          /* QM2_OUT_*: what went wrong first */
     pthread_mutex_t lock;
-    int64_t    sum[401], sumsq[401];
-    uint64_t   cnt[401];
+    double     t_fetch, t_write;                /* seconds, summed over the workers (QM2_TIMING) */
 } out_job;
+
+static double out_now(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
 
 static int pread_all(int fd, void *buf, size_t n, uint64_t off, size_t *got_out)
 {
@@ -60,27 +65,29 @@ static int pread_all(int fd, void *buf, size_t n, uint64_t off, size_t *got_out)
  * earlier reads left in it.  With n entries in the file, F = n / 2^20 full blocks and r = n % 2^20: entry e >= n reads
  * position p = e % 2^20 of that array, which holds file entry F * 2^20 + p if p < r (the last, partial read), else
  * file entry (F - 1) * 2^20 + p (the last full block).  With F = 0 the rest of the array is the reference's
- * uninitialised stack: taken as zeros here (the one deliberate difference, on an input the reference leaves undefined). */
-static int stale_block(out_job *j)
+ * uninitialised stack: taken as zeros here (the one deliberate difference, on an input the reference leaves undefined).
+ * -> the 2^20 values, or NULL (*bad says why). */
+static uint16_t *stale_block(int qgc_fd, uint64_t n_qgc, int *bad)
 {
-    const uint64_t B = QM2_GC_BLOCK, F = j->n_qgc / B, r = j->n_qgc % B;
-    j->stale = calloc(B, sizeof(uint16_t));
-    if (!j->stale) return QM2_OUT_ALLOC;
+    const uint64_t B = QM2_GC_BLOCK, F = n_qgc / B, r = n_qgc % B;
+    uint16_t *stale = calloc(B, sizeof(uint16_t));
+    if (!stale) { *bad = QM2_OUT_ALLOC; return NULL; }
     size_t got = 0;
-    if (F && pread_all(j->qgc_fd, j->stale, B * sizeof(uint16_t), (F - 1) * B * sizeof(uint16_t), &got)) return QM2_OUT_QGC;
-    if (r && pread_all(j->qgc_fd, j->stale, r * sizeof(uint16_t), F * B * sizeof(uint16_t), &got)) return QM2_OUT_QGC;
-    return QM2_OUT_OK;
+    if ((F && pread_all(qgc_fd, stale, B * sizeof(uint16_t), (F - 1) * B * sizeof(uint16_t), &got)) ||
+        (r && pread_all(qgc_fd, stale, r * sizeof(uint16_t), F * B * sizeof(uint16_t), &got))) {
+        free(stale);
+        *bad = QM2_OUT_QGC;
+        return NULL;
+    }
+    return stale;
 }
 
 static void *out_worker(void *arg)
 {
     out_job *j = arg;
     uint16_t *out = malloc(QM2_PIECE_ENTRIES * sizeof(uint16_t));
-    uint16_t *gc = j->qgc_fd >= 0 ? malloc(QM2_PIECE_ENTRIES * sizeof(uint16_t)) : NULL;
-    int64_t sum[401], sumsq[401];
-    uint64_t cnt[401];
-    memset(sum, 0, sizeof sum); memset(sumsq, 0, sizeof sumsq); memset(cnt, 0, sizeof cnt);
-    int bad = !out || (j->qgc_fd >= 0 && !gc) ? QM2_OUT_ALLOC : QM2_OUT_OK;
+    int bad = !out ? QM2_OUT_ALLOC : QM2_OUT_OK;
+    double t_fetch = 0, t_write = 0;
     while (!bad) {
         pthread_mutex_lock(&j->lock);
         const uint64_t at = j->next;
@@ -89,31 +96,10 @@ static void *out_worker(void *arg)
         pthread_mutex_unlock(&j->lock);
         if (stop) break;
         const uint64_t m = j->n_entries - at < QM2_PIECE_ENTRIES ? j->n_entries - at : QM2_PIECE_ENTRIES;
+        const double t0 = out_now();
         if (qm2_chain_fetch(j->ctx, out, at, m)) { bad = QM2_OUT_FETCH; break; }
-        if (gc) {
-            /* :502-503: the piece's GC values; behind the end of a short .qgc, what the reference's array still holds */
-            const uint64_t have = at >= j->n_qgc ? 0 : (j->n_qgc - at < m ? j->n_qgc - at : m);
-            size_t got = 0;
-            if (have && (pread_all(j->qgc_fd, gc, have * sizeof(uint16_t), at * sizeof(uint16_t), &got) || got != have * sizeof(uint16_t))) {
-                bad = QM2_OUT_QGC;
-                break;
-            }
-            for (uint64_t i = have; i < m; i++) gc[i] = j->stale[(at + i) & (QM2_GC_BLOCK - 1)];
-            for (uint64_t i = 0; i < m; i++) {
-                const uint16_t gcv = gc[i];
-                if (gcv & 0x8000) {                          /* control-region k-mer (:504) */
-                    const uint32_t b = gcv & 0x1FF;
-                    if (b < 401) {
-                        const uint16_t v = out[i];
-                        sum[b] += v;
-                        cnt[b]++;
-                        /* the reference squares a promoted uint16 in `int` (:507): above 46340 that overflows, and
-                         * what its build does is wrap; pinned here without the undefined behaviour */
-                        sumsq[b] += (int32_t)((uint32_t)v * (uint32_t)v);
-                    }
-                }
-            }
-        }
+        const double t1 = out_now();
+        t_fetch += t1 - t0;
         size_t put = 0;                                                        /* :512, :517 */
         while (put < m * sizeof(uint16_t)) {
             const ssize_t n = pwrite(j->bin_fd, (const char *)out + put, m * sizeof(uint16_t) - put, (off_t)(at * sizeof(uint16_t) + put));
@@ -121,12 +107,13 @@ static void *out_worker(void *arg)
             if (n <= 0) { bad = QM2_OUT_WRITE; break; }
             put += (size_t)n;
         }
+        t_write += out_now() - t1;
     }
     pthread_mutex_lock(&j->lock);
+    j->t_fetch += t_fetch; j->t_write += t_write;
     if (bad && !j->failed) j->failed = bad;
-    for (int b = 0; b < 401; b++) { j->sum[b] += sum[b]; j->sumsq[b] += sumsq[b]; j->cnt[b] += cnt[b]; }
     pthread_mutex_unlock(&j->lock);
-    free(out); free(gc);
+    free(out);
     return NULL;
 }
 
@@ -230,43 +217,63 @@ int qm2_write_outputs(qm2_dict_file *d, qm2_ctx *ctx, const char *ref_prefix, co
 
     double sum[401], sumsq[401];
     uint32_t cnt[401];
+    memset(sum, 0, sizeof sum); memset(sumsq, 0, sizeof sumsq); memset(cnt, 0, sizeof cnt);
     int rc = 0, n_th = 0;
+    double t_sums = 0;
     {
         out_job job;
         memset(&job, 0, sizeof job);
         job.ctx = ctx;
         job.bin_fd = fileno(bin);
-        job.qgc_fd = qgc ? fileno(qgc) : -1;
         job.n_entries = n_entries;
-        job.n_qgc = n_entries;
-        if (qgc) {
-            struct stat gsb;
-            if (fstat(job.qgc_fd, &gsb) == 0 && S_ISREG(gsb.st_mode) && (uint64_t)gsb.st_size / sizeof(uint16_t) < n_entries) {
-                job.n_qgc = (uint64_t)gsb.st_size / sizeof(uint16_t);
-                job.failed = stale_block(&job);
-            }
-        }
+        /* (4.5 GB at hg38 scale: 1.2 s, the rate at which ONE file takes buffered writes — twelve threads calling pwrite
+         * take turns at its inode lock; mapping the file and fetching straight into the mapping was measured the same,
+         * 1.12 s: the page cache of one file fills at ~4 GB/s either way) */
         pthread_mutex_init(&job.lock, NULL);
         pthread_t th[QM2_OUT_THREADS];
         const uint64_t pieces = (n_entries + QM2_PIECE_ENTRIES - 1) / QM2_PIECE_ENTRIES;
-        while (!job.failed && n_th < QM2_OUT_THREADS && (uint64_t)n_th < pieces && pthread_create(&th[n_th], NULL, out_worker, &job) == 0) n_th++;
-        if (n_th == 0 && !job.failed) out_worker(&job);                        /* no thread to be had: this one */
+        while (n_th < QM2_OUT_THREADS && (uint64_t)n_th < pieces && pthread_create(&th[n_th], NULL, out_worker, &job) == 0) n_th++;
+        /* the GC sums meanwhile, on the device */
+        int gc_bad = QM2_OUT_OK;
+        if (qgc) {
+            const double t_a = out_now();
+            const int qgc_fd = fileno(qgc);
+            uint64_t n_qgc = n_entries;
+            uint16_t *stale = NULL;
+            struct stat gsb;
+            if (fstat(qgc_fd, &gsb) == 0 && S_ISREG(gsb.st_mode) && (uint64_t)gsb.st_size / sizeof(uint16_t) < n_entries) {
+                n_qgc = (uint64_t)gsb.st_size / sizeof(uint16_t);
+                stale = stale_block(qgc_fd, n_qgc, &gc_bad);
+            }
+            if (!gc_bad) {
+                int64_t isum[401], isq[401];
+                uint64_t icnt[401];
+                /* (a failure has printed its reason itself: qm2_last_error) */
+                if (qm2_chain_gc_sums_fd(ctx, qgc_fd, n_qgc, stale, isum, isq, icnt)) gc_bad = QM2_OUT_QGC;
+                else for (int b = 0; b < 401; b++) { sum[b] = (double)isum[b]; sumsq[b] = (double)isq[b]; cnt[b] = (uint32_t)icnt[b]; }
+            }
+            free(stale);
+            t_sums = out_now() - t_a;
+        }
+        if (n_th == 0) out_worker(&job);                                        /* no thread to be had: this one */
         for (int t = 0; t < n_th; t++) pthread_join(th[t], NULL);
         pthread_mutex_destroy(&job.lock);
-        free(job.stale);
+        if (!job.failed) job.failed = gc_bad;
         if (job.failed) {
             /* (a failed qm2_chain_fetch has printed the HIP error itself: qm2_last_error) */
             puts(job.failed == QM2_OUT_ALLOC ? "Memory allocation failed" : job.failed == QM2_OUT_FETCH ? "Fetching the counts from the device failed"
                  : job.failed == QM2_OUT_QGC ? "Reading the GC control file failed" : "Write to .bin failed");
             rc = 1;
         }
-        for (int b = 0; b < 401; b++) { sum[b] = (double)job.sum[b]; sumsq[b] = (double)job.sumsq[b]; cnt[b] = (uint32_t)job.cnt[b]; }
+        if (getenv("QM2_TIMING"))
+            printf("QM2 epilogue workers (seconds summed over %d threads): fetch %.3f, .bin write %.3f; GC sums on the device beside them %.3f s\n",
+                   n_th ? n_th : 1, job.t_fetch, job.t_write, t_sums);
     }
     if (fclose(bin) != 0 && !rc) { puts("Write to .bin failed"); rc = 1; }
     clock_gettime(CLOCK_MONOTONIC, &t2);
     if (getenv("QM2_TIMING"))
         printf("QM2 epilogue: chain file -> device + list ranking %.3f s, .bin%s on %d threads %.3f s\n",
-               (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec), qgc ? " + GC sums" : "", n_th ? n_th : 1,
+               (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec), qgc ? " (+ GC sums on the device)" : "", n_th ? n_th : 1,
                (t2.tv_sec - t1.tv_sec) + 1e-9 * (t2.tv_nsec - t1.tv_nsec));
     if (rc) { if (qgc) fclose(qgc); free(path); return 1; }
 

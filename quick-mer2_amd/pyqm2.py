@@ -56,7 +56,7 @@ class Dup(C.Structure):
 # every symbol include/qm2.h and include/qm2_tools.h declare
 ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_probe_slabs_device", "qm2_probe_subslabs_device", "qm2_route_xcd_device", "qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
-               "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_submit_raw_device", "qm2_staging_commit_raw", "qm2_raw_verdict",
+               "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_chain_gc_sums_fd", "qm2_submit_raw_device", "qm2_staging_commit_raw", "qm2_raw_verdict",
                "qm2_shard_span", "qm2_last_error",
                "qm2_abi_version"]
 TOOL_SYMBOLS = ["qm2t_genome_generate", "qm2t_dict_build", "qm2t_reads_generate",
@@ -140,6 +140,8 @@ def lib():
     L.qm2_keys_from_fd.argtypes = [vp, C.c_int, u64]
     L.qm2_chain_gather_fd.restype = C.c_int
     L.qm2_chain_gather_fd.argtypes = [vp, C.c_int, u64, u64, C.POINTER(u64)]
+    L.qm2_chain_gc_sums_fd.restype = C.c_int
+    L.qm2_chain_gc_sums_fd.argtypes = [vp, C.c_int, u64, vp, vp, vp, vp]
     L.qm2_chain_fetch.restype = C.c_int
     L.qm2_chain_fetch.argtypes = [vp, vp, u64, u64]
     L.qm2_shard_span.restype = C.c_int
@@ -348,6 +350,16 @@ class Counter:
         if len(out):
             _check(lib().qm2_chain_fetch(self._h, out.ctypes.data, 0, len(out)), "qm2_chain_fetch")
         return out
+
+    def chain_gc_sums_fd(self, fd, n_file, stale=None):
+        """The GC curve's sums over the gathered counts (QuicKmer.c:504-509): -> (sum, sumsq, cnt), int64/int64/uint64 [401]."""
+        s, q, c = np.zeros(401, np.int64), np.zeros(401, np.int64), np.zeros(401, np.uint64)
+        if stale is not None:
+            stale = np.ascontiguousarray(stale, dtype=np.uint16)
+            assert len(stale) == 1 << 20
+        _check(lib().qm2_chain_gc_sums_fd(self._h, int(fd), int(n_file), stale.ctypes.data if stale is not None else None,
+                                          s.ctypes.data, q.ctypes.data, c.ctypes.data), "qm2_chain_gc_sums_fd")
+        return s, q, c
 
     def profile(self):
         p = Profile()

@@ -1256,6 +1256,47 @@ def test_chain_gather_matches_reference_bin(qm2, tmp_path):
             assert out.tobytes() == exp, (setname, reads_name)
 
 
+def test_gc_sums_on_the_device(qm2, tmp_path):
+    """qm2_chain_gc_sums_fd (QuicKmer.c:504-509 on the device) against the loop written out in numpy: the reference's
+    .qgc; a .qgc that marks EVERY k-mer as control over deep counts (50 000^2 does not fit the reference's `int`
+    product, :507: wrapped); bins >= 401 ignored; a file cut short, where the entries behind its end take the values the
+    reference's 2^20-entry buffer still holds (the stale block; the CLI run against the reference itself pins the rule)."""
+    qm = kat_qm()
+    cases = synth.kat_cases(synth.kat_reference())
+    rng = np.random.default_rng(3)
+    for reads_name in ("reads_fa", "deep50000"):
+        p = tmp_path / (reads_name + ".fa")
+        p.write_bytes(cases[reads_name][1])
+        lines = ol.strip_reads(str(p))
+        with qm2.Counter(qm["keys"], k=qm["k"]) as c:
+            c.submit(lines)
+            depth = c.chain_gather(qm["chain"], qm["first"])
+            n = len(depth)
+            assert depth.tobytes() == open(os.path.join(GOLD, "kat", reads_name + ".bin"), "rb").read()
+            ref_qgc = np.fromfile(os.path.join(GOLD, "kat", "ref.fa.qgc"), dtype=np.uint16)
+            all_ctrl = (((np.arange(n) * 7) % 512) | 0x8000).astype(np.uint16)      # bins 0..511: 401.. are skipped (the deep k-mer, entry 1000: bin 344)
+            stale = rng.integers(0, 1 << 16, 1 << 20).astype(np.uint16)
+            for tag, gc, n_file in (("reference", ref_qgc, n), ("all control", all_ctrl, n), ("cut short", all_ctrl, n // 3),
+                                    ("empty file", all_ctrl, 0), ("longer file", np.concatenate([ref_qgc, ref_qgc]), 2 * n)):
+                f = tmp_path / "x.qgc"
+                gc[:n_file].tofile(str(f))
+                with open(str(f), "rb") as fh:
+                    s_, q_, c_ = c.chain_gc_sums_fd(fh.fileno(), n_file, stale if n_file < n else None)
+                eff = np.where(np.arange(n) < n_file, gc[:n] if len(gc) >= n else np.resize(gc, n), stale[np.arange(n) & ((1 << 20) - 1)])
+                ctrl = ((eff & 0x8000) != 0) & ((eff & 0x1FF) < 401)
+                b = (eff & 0x1FF)[ctrl].astype(np.int64)
+                v = depth[ctrl].astype(np.int64)
+                sq = ((v * v) & 0xFFFFFFFF).astype(np.uint32).view(np.int32).astype(np.int64)      # the `int` product, wrapped
+                assert (c_ == np.bincount(b, minlength=401).astype(np.uint64)).all(), (reads_name, tag)
+                assert (s_ == np.array([v[b == i].sum() for i in range(401)])).all(), (reads_name, tag)
+                assert (q_ == np.array([sq[b == i].sum() for i in range(401)])).all(), (reads_name, tag)
+                if reads_name == "deep50000" and tag == "all control":
+                    assert (sq < 0).any() and (v > 46340).any()                    # the wrap really happens
+            with pytest.raises(qm2.Qm2Error):
+                with open(str(f), "rb") as fh:
+                    c.chain_gc_sums_fd(fh.fileno(), 0, None)                         # short file, no stale block
+
+
 def test_chain_gather_large_random_cycle(qm2, torch_cuda):
     """2^24-slot table, ~6 M keys chained in a random order; ext_keys (the table survives)."""
     torch = torch_cuda

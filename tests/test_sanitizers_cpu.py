@@ -4,7 +4,7 @@ ThreadSanitizer and with AddressSanitizer + UBSan and driven over FASTA / FASTQ 
 thread counts, both hand-overs (stripped lines, raw blocks in turns); and tools/qm2_mkdict.c under ASan + UBSan on the
 dictionaries the reference wrote (incl. the growth at 80 % fill), `est` (qm2_est.c) on the reference's KAT counts, and the
 threaded .bin / GC-curve loop of the epilogue (qm2_formats.c) under both, fed the reference's own counts through stand-ins
-for the three device calls it makes.  A report from a sanitizer fails the test; so does
+for the device calls it makes.  A report from a sanitizer fails the test; so does
 output that differs from the oracle's strip / the reference's files."""
 import json
 import os
@@ -196,6 +196,7 @@ EPILOGUE = r'''
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include "qm2.h"
 #include "qm2_host.h"
 /* stand-ins for the device: the counts in chain order ARE the reference's .bin */
@@ -203,6 +204,14 @@ static uint16_t *BIN; static uint64_t N;
 int qm2_chain_gather_fd(qm2_ctx *c, int fd, uint64_t off, uint64_t first, uint64_t *n_out) { (void)c; (void)fd; (void)off; (void)first; *n_out = N; return 0; }
 int qm2_chain_fetch(qm2_ctx *c, uint16_t *out, uint64_t offset, uint64_t count) { (void)c; if (offset + count > N) return 1; memcpy(out, BIN + offset, count * 2); return 0; }
 int qm2_keys_from_fd(qm2_ctx *c, int fd, uint64_t off) { (void)c; (void)fd; (void)off; return 1; }
+/* (the device's sums, QuicKmer.c:504-509, serially: what the kernel is compared with on the GPU box is the reference's .txt) */
+int qm2_chain_gc_sums_fd(qm2_ctx *c, int fd, uint64_t n_file, const uint16_t *stale, int64_t *sum, int64_t *sumsq, uint64_t *cnt) { (void)c;
+  memset(sum, 0, 401 * 8); memset(sumsq, 0, 401 * 8); memset(cnt, 0, 401 * 8);
+  FILE *f = fdopen(dup(fd), "rb"); if (!f) return 1; rewind(f);
+  for (uint64_t e = 0; e < N; e++) { uint16_t g;
+    if (e < n_file) { if (fread(&g, 2, 1, f) != 1) { fclose(f); return 1; } } else { if (!stale) { fclose(f); return 1; } g = stale[e & 0xFFFFF]; }
+    if ((g & 0x8000) && (g & 0x1FF) < 401) { const uint32_t v = BIN[e]; sum[g & 0x1FF] += v; cnt[g & 0x1FF]++; sumsq[g & 0x1FF] += (int32_t)(v * v); } }
+  fclose(f); return 0; }
 int main(int argc, char **argv) {      /* ref prefix, reference .bin, out prefix */
   if (argc < 4) return 9;
   FILE *f = fopen(argv[2], "rb"); if (!f) return 8;
