@@ -882,7 +882,9 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                 const bool cand = lm[j] <= le[j];
                 /* (lm <= kWinLast: a real fingerprint match — with none, slot c holds a key of another fingerprint,
                  *  or, in a slice cut short by its span, whatever the buffer held before) */
-                const bool hit = on && cand && lm[j] <= kWinLast && vv[j] == km[j];   /* :98 */
+                /* (& and not &&: with && hipcc sinks the first key read of a set into the branch and waits for it there,
+                 *  one exposed LDS round trip per set: bucket_count 26.2 -> 25.5 ms at C3) */
+                const bool hit = on & cand & (lm[j] <= kWinLast) & (vv[j] == km[j]);  /* :98 */
                 atomicAdd(&bcnt[pp[j] + c], hit ? 1u : 0u);                 /* :291 */
                 w_hits_a += __popcll(__ballot(hit));
                 /* slots inspected = (first flagged bit >> 3) + 1, and a flagged bit is 8 c + 7: summed as bit + 1,
