@@ -294,6 +294,30 @@ __device__ __forceinline__ void copy_store(const SplitLds &L, uint64_t km, const
     }
 }
 
+/* copy_store in two halves as well: the child's {offset, limit} is asked for early (copy_lookup) and used late
+ * (copy_finish), with the k-mer's own work of the chunk loop in between — as one piece, the LDS read and the wait for
+ * it sit back to back, one exposed round trip per k-mer of every lane */
+__device__ __forceinline__ uint64_t copy_lookup(const SplitLds &L, uint64_t km, uint32_t shift, uint32_t bits, uint32_t &child)
+{
+    child = child_of(km, shift, bits);
+    return *reinterpret_cast<const uint64_t *>(&L.dl[child]);
+}
+
+template <int PIECE, bool SEG>
+__device__ __forceinline__ void copy_finish(uint64_t km, uint32_t child, uint64_t dlw, const SplitDst &d, uint64_t child0)
+{
+    const uint32_t i = threadIdx.x + PIECE * kSplitThreads;
+    const uint32_t dx = (uint32_t)dlw, dy = (uint32_t)(dlw >> 32);
+    typedef uint64_t __attribute__((address_space(1))) global_u64;
+    if constexpr (SEG) {
+        global_u64 *dst = (global_u64 *)(uintptr_t)d.kmers;
+        if (i < dy) dst[slot_of<true>(child0 + child, i + dx, d.cap, d.lg_row)] = km;
+    } else {
+        global_u64 *dst = (global_u64 *)(uintptr_t)(d.kmers + (child0 + child) * (uint64_t)d.cap);
+        if (i < dy) dst[i + dx] = km;
+    }
+}
+
 template <int PIECE, bool SEG>
 __device__ __forceinline__ void copy_piece(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
 {
@@ -343,14 +367,21 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
         QM2_STAMP(17);
         uint64_t km[kKpt];
         uint32_t tag[kKpt];
-        /* k-mer J of this chunk, then copy-out piece J of the previous chunk */
+        /* k-mer J of this chunk between the two halves of copy-out piece J of the previous chunk (split_text 21.96 -> 21.56 ms at C3
+         * against lookup and use back to back) */
+        uint64_t out = pend ? copy_fetch<0>(L) : 0;
 #define QM2_T(J)                                                                   \
         {                                                                          \
-            const uint64_t out = pend ? copy_fetch<J>(L) : 0;    /* (its LDS latency hides behind the k-mer's own work) */ \
+            /* piece J + 1 is fetched a step ahead; piece J's child is looked up before the k-mer's own work and used behind it */ \
+            const uint64_t out_next = pend ? copy_fetch<(J + 1 < kKpt ? J + 1 : J)>(L) : 0; \
+            uint32_t oc = 0;                                                       \
+            const uint64_t dlw = pend ? copy_lookup(L, out, shift, bits, oc) : 0;  \
             km[J] = kmer_at<K30, J>(W, k);                                         \
+            /* (a select without the branch around the hash was measured: no difference) */ \
             const uint32_t b = (W.emit & (0x8000u >> J)) ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | atomicAdd(&L.hist[b], 1u);      /* (a count: < 2^15) */ \
-            if (pend) copy_store<J, SEG>(L, out, d, child0, shift, bits);          \
+            if (pend) copy_finish<J, SEG>(out, oc, dlw, d, child0);                \
+            out = out_next;                                                        \
         }
         QM2_T(0) QM2_T(1) QM2_T(2) QM2_T(3) QM2_T(4) QM2_T(5) QM2_T(6) QM2_T(7)
         QM2_T(8) QM2_T(9) QM2_T(10) QM2_T(11) QM2_T(12) QM2_T(13) QM2_T(14) QM2_T(15)
@@ -443,12 +474,16 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
             km[2 * j + 1] = at + 1 < n ? ((uint64_t)nxt[j].w << 32) | nxt[j].z : kPad;   /* (an odd fill: the pair's second half is stale) */
         }
         fetch(first + (uint64_t)wgs_per_parent * kSplitSlots);
+        uint64_t out = pend ? copy_fetch<0>(L) : 0;
 #define QM2_K(J)                                                                   \
         {                                                                          \
-            const uint64_t out = pend ? copy_fetch<J>(L) : 0;                      \
+            const uint64_t out_next = pend ? copy_fetch<(J + 1 < kKpt ? J + 1 : J)>(L) : 0; \
+            uint32_t oc = 0;                                                       \
+            const uint64_t dlw = pend ? copy_lookup(L, out, shift, bits, oc) : 0;  \
             const uint32_t b = km[J] != kPad ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | atomicAdd(&L.hist[b], 1u);      /* (a count: < 2^15) */ \
-            if (pend) copy_store<J, DST_SEG>(L, out, d, child0, shift, bits);      \
+            if (pend) copy_finish<J, DST_SEG>(out, oc, dlw, d, child0);            \
+            out = out_next;                                                        \
         }
         QM2_K(0) QM2_K(1) QM2_K(2) QM2_K(3) QM2_K(4) QM2_K(5) QM2_K(6) QM2_K(7)
         QM2_K(8) QM2_K(9) QM2_K(10) QM2_K(11) QM2_K(12) QM2_K(13) QM2_K(14) QM2_K(15)
