@@ -338,16 +338,21 @@ __device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, u
  * the home slot.  One chunk = 16 tiles (one per wave). */
 /* `call` (qm2_route_device): the launch's totals {bases, k-mers, k-mers that fitted nowhere} go there
  * instead of into the context's statistics. */
-template <bool K30, bool SEG>
+/* FX: 0, or (shift << 8 | bits) as compile-time constants — the split of an hg38-scale table (H = 2^32: 10 + 10 bucket
+ * bits above 12 slot bits).  v_bfe_u32 takes one scalar operand; with both in SGPRs hipcc moves one into a VGPR in
+ * front of EVERY hash (it has no register to keep it in): two instructions per k-mer. */
+template <bool K30, bool SEG, uint32_t FX = 0>
 __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_kernel(SeqView sv, uint32_t k, uint32_t shift, uint32_t bits,
                                                                    uint64_t n_chunks, SplitDst d, DevStats *stats,
                                                                    unsigned long long *call)
 {
+    if constexpr (FX != 0) { shift = FX >> 8; bits = FX & 0xFFu; }
     const uint32_t fan = 1u << bits;
     __shared__ SplitLds L;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     unsigned long long n_bases = 0, n_kmers = 0, lost = 0;
-    bool pend = false;
+    bool pend = false;          /* (tested per step; running the first chunk's copy-out over an all-refusing L.dl instead, no test:
+                                 *  split_text 21.4 -> 23.0 ms, split_kmer 24.6 -> 27.3: hipcc schedules the longer blocks worse) */
     const uint64_t child0 = sub_region0(d, fan);
     /* the 16 bytes of this lane for the NEXT chunk are fetched while the current one is processed */
     uint4 bytes = load16_raw(sv, lane_offset(((uint64_t)blockIdx.x * kSplitWaves + wave) * kTileBytes, lane));
@@ -416,12 +421,13 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
  * takes its chunks x, x + wgs_per_parent, ...
  * FLAT (level 1 of a shard, qm2_probe_slabs_device): the parents are the slabs a shard received from its
  * peers — src_cap apart, src_cursors[slab] k-mers in each — and they all feed the same children 0 .. fan-1. */
-template <bool FLAT, bool SRC_SEG, bool DST_SEG>
+template <bool FLAT, bool SRC_SEG, bool DST_SEG, uint32_t FX = 0>
 __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_kernel(const uint64_t *src, const uint32_t *src_cursors,
                                                                    uint64_t src_cap, uint32_t src_lg_row, uint32_t parent_mask, uint32_t shift, uint32_t bits,
                                                                    uint32_t wgs_per_parent, uint32_t n_parents,
                                                                    SplitDst d, DevStats *stats, uint32_t src_peer_stride = 0)
 {
+    if constexpr (FX != 0) { shift = FX >> 8; bits = FX & 0xFFu; }
     const uint32_t fan = 1u << bits;
     __shared__ SplitLds L;
     /* Block -> (parent, x).  Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one, each
