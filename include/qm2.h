@@ -24,6 +24,7 @@
  *   "total %lu kmers" bookkeeping, :445, :481           qm2_stats
  *   progress line every 2^30 k-mers, :446               qm2_stats_peek
  *   chain read + walk -> depth in genome order, :483-516  qm2_chain_gather(_fd) / qm2_chain_fetch
+ *   GC-curve sums over the control k-mers, :501-509     qm2_chain_gc_sums_fd
  *   free, :519-520                                      qm2_close
  *
  * Plain C types only: no torch / HIP types cross this boundary (device
