@@ -55,7 +55,9 @@ def main():
             buf[where] = line
         return buf.view(-1)
 
-    ctx = pyqm2.Counter(None, hash_size=H, k=k, device=0, flags=pyqm2.FLAG_TIMING, ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr())
+    # (HH_KPK: the k-mers-per-KiB hint bench.py and the CLI give, 0.8 x 1024 for 150-base reads; 0 = none: buffers for one k-mer per byte)
+    ctx = pyqm2.Counter(None, hash_size=H, k=k, device=0, flags=pyqm2.FLAG_TIMING, ext_keys=keys.data_ptr(), ext_counters=counters.data_ptr(),
+                        kmers_per_kib=int(os.environ.get("HH_KPK", "824")))
     ctx.prepare(nbytes)
     only = os.environ.get("HH_ONLY")
     for name, args in (("uniform reads", (0, 0, 0)), ("5 % of the reads from 1000 families", (0.05, 1000, 0)),
