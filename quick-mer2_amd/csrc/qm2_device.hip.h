@@ -75,13 +75,33 @@ __host__ __device__ __forceinline__ uint32_t zero_bytes(uint32_t x)
  * code = (c >> 1) & 3  (:411): A,a->0  C,c->1  T,t->2  G,g,n->3, any byte works. */
 __host__ __device__ __forceinline__ uint32_t pack4(uint32_t w)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* the four codes times 64, 16, 4, 1: one full-rate v_dot4_u32_u8 (the multiplier below does not fit 24 bits, so the
+     * product is a quarter-rate v_mul_lo_u32) */
+    return __builtin_amdgcn_udot4((w >> 1) & 0x03030303u, 0x01041040u, 0u, false);
+#else
     return ((((w >> 1) & 0x03030303u) * 0x40100401u) >> 24);
+#endif
 }
 
 /* Four bytes -> 4 flag bits (first byte in bit 3) from a zero_bytes() result. */
 __host__ __device__ __forceinline__ uint32_t flags4(uint32_t z)
 {
     return (((z >> 7) * 0x08040201u) >> 24) & 0xFu;
+}
+
+/* Sixteen bytes -> 16 flag bits (first byte in bit 15) from four zero_bytes() results. */
+__host__ __device__ __forceinline__ uint32_t flags16(uint32_t zx, uint32_t zy, uint32_t zz, uint32_t zw)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* a flagged byte is 0x80: times 128 .. 16 (first dword of a pair) and 8 .. 1 (second) the pair's eight flags come
+     * out as one number, times 128 — four v_dot4_u32_u8 instead of four quarter-rate multiplies and their shifts */
+    const uint32_t hi = __builtin_amdgcn_udot4(zx, 0x10204080u, __builtin_amdgcn_udot4(zy, 0x01020408u, 0u, false), false);
+    const uint32_t lo = __builtin_amdgcn_udot4(zz, 0x10204080u, __builtin_amdgcn_udot4(zw, 0x01020408u, 0u, false), false);
+    return ((hi << 8) | lo) >> 7;
+#else
+    return (flags4(zx) << 12) | (flags4(zy) << 8) | (flags4(zz) << 4) | flags4(zw);
+#endif
 }
 
 struct Packed {
@@ -96,10 +116,10 @@ __host__ __device__ __forceinline__ Packed pack16(uint4 v)
     p.fwd = (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w);
     uint32_t nx = zero_bytes(v.x ^ 0x0A0A0A0Au), ny = zero_bytes(v.y ^ 0x0A0A0A0Au);
     uint32_t nz = zero_bytes(v.z ^ 0x0A0A0A0Au), nw = zero_bytes(v.w ^ 0x0A0A0A0Au);
-    p.nl = (flags4(nx) << 12) | (flags4(ny) << 8) | (flags4(nz) << 4) | flags4(nw);
+    p.nl = flags16(nx, ny, nz, nw);
     uint32_t bx = zero_bytes(v.x ^ 0x4E4E4E4Eu), by = zero_bytes(v.y ^ 0x4E4E4E4Eu);
     uint32_t bz = zero_bytes(v.z ^ 0x4E4E4E4Eu), bw = zero_bytes(v.w ^ 0x4E4E4E4Eu);
-    p.bad = p.nl | (flags4(bx) << 12) | (flags4(by) << 8) | (flags4(bz) << 4) | flags4(bw);
+    p.bad = p.nl | flags16(bx, by, bz, bw);
     return p;
 }
 
