@@ -978,6 +978,8 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
             QM2_SET(0) QM2_SET(1) QM2_SET(2) QM2_SET(3) QM2_SET(4) QM2_SET(5)
 #undef QM2_SET
             static_assert(G2 <= 6 * kR, "at most six sets per group");
+            /* (the two sets of a group interleaved — the second set's hashes and fingerprint reads issued before the first
+             *  set's compares — measured: 25.47 -> 25.38 ms, nothing: the other prober waves already cover those waits) */
             QM2_STAMP(5);
             base += kGroupKmers;
         }
