@@ -644,7 +644,8 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
             for (int st = 0; st < kCntSteps; st++) {
                 const uint32_t i4 = tid + st * kLoaderThreads;
 #ifdef QM2_EXP_HALF_COUNTERS            /* ... and of the counter loads */
-                ov[st] = 4 * i4 - g.int_lo < g.int_len && (i4 & 1u) ? cp4[i4] : u32x4{0, 0, 0, 0};
+                /* (the lower HALF of the tile, whole lines: skipping every other 16 bytes, as first tried, leaves every DRAM sector in use) */
+                ov[st] = 4 * i4 - g.int_lo < g.int_len && i4 < (uint32_t)kSeg / 8u ? cp4[i4] : u32x4{0, 0, 0, 0};
 #else
                 ov[st] = 4 * i4 - g.int_lo < g.int_len ? cp4[i4] : u32x4{0, 0, 0, 0};
 #endif
@@ -700,7 +701,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                     }
                     if (i - g.int_lo < g.int_len) {
 #ifdef QM2_EXP_HALF_COUNTERS        /* timing experiment only (WRONG counts): half of the counter stores ... */
-                        if ((i >> 2) & 1u)
+                        if (i < (uint32_t)kSeg / 2u)
 #endif
                         *reinterpret_cast<u32x4 *>(cp + i) = cv;
 #ifdef QM2_EXP_NO_EDGE_ATOMICS
