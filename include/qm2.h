@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define QM2_ABI_VERSION 3
+#define QM2_ABI_VERSION 4
 
 typedef struct qm2_ctx qm2_ctx;
 
@@ -97,7 +97,12 @@ typedef struct {
                                  ALREADY resident (then `keys` may be NULL)      */
     void    *ext_counters;    /* optional: device pointer to H x u32 counters
                                  owned by the caller (e.g. a tensor handed to
-                                 RCCL for the replica reduce); zeroed by caller  */
+                                 RCCL for the replica reduce); zeroed by caller.
+                                 COMPLETE ONLY BEHIND qm2_finish (or a call of
+                                 qm2_counters_device / qm2_merge_counters): between
+                                 batches part of the counts sits in a 2-byte array
+                                 of the context's own (the private bucket interiors
+                                 of the partitioned pipeline) and is added in there */
     void    *stream;          /* optional hipStream_t used by qm2_submit_device /
                                  qm2_encode_device / qm2_probe_device; NULL =
                                  a stream owned by the context                   */

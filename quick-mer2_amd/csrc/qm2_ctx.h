@@ -84,6 +84,13 @@ struct qm2_ctx {
     uint32_t    flags = 0;
     uint64_t   *keys = nullptr;
     bool        own_keys = false;
+    /* The counts of bucket_count's PRIVATE bucket interiors live in 2 bytes per slot (the reference's own width, :23):
+     * that kernel is bound by its bytes, and 4-byte counters are a quarter of its table pass.  Everything atomic —
+     * bucket edges, halo, shared buckets, the spill list, the direct kernel — adds into the 32-bit array; a tile value
+     * above 65535 sends its upper part there too, so count = counters[i] + interior16[i] exactly.  qm2_fold_counters
+     * adds the small array into the big one before anybody looks (qm2_finish, merge, the chain gather). */
+    uint16_t   *interior16 = nullptr;
+    bool        interior_dirty = false;
     bool        keys_consumed = false;      /* the chain was uploaded over the key table */
     bool        keys_pending = false;       /* QM2_FLAG_KEYS_LATER: qm2_keys_from_fd has not run yet */
     uint32_t   *counters = nullptr;
@@ -131,7 +138,8 @@ struct qm2_ctx {
     uint64_t    n_gathered = 0;
 };
 
-int qm2_fail(const char *fmt, ...);         /* sets qm2_last_error(), prints, returns 1 */
+int qm2_fail(const char *fmt, ...);
+int qm2_fold_counters(qm2_ctx *c);           /* interior16 -> counters (on c->stream, not synchronised); no-op when nothing is pending */         /* sets qm2_last_error(), prints, returns 1 */
 void qm2_part_free(qm2::PartPlan &p);
 /* qm2_io.hip: nbytes of `fd` from `off` -> device memory `dst`, read by several threads through pinned buffers */
 int qm2_stream_fd(qm2_ctx *c, int fd, uint64_t off, void *dst, uint64_t nbytes, const char *what);

@@ -36,6 +36,7 @@ constexpr uint64_t kMask60        = (1ull << 60) - 1;
 struct TableView {
     const uint64_t *keys;      /* slots [span_lo, span_hi) of the table          */
     uint32_t       *counters;  /* same span, 32-bit accumulators                 */
+    uint16_t       *interior16;/* same span: the private bucket interiors of bucket_count (qm2_ctx.h); else unused */
     uint64_t        span_lo;   /* global slot index of keys[0]                   */
     uint32_t        hmask;     /* H - 1 (H <= 2^32)                              */
     uint32_t        hhalf;     /* H >> 1                                         */

@@ -100,6 +100,7 @@ static int chain_gather(qm2_ctx *c, const uint32_t *chain, int fd, uint64_t file
     HIP_OK(hipSetDevice(c->device));
     const uint64_t H = c->H;
     hipStream_t s = c->stream;
+    if (qm2_fold_counters(c)) return 1;                          /* (the walk reads counters[]: whole before it starts; same stream) */
 
     ChainView cv;
     /* ~2^20 splitters: enough parallel walkers to hide the pointer-chase latency, few

@@ -70,6 +70,7 @@ static TableView table_view(const qm2_ctx *c)
     TableView tv;
     tv.keys = c->keys;
     tv.counters = c->counters;
+    tv.interior16 = c->interior16;
     tv.span_lo = c->span_lo;
     tv.hmask = (uint32_t)(c->H - 1);
     tv.hhalf = (uint32_t)(c->H >> 1);
@@ -234,6 +235,15 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     if (e == hipSuccess) e = hipMalloc((void **)&p.cursors, p.n_cursors * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p.spill, p.spill_cap * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p.spill_count, sizeof(unsigned long long));
+    if (e == hipSuccess && !c->interior16) {
+        /* the 2-byte counters of the bucket interiors (qm2_ctx.h): once per context, they outlive a re-plan */
+        const uint64_t n_slots = c->span_hi - c->span_lo;
+        e = hipMalloc((void **)&c->interior16, n_slots * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMemsetAsync(c->interior16, 0, n_slots * sizeof(uint16_t), c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess && c->interior16) { (void)hipFree(c->interior16); c->interior16 = nullptr; }
+        c->prof.allocations++;
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         qm2_part_free(p);
@@ -385,6 +395,7 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
         const uint32_t n_buckets = (uint32_t)p.buckets[L];
         const int grid = (int)std::min<uint64_t>(n_buckets, (uint64_t)c->n_cu * QM2_COUNT_GRID_MULT);
         if (time_begin(c, &t, QM2_K_BUCKET_COUNT)) return 1;
+        c->interior_dirty = true;
         /* the group size (16-byte k-mer loads per prober thread) is picked so that a bucket's fill (mean
          * + 3 sigma of uniform hashing; k-mers per byte measured on earlier batches through an asynchronous
          * copy of the stats block) wastes the fewest rows */
@@ -712,6 +723,7 @@ extern "C" void qm2_close(qm2_ctx *c)
     if (c->gathered) (void)hipFree(c->gathered);
     if (c->own_keys && c->keys) (void)hipFree(c->keys);
     if (c->own_counters && c->counters) (void)hipFree(c->counters);
+    if (c->interior16) (void)hipFree(c->interior16);
     if (c->narrow) (void)hipFree(c->narrow);
     if (c->stats) (void)hipFree(c->stats);
     if (c->stats_peek) (void)hipHostFree(c->stats_peek);
@@ -725,7 +737,12 @@ extern "C" void qm2_close(qm2_ctx *c)
     delete c;
 }
 
-extern "C" void *qm2_counters_device(qm2_ctx *c) { return c ? c->counters : nullptr; }
+extern "C" void *qm2_counters_device(qm2_ctx *c)
+{
+    /* (whoever asks for the array is about to read it: the interiors' 2-byte counts go in first, behind the work queued so far) */
+    if (c && c->interior_dirty && (qm2_fold_counters(c) || hipStreamSynchronize(c->stream) != hipSuccess)) return nullptr;
+    return c ? c->counters : nullptr;
+}
 extern "C" void *qm2_keys_device(qm2_ctx *c) { return c ? c->keys : nullptr; }
 
 /* ---- host-buffer pipeline: pinned staging -> device batch -> kernels --------- */
@@ -1101,6 +1118,36 @@ extern "C" int qm2_flush(qm2_ctx *c)
 }
 
 /* dst += src, whole counter arrays (replicas of one table on one or two devices) */
+/* counters[i] += interior16[i]; interior16[i] = 0 (qm2_ctx.h): four slots a step, groups without a count are skipped */
+__global__ void fold_counters_kernel(uint32_t *counters, uint16_t *interior16, uint64_t n)
+{
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t groups = n / 4;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (uint64_t)gridDim.x * blockDim.x) {
+        const u32x2 v = reinterpret_cast<const u32x2 *>(interior16)[g];
+        if ((v.x | v.y) == 0) continue;
+        u32x4 cv = reinterpret_cast<const u32x4 *>(counters)[g];
+        cv.x += v.x & 0xFFFFu; cv.y += v.x >> 16; cv.z += v.y & 0xFFFFu; cv.w += v.y >> 16;
+        reinterpret_cast<u32x4 *>(counters)[g] = cv;
+        reinterpret_cast<u32x2 *>(interior16)[g] = u32x2{0, 0};
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (uint64_t i = groups * 4; i < n; i++) { counters[i] += interior16[i]; interior16[i] = 0; }
+}
+
+int qm2_fold_counters(qm2_ctx *c)
+{
+    if (!c->interior16 || !c->interior_dirty) return 0;
+    if (use_device(c)) return 1;
+    const uint64_t n_slots = c->span_hi - c->span_lo;
+    const int grid = (int)std::min<uint64_t>((n_slots / 4 + 255) / 256 + 1, (uint64_t)c->n_cu * 16);
+    hipLaunchKernelGGL(fold_counters_kernel, dim3(grid), dim3(256), 0, c->stream, c->counters, c->interior16, n_slots);
+    HIP_OK(hipGetLastError());
+    c->interior_dirty = false;
+    return 0;
+}
+
 __global__ void add_counters_kernel(uint32_t *dst, const uint32_t *src, uint64_t n)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
@@ -1115,7 +1162,12 @@ extern "C" int qm2_merge_counters(qm2_ctx *dst, qm2_ctx *src)
     if (dst->H != src->H || src->span_lo < dst->span_lo || src->span_hi > dst->span_hi)
         return fail("qm2_merge_counters: the source's slots are not part of the destination's table");
     if (qm2_sync(src) || qm2_sync(dst)) return 1;
+    /* (both arrays whole: the interiors' 2-byte counts first) */
+    if (qm2_fold_counters(src) || qm2_fold_counters(dst)) return 1;
+    if (use_device(src)) return 1;
+    HIP_OK(hipStreamSynchronize(src->stream));
     if (use_device(dst)) return 1;
+    HIP_OK(hipStreamSynchronize(dst->stream));
     const uint64_t n = src->span_hi - src->span_lo;
     uint32_t *const into = dst->counters + (src->span_lo - dst->span_lo);
     const int grid = dst->n_cu * 8;
@@ -1186,6 +1238,8 @@ extern "C" int qm2_prepare(qm2_ctx *c, uint64_t batch_bytes, uint32_t what)
 extern "C" int qm2_finish(qm2_ctx *c, uint16_t *depth_out, qm2_stats *st)
 {
     if (qm2_sync(c)) return 1;
+    /* the counters are complete from here on (own array or the caller's ext_counters) */
+    if (c->interior_dirty) { if (qm2_fold_counters(c)) return 1; HIP_OK(hipStreamSynchronize(c->stream)); }
     const uint64_t n_slots = c->span_hi - c->span_lo;
     if (depth_out) {
         if (!c->narrow) HIP_OK(hipMalloc((void **)&c->narrow, n_slots * sizeof(uint16_t)));
@@ -1211,6 +1265,8 @@ extern "C" int qm2_reset(qm2_ctx *c)
     if (qm2_sync(c)) return 1;
     const uint64_t n_slots = c->span_hi - c->span_lo;
     HIP_OK(hipMemsetAsync(c->counters, 0, n_slots * sizeof(uint32_t), c->stream));
+    if (c->interior16) HIP_OK(hipMemsetAsync(c->interior16, 0, n_slots * sizeof(uint16_t), c->stream));
+    c->interior_dirty = false;
     HIP_OK(hipMemsetAsync(c->stats, 0, sizeof(DevStats), c->stream));
     c->bytes_launched = 0;
     c->peek_pending = false;

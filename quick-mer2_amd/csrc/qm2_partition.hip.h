@@ -612,10 +612,6 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         const bool sh = shared != nullptr && ((shared[b >> 5] >> (b & 31)) & 1u) != 0;
         g.int_lo = (uint32_t)(own_lo - lo) + kHalo;
         g.int_len = sh ? 0u : (uint32_t)S - 2u * kHalo;
-#ifdef QM2_EXP_NO_EDGE_ATOMICS      /* timing experiment only (WRONG counts at bucket edges): the whole own range stored plainly */
-        g.int_lo = (uint32_t)(own_lo - lo);
-        g.int_len = (uint32_t)S;
-#endif
         return g;
     };
     auto fill_of = [&](uint32_t b) {
@@ -628,8 +624,9 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         __builtin_amdgcn_s_setprio(2);
         constexpr int kKeySteps = (kSeg / 2 + 8 + kLoaderThreads - 1) / kLoaderThreads;   /* 2 keys per lane and step (+ the 0xFF pad) */
         constexpr int kCntSteps = (kSeg / 4 + kLoaderThreads - 1) / kLoaderThreads;       /* 4 counters per lane and step */
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         u32x4 kv[kKeySteps];
-        u32x4 ov[kCntSteps];
+        u32x2 ov[kCntSteps];                     /* four 16-bit interior counters a step (tv.interior16) */
         auto fetch = [&](uint32_t b) {
             if (b >= n_buckets) return;
             const Geo g = geo(b);
@@ -639,16 +636,12 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                 const uint32_t i2 = tid + st * kLoaderThreads;
                 kv[st] = 2 * i2 < g.seg ? kp[i2] : u32x4{0, 0, 0, 0};
             }
-            const u32x4 *cp4 = reinterpret_cast<const u32x4 *>(tv.counters + (g.seg_lo - tv.span_lo));
+            /* (g.seg_lo is a multiple of 4 slots: 8-byte aligned in the 2-byte array) */
+            const u32x2 *cp2 = reinterpret_cast<const u32x2 *>(tv.interior16 + (g.seg_lo - tv.span_lo));
 #pragma unroll
             for (int st = 0; st < kCntSteps; st++) {
                 const uint32_t i4 = tid + st * kLoaderThreads;
-#ifdef QM2_EXP_HALF_COUNTERS            /* ... and of the counter loads */
-                /* (the lower HALF of the tile, whole lines: skipping every other 16 bytes, as first tried, leaves every DRAM sector in use) */
-                ov[st] = 4 * i4 - g.int_lo < g.int_len && i4 < (uint32_t)kSeg / 8u ? cp4[i4] : u32x4{0, 0, 0, 0};
-#else
-                ov[st] = 4 * i4 - g.int_lo < g.int_len ? cp4[i4] : u32x4{0, 0, 0, 0};
-#endif
+                ov[st] = 4 * i4 - g.int_lo < g.int_len ? cp2[i4] : u32x2{0, 0};
             }
         };
         /* registers -> LDS buffer `bf`: keys, fingerprints, counter tile; mirrored when the bucket walks down */
@@ -677,7 +670,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
             for (int st = 0; st < kCntSteps; st++) {
                 const uint32_t i = 4u * (tid + st * kLoaderThreads);
                 if (i < g.seg) {
-                    const u32x4 o = ov[st];
+                    const u32x4 o = u32x4{ov[st].x & 0xFFFFu, ov[st].x >> 16, ov[st].y & 0xFFFFu, ov[st].y >> 16};
                     if (g.down) *reinterpret_cast<u32x4 *>(&scnt[bf][g.seg - 4u - i]) = u32x4{o.w, o.z, o.y, o.x};
                     else        *reinterpret_cast<u32x4 *>(&scnt[bf][i]) = o;
                 }
@@ -688,6 +681,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
             if (fill_of(b) == 0) return;                 /* nothing was counted: the tile is what was loaded */
             const Geo g = geo(b);
             uint32_t *const cp = tv.counters + (g.seg_lo - tv.span_lo);
+            uint16_t *const cp16 = tv.interior16 + (g.seg_lo - tv.span_lo);
 #pragma unroll
             for (int st = 0; st < kCntSteps; st++) {
                 const uint32_t i = 4u * (tid + st * kLoaderThreads);
@@ -700,13 +694,15 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                         cv = *reinterpret_cast<const u32x4 *>(&scnt[bf][i]);
                     }
                     if (i - g.int_lo < g.int_len) {
-#ifdef QM2_EXP_HALF_COUNTERS        /* timing experiment only (WRONG counts): half of the counter stores ... */
-                        if (i < (uint32_t)kSeg / 2u)
-#endif
-                        *reinterpret_cast<u32x4 *>(cp + i) = cv;
-#ifdef QM2_EXP_NO_EDGE_ATOMICS
-                    } else if (true) {
-#endif
+                        /* private interior: the low halves go back where they came from; what has outgrown 16 bits (a
+                         * k-mer seen more than 65535 times: :291 wraps there, this keeps counting) moves to the wide array */
+                        *reinterpret_cast<u32x2 *>(cp16 + i) = u32x2{(cv.x & 0xFFFFu) | (cv.y << 16), (cv.z & 0xFFFFu) | (cv.w << 16)};
+                        if ((cv.x | cv.y | cv.z | cv.w) >> 16) {
+                            if (cv.x >> 16) atomicAdd(cp + i, cv.x & 0xFFFF0000u);
+                            if (cv.y >> 16) atomicAdd(cp + i + 1, cv.y & 0xFFFF0000u);
+                            if (cv.z >> 16) atomicAdd(cp + i + 2, cv.z & 0xFFFF0000u);
+                            if (cv.w >> 16) atomicAdd(cp + i + 3, cv.w & 0xFFFF0000u);
+                        }
                     } else {
                         if (cv.x) atomicAdd(cp + i, cv.x);
                         if (cv.y) atomicAdd(cp + i + 1, cv.y);

@@ -146,7 +146,9 @@ class HipEngine:
     def drain(self, ctx):
         self.s_route.synchronize()
         self.s_probe.synchronize()
-        ctx.sync()
+        # qm2_finish, not qm2_sync: the counter tensor this job owns (ext_counters) is complete only behind it
+        # (the counts of the bucket interiors are folded in there: include/qm2.h)
+        ctx.finish(want_depth=False)
 
 
 class ReplicaJob:
@@ -170,6 +172,7 @@ class ReplicaJob:
 
     def finish(self):
         """-> uint16[H] on every rank (mod-2^16 truncation commutes with the sum)."""
+        self.engine.drain(self.ctx)          # (the counter tensor is complete behind qm2_finish)
         if self.dist.get_world_size() > 1:
             step = 1 << 28                   # 1 GiB pieces: no 2^31-element count reaches the collective
             for a in range(0, self.counters.numel(), step):

@@ -557,6 +557,44 @@ def test_wrap_mod_65536_and_reset(qm2):
         assert st["n_kmers"] == 0 and not depth.any()
 
 
+def test_interior_counters_outgrow_16_bits(qm2, torch_cuda):
+    """The private interior of a bucket is counted in 2 bytes per slot in HBM (the u32 LDS tile starts from them and
+    is stored back), everything atomic in the caller's u32 array; a tile value above 65535 sends its upper part to the
+    wide array.  One dictionary k-mer that sits in a bucket interior, 2000 times per batch — inside its bucket's
+    capacity, so it goes through the tile and not through the spill list — over 40 batches: 80 000.  The u32 array
+    behind qm2_finish must hold exactly that (a lost upper part would still pass every mod-65536 check), the uint16
+    depth 80 000 - 65 536, every other slot the oracle's count."""
+    torch = torch_cuda
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    keys = qm["keys"]
+    H = len(keys)
+    inner = [s_ for s_ in np.flatnonzero(keys) if 512 <= (int(s_) % 4096) < 3584]
+    slot = int(inner[len(inner) // 2])
+    km = int(keys[slot])
+    one = "".join("ACTG"[(km >> (2 * (29 - i))) & 3] for i in range(30)).encode()      # code = (c >> 1) & 3 (:411): A 0, C 1, T 2, G 3
+    ref = synth.kat_reference().tobytes()
+    rng = np.random.default_rng(11)
+    normal = b"".join(ref[int(p):int(p) + 150] + b"\n" for p in rng.integers(0, 4800, 4000))
+    batch = normal + (one + b"\n") * 2000
+    d_keys = torch.from_numpy(keys.view(np.int64)).cuda()
+    counters = torch.zeros(H, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with qm2.Counter(None, hash_size=H, k=30, ext_keys=d_keys.data_ptr(), ext_counters=counters.data_ptr(),
+                     flags=qm2.FLAG_PARTITION | qm2.FLAG_TIMING) as c:
+        for _ in range(40):
+            c.submit(batch)
+            c.sync()
+        depth, st = c.finish()
+        prof = c.profile()
+    assert prof["partitioned_batches"] == 40 and prof["fallback_batches"] == 0 and prof["spilled_kmers"] == 0
+    exp1, st1 = ol.count_lines(keys, 30, batch)
+    wide = counters.cpu().numpy().view(np.uint32)
+    assert np.array_equal(wide, 40 * exp1.astype(np.uint32))              # (one batch stays far below 65536 everywhere)
+    assert int(wide[slot]) >= 80000 and int(depth[slot]) == int(wide[slot]) - 65536
+    assert np.array_equal(depth, (wide & 0xFFFF).astype(np.uint16))
+    assert st == {a: 40 * b for a, b in st1.items()}
+
+
 def test_skewed_input_spills_and_falls_back(qm2):
     """Partitioned pipeline under skew: poly-A floods one bucket.  A mild flood goes through the
     spill list; a total one overflows even that and the batch is recounted by the direct kernel
