@@ -418,6 +418,12 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
                 }
             }
         }
+        {   /* (experiments: force the loader waves / the group size) */
+            static const int env_lw = getenv("QM2_COUNT_LW") ? atoi(getenv("QM2_COUNT_LW")) : 0;
+            static const int env_g = getenv("QM2_COUNT_G") ? atoi(getenv("QM2_COUNT_G")) : 0;
+            if (env_lw == 3 || env_lw == 4) lw = env_lw;
+            if (env_g >= 2 && env_g <= 6) g = env_g;
+        }
         const CountGeo cg = {c->own_lo, c->span_lo, c->span_hi, c->H >> 1};
 #define QM2_LAUNCH_COUNT(G_, LW_)                                                                               \
         hipLaunchKernelGGL((bucket_count_kernel<kLgS, G_, LW_>), dim3(grid), dim3(kCountThreads), 0, s,        \
