@@ -410,10 +410,11 @@ int qm2_main_count(int argc, char **argv)
     const char *ref_prefix = argv[argc - 3], *reads = argv[argc - 2], *out_prefix = argv[argc - 1];
     /* -t sized the reference's probing workers (:372-384); those are GPU waves now.  Here it sizes
      * the host threads that strip FASTA/FASTQ blocks into pinned staging (default 4). */
-    /* default: 16 where the machine has the cores, else 8 or 4 */
-    /* (hg38 scale, 30.7 GB of FASTQ from /dev/shm, 256-thread host: -t 12 / 16 / 24 / 32 -> 12.6 / 20.8 / 19.2 / 16.4 G bases/s) */
+    /* default: 12 where the machine has the cores, else 8 or 4.  Since the readers count newlines at memory speed 8 of them
+     * fill the PCIe link (hg38 scale, 30.7 GB of FASTQ from /dev/shm, a 16-core share of a 256-thread host: -t 8 / 12 / 16 / 24
+     * -> 19.0 / 22.9 / 19.3 / 20.9 G bases/s; chr22 scale 20.4 / 23.5 / 21.6); before that it was 12.6 / 20.8 / 19.2 at 12 / 16 / 24 */
     const long cores = sysconf(_SC_NPROCESSORS_ONLN);
-    int n_strip = getopt_seen_t ? (int)thread_count : (cores >= 32 ? 16 : cores >= 16 ? 8 : 4);
+    int n_strip = getopt_seen_t ? (int)thread_count : (cores >= 24 ? 12 : cores >= 16 ? 8 : 4);
     if (n_strip > 32) n_strip = 32;
 
     const int timing = getenv("QM2_TIMING") != NULL;   /* extra phase lines; off by default so that
