@@ -525,6 +525,16 @@ def test_prepare_peek_flush_and_merge(qm2, tmp_path):
             assert np.array_equal(depth, exp_depth)
             d_b, _ = b.finish()                         # the source keeps its own counts
             assert int(d_b.astype(np.uint64).sum()) == sb["n_hits"]
+        # the same without a qm2_finish in front of the merge: both contexts still hold part of their counts in the
+        # 2-byte interior arrays (partitioned pipeline), and the merge must add those in first, on both sides
+        with qm2.Counter(keys, k=qm["k"], flags=flags) as a, qm2.Counter(keys, k=qm["k"], flags=flags) as b:
+            a.submit(lines[:cut]); a.sync()
+            b.submit(lines[cut:]); b.sync()
+            a.merge_counters(b)
+            a.submit(lines[:cut]); a.sync()            # ... and keeps counting on top of the merged counts
+            depth, st = a.finish()
+            e2, _ = ol.count_lines(keys, qm["k"], lines + lines[:cut])
+            assert np.array_equal(depth, e2)
 
 
 def test_empty_and_degenerate_inputs(qm2):
