@@ -239,9 +239,11 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(const uint64_t *kmers, ui
     if (held && lane == 0) atomicAdd(&tv.counters[held_idx], held);
     if (stats) {
         n_probes = wave_sum(n_probes); n_hits = wave_sum(n_hits);
-        if (lane == 0) {
+        /* (only waves that probed anything: the spill list is EMPTY on ordinary input, and 8192 idle waves adding
+         *  zeros to the same two words were the whole 0.2 ms this launch took per batch) */
+        if (lane == 0 && n_probes) {
             atomicAdd(&stats->n_probes, n_probes);
-            atomicAdd(&stats->n_hits, n_hits);
+            if (n_hits) atomicAdd(&stats->n_hits, n_hits);
         }
     }
 }
