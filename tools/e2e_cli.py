@@ -115,7 +115,7 @@ for name, thr, extra in runs:
     devs = extra.pop("_devices", None)
     for rep in range(reps):
         t = time.time()
-        r = subprocess.run([cli, "count", "-t", thr] + ((["--shards", devs[1:]] if devs.startswith("s") else ["--devices", devs]) if devs else []) +
+        r = subprocess.run([cli, "count"] + (["-t", thr] if thr else []) + ((["--shards", devs[1:]] if devs.startswith("s") else ["--devices", devs]) if devs else []) +
                            [os.path.join(work, "ref.fa"), os.path.join(reads_dir, name), os.path.join(work, "out")],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, QM2_TIMING="1", **extra))
         walls.append(time.time() - t)
