@@ -446,7 +446,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("QM2_REHEARSE_ON_ONE_GPU") == "1":
+            # N ranks of this very script on ONE card (tests/test_gpu_parity.py::test_bench_replicas_two_ranks_on_one_gpu):
+            # RCCL refuses two ranks on one device, so the rehearsal's collectives go through gloo
+            local = 0
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the count path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -532,14 +538,27 @@ def main():
     barrier()
     t1 = time.perf_counter()
 
+    # Every rank completes its own counters first: the steps above end with qm2_sync, which leaves the counts of the
+    # private bucket interiors in the context's 2-byte array; only qm2_finish (or qm2_counters_device /
+    # qm2_merge_counters) folds them into the 4-byte array that is about to be summed (include/qm2.h, ABI 4).
+    # Timed on its own (a 10 ms streaming pass at hg38 scale), outside the steps and outside the reduce.
+    tf0 = time.perf_counter()
+    _, st1 = ctx.finish(want_depth=False)
+    torch.cuda.synchronize()
+    fold_ms = 1e3 * (time.perf_counter() - tf0)
+
     # The replicas' ONE exchange, once per job (not per step): RCCL sum of the u32 counters onto
     # rank 0, which then owns the job's counts.  Timed on its own and reported beside the steps.
     reduce_ms = None
     if use_dist:
+        barrier()
         tr0 = time.perf_counter()
         step_elems = 1 << 28                     # 1 GiB pieces: no 2^31-element count reaches the collective
         for a in range(0, counters.numel(), step_elems):
-            dist.reduce(counters[a:a + step_elems], dst=0)
+            if dist.get_backend() == "gloo":     # (the one-GPU rehearsal: gloo has no reduce of device tensors)
+                dist.all_reduce(counters[a:a + step_elems])
+            else:
+                dist.reduce(counters[a:a + step_elems], dst=0)
         torch.cuda.synchronize()
         barrier()
         reduce_ms = 1e3 * (time.perf_counter() - tr0)
@@ -572,7 +591,6 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    _, st1 = ctx.finish(want_depth=False)
     prof1 = ctx.profile()
     d = {a: st1[a] - st0[a] for a in st1}
     bases_rank = d["n_bases"]
@@ -789,6 +807,7 @@ def main():
                        if world > 1 else "1 GPU", "inputs": "resident in HBM (value); host-fed rates under `streamed`",
                        "setup_s": round(t_setup, 1),
                        "final_reduce_ms": round(reduce_ms, 2) if reduce_ms is not None else None,
+                       "fold_ms": round(fold_ms, 2),
                        "counts_conserved": counts_conserved, "spilled_kmers": prof1["spilled_kmers"] - prof0["spilled_kmers"]},
             "kernel_only_bases_per_s": roofline["kernel_only_bases_per_s"],
             "streamed_bases_per_s": streamed["streamed_bases_per_s"] if streamed else None,

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define QM2_ABI_VERSION 4
+#define QM2_ABI_VERSION 5
 
 typedef struct qm2_ctx qm2_ctx;
 
@@ -278,6 +278,14 @@ int qm2_route_device(qm2_ctx *c, const void *d_seq_bytes, size_t n, const uint64
                      uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t *d_fill, uint64_t *d_call);
 int qm2_probe_slabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_slabs,
                            const uint32_t *d_fill);
+/* qm2_route_device for text that starts in the MIDDLE of a line (a line longer than the caller's batch, cut by the
+ * caller): the first `carry` bytes (<= 32; at least max(k, 31) - 1 of the line's bytes in front of the cut, or all of
+ * them if the line is younger) are look-back only — windows that end inside them emit nothing, they were routed with
+ * the previous piece — exactly what qm2_submit does with a line it has to cut (QuicKmer.c:415-416: the forward window
+ * and the 30-base reverse-complement register both reach back).  Positions in d_suppress count from d_seq_bytes.  ABI 5. */
+int qm2_route_device_carry(qm2_ctx *c, const void *d_seq_bytes, size_t n, uint32_t carry, const uint64_t *d_suppress,
+                           uint64_t n_suppress, uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t *d_fill,
+                           uint64_t *d_call);
 
 /* The same when the senders have already partitioned what they route: qm2_route_device called with
  * n_owners x n_subs "owners" (<= 1024 in all) cuts every owner's slab into n_subs sub-slabs by the next

@@ -30,7 +30,8 @@ static void help_count(void)
     puts("--devices a,b,..\tGPUs to count on (a replica of the dictionary on each, the reads dealt to them a device");
     puts("\t\tbatch at a time, the counts summed on the first); default: the current device");
     puts("--shards a,b,..\tGPUs (a power of two of them) that each hold a hash range of the dictionary; the k-mers");
-    puts("\t\tof every batch are routed to their owners by RCCL (needs libqm2_shards.so beside this binary)");
+    puts("\t\tof every batch are routed to their owners by RCCL (needs libqm2_shards.so beside this binary).");
+    puts("\t\tEXPERIMENTAL on more than one GPU (not yet run on two physical GPUs): set QM2_SHARDS_EXPERIMENTAL=1");
 }
 
 /* The reference prints `Read %liG kmers` whenever its k-mer count reaches a multiple of 2^30 (:446).

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <mutex>
@@ -50,8 +51,10 @@ struct PartPlan {                           /* how a batch is radix-partitioned 
     uint32_t bits[kMaxLevels] = {0, 0, 0};
     uint32_t shift[kMaxLevels] = {0, 0, 0}; /* child id at level l = (home >> shift[l]) & (fan-1) */
     uint64_t buckets[kMaxLevels] = {0, 0, 0};
-    /* sized for `reserved` payload bytes */
-    uint64_t reserved = 0;
+    /* sized for `reserved` payload bytes.  (Atomic, like qm2_ctx::keys_pending: the CLI makes the partition buffers —
+     * qm2_prepare — on one thread while qm2_keys_from_fd streams the dictionary on another; each looks at the other's
+     * flag to decide who takes the one-off look at the runs of occupied slots, itself under runs_mu.) */
+    std::atomic<uint64_t> reserved{0};
     uint64_t refused = 0;                   /* smallest batch whose buffers did not fit in HBM */
     uint32_t cap[kMaxLevels] = {0, 0, 0};
     bool     ext0 = false;                  /* level 0 comes from outside (qm2_probe_subslabs_device: the sub-slabs a shard received ARE its level 0) */
@@ -92,7 +95,8 @@ struct qm2_ctx {
     uint16_t   *interior16 = nullptr;
     bool        interior_dirty = false;
     bool        keys_consumed = false;      /* the chain was uploaded over the key table */
-    bool        keys_pending = false;       /* QM2_FLAG_KEYS_LATER: qm2_keys_from_fd has not run yet */
+    std::atomic<bool> keys_pending{false};  /* QM2_FLAG_KEYS_LATER: qm2_keys_from_fd has not run yet */
+    std::atomic<uint64_t> n_allocations{0}; /* hipMalloc / hipHostMalloc calls so far (qm2_profile.allocations; counted from both threads) */
     uint32_t   *counters = nullptr;
     bool        own_counters = false;
     uint16_t   *narrow = nullptr;           /* H x u16 scratch for qm2_finish */

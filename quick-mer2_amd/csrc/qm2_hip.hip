@@ -178,6 +178,25 @@ void qm2_part_free(PartPlan &p)
     p.reserved = 0;
 }
 
+/* The plan comes in two kinds: level 0 made by this context's own split (first_bits = 0: qm2_submit*,
+ * qm2_submit_device, qm2_probe_slabs_device), or given from outside with `first_bits` bits
+ * (qm2_probe_subslabs_device: no buffer and no cursors of ours at level 0).  A context may mix the calls; the plan
+ * is rebuilt when the kind (or the width of the given level) changes — launching one kind on the other's plan
+ * would put level 0's reservations into level 1's cursors and count stale buffer contents. */
+static int part_plan_kind(qm2_ctx *c, int first_bits)
+{
+    PartPlan &p = c->part;
+    const bool want_ext = first_bits > 0;
+    if (p.ext0 == want_ext && (!want_ext || (p.levels != 0 && p.bits[0] == (uint32_t)first_bits))) return 0;
+    HIP_OK(hipStreamSynchronize(c->stream));                          /* buffers may be in use */
+    qm2_part_free(p);
+    if (p.shared) { (void)hipFree(p.shared); p.shared = nullptr; }
+    p.runs = 0;
+    p.refused = 0;
+    part_init(c, p.max_bits, first_bits);
+    return 0;
+}
+
 /* Make sure the partition buffers can take a batch of n payload bytes (an upper
  * bound on its k-mers).  Returns 1 with g_err set when memory does not allow:
  * the caller then uses the direct kernel. */
@@ -231,7 +250,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     p.spill_cap = std::min<uint64_t>((uint64_t)want_kmers / 4 + 4096, 0xFFFFFFFFull);  /* 2 B of HBM per input byte; places are 32-bit in sort_chunk's announcements */
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++)
-        if (p.buf_slots[i]) { e = hipMalloc((void **)&p.buf[i], p.buf_slots[i] * sizeof(uint64_t)); c->prof.allocations++; }
+        if (p.buf_slots[i]) { e = hipMalloc((void **)&p.buf[i], p.buf_slots[i] * sizeof(uint64_t)); c->n_allocations++; }
     if (e == hipSuccess) e = hipMalloc((void **)&p.cursors, p.n_cursors * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p.spill, p.spill_cap * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p.spill_count, sizeof(unsigned long long));
@@ -242,7 +261,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
         if (e == hipSuccess) e = hipMemsetAsync(c->interior16, 0, n_slots * sizeof(uint16_t), c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess && c->interior16) { (void)hipFree(c->interior16); c->interior16 = nullptr; }
-        c->prof.allocations++;
+        c->n_allocations++;
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -497,7 +516,7 @@ static int runs_fit(qm2_ctx *c, bool *ok)
         unsigned int *d_found = nullptr, found = 0;
         uint32_t *d_shared = nullptr;
         hipError_t e = hipMalloc((void **)&d_found, sizeof(unsigned int));
-        c->prof.allocations++;
+        c->n_allocations++;
         if (e == hipSuccess) e = hipMalloc((void **)&d_shared, words * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemsetAsync(d_found, 0, sizeof(unsigned int), c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_shared, 0, words * sizeof(uint32_t), c->stream);
@@ -556,6 +575,7 @@ static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry,
     if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
     const SeqView sv = seq_view(data, n, carry, d_sup, n_sup);
     c->bytes_launched += n;
+    if (part_plan_kind(c, 0)) return 1;                               /* (after qm2_probe_subslabs_device: the plan of our own level 0 again) */
     bool part = (c->flags & QM2_FLAG_PARTITION) != 0 || ((uint64_t)n >= c->H / 8 && n >= (1u << 20));
     if (c->flags & QM2_FLAG_DIRECT) part = false;
     if (c->span_lo != 0 || c->span_hi != c->H) part = false;         /* (text into a shard: only what stays in its span) */
@@ -760,7 +780,7 @@ static int batch_ready(qm2_ctx *c, Batch &b)
     if (!b.copied) HIP_OK(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
     if (!b.dev) {
         HIP_OK(hipMalloc((void **)&b.dev, c->batch_bytes + kCarry + kDevPad));
-        c->prof.allocations++;
+        c->n_allocations++;
     }
     if (b.busy) {
         HIP_OK(hipEventSynchronize(b.done));
@@ -799,7 +819,7 @@ static int batch_flush(qm2_ctx *c)
             if (b.dev_wraps) HIP_OK(hipFree(b.dev_wraps));
             b.wraps_cap = std::max<size_t>(n_sup, 1024);
             HIP_OK(hipMalloc((void **)&b.dev_wraps, b.wraps_cap * sizeof(uint64_t)));
-            c->prof.allocations++;
+            c->n_allocations++;
         }
         HIP_OK(hipMemcpy(b.dev_wraps, b.wraps.data(), n_sup * sizeof(uint64_t), hipMemcpyHostToDevice));
         d_sup = b.dev_wraps;
@@ -817,7 +837,7 @@ int qm2_slot_ready(qm2_ctx *c, Slot &s)
 {
     if (!s.host) {
         HIP_OK(hipHostMalloc((void **)&s.host, c->staging_bytes, hipHostMallocDefault));
-        c->prof.allocations++;
+        c->n_allocations++;
         HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
     if (s.busy) {
@@ -962,7 +982,7 @@ static int raw_reserve(qm2_ctx *c, size_t n)
         c->raw_out = nullptr;
         c->raw_cap = n + n / 8 + 4096;
         HIP_OK(hipMalloc((void **)&c->raw_out, c->raw_cap));
-        c->prof.allocations++;
+        c->n_allocations++;
     }
     if (n_tiles > c->raw_tile_cap) {
         HIP_OK(hipStreamSynchronize(s));
@@ -970,11 +990,11 @@ static int raw_reserve(qm2_ctx *c, size_t n)
         c->raw_tiles = nullptr;
         c->raw_tile_cap = n_tiles + n_tiles / 8 + 16;
         HIP_OK(hipMalloc(&c->raw_tiles, c->raw_tile_cap * 40));
-        c->prof.allocations++;
+        c->n_allocations++;
     }
     if (!c->raw_flags) {
         HIP_OK(hipMalloc((void **)&c->raw_flags, 4 * sizeof(unsigned int)));
-        c->prof.allocations++;
+        c->n_allocations++;
         HIP_OK(hipMalloc((void **)&c->raw_wraps, kRawWrapCap * sizeof(uint64_t)));
     }
     return 0;
@@ -1282,6 +1302,7 @@ extern "C" int qm2_reset(qm2_ctx *c)
     c->raw_shift = 0;
     HIP_OK(hipStreamSynchronize(c->stream));
     memset(&c->prof, 0, sizeof c->prof);
+    c->n_allocations = 0;
     return 0;
 }
 
@@ -1293,6 +1314,7 @@ extern "C" int qm2_get_profile(qm2_ctx *c, qm2_profile *p)
     HIP_OK(hipMemcpy(&st, c->stats, sizeof st, hipMemcpyDeviceToHost));
     c->prof.fallback_batches = st.fallbacks;
     c->prof.spilled_kmers = st.spilled;
+    c->prof.allocations = c->n_allocations.load();
     *p = c->prof;
     return 0;
 }
@@ -1360,12 +1382,20 @@ extern "C" int qm2_probe_device(qm2_ctx *c, const uint64_t *d_kmers, uint64_t n,
 }
 
 static int route_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup, uint64_t n_sup,
-                        uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t xcd_subs, uint32_t *d_fill, uint64_t *d_call);
+                        uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t xcd_subs, uint32_t *d_fill, uint64_t *d_call,
+                        uint32_t carry = 0);
 
 extern "C" int qm2_route_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup, uint64_t n_sup,
                                 uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t *d_fill, uint64_t *d_call)
 {
     return route_device(c, d_seq, n, d_sup, n_sup, d_slabs, slab_cap, n_owners, 1, d_fill, d_call);
+}
+
+extern "C" int qm2_route_device_carry(qm2_ctx *c, const void *d_seq, size_t n, uint32_t carry, const uint64_t *d_sup, uint64_t n_sup,
+                                      uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t *d_fill, uint64_t *d_call)
+{
+    if (carry > kCarry || carry > n) return fail("qm2_route_device_carry: at most %u look-back bytes, and no more than the text", (unsigned)kCarry);
+    return route_device(c, d_seq, n, d_sup, n_sup, d_slabs, slab_cap, n_owners, 1, d_fill, d_call, carry);
 }
 
 extern "C" int qm2_route_xcd_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup, uint64_t n_sup,
@@ -1375,7 +1405,8 @@ extern "C" int qm2_route_xcd_device(qm2_ctx *c, const void *d_seq, size_t n, con
 }
 
 static int route_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup, uint64_t n_sup,
-                        uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t xcd_subs, uint32_t *d_fill, uint64_t *d_call)
+                        uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t xcd_subs, uint32_t *d_fill, uint64_t *d_call,
+                        uint32_t carry)
 {
     if (!c) return fail("qm2_route_device: null context");
     if (n == 0) return 0;
@@ -1385,7 +1416,7 @@ static int route_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t 
     if ((slab_cap & 1u) || ((uintptr_t)d_slabs & 15u) || slab_cap > 0xFFFFFFFFull)
         return fail("qm2_route_device: slabs must be 16-byte aligned, of an even capacity below 2^32");
     if (use_device(c)) return 1;
-    const SeqView sv = seq_view((const uint8_t *)d_seq, n, 0, d_sup, n_sup);
+    const SeqView sv = seq_view((const uint8_t *)d_seq, n, carry, d_sup, n_sup);
     uint32_t lgG = 0;
     while ((1u << lgG) < n_owners) lgG++;
     SplitDst d = {d_slabs, d_fill, (uint32_t)slab_cap, nullptr, nullptr, 0, 0, xcd_subs};
@@ -1413,6 +1444,7 @@ extern "C" int qm2_probe_slabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint6
     if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
     if (c->keys_consumed) return fail("qm2: the key table was overwritten by qm2_chain_gather; this context cannot count any more");
     if (use_device(c)) return 1;
+    if (part_plan_kind(c, 0)) return 1;                               /* (after qm2_probe_subslabs_device: the plan of our own level 0 again) */
     const uint64_t n_upper = slab_cap * n_slabs;
     bool part = c->part.levels != 0 && !(c->flags & QM2_FLAG_DIRECT) && !(slab_cap & 1u) && !((uintptr_t)d_slabs & 15u) &&
                 ((c->flags & QM2_FLAG_PARTITION) || (n_upper >= (c->span_hi - c->span_lo) / 16 && n_upper >= (1u << 17)));
@@ -1461,14 +1493,8 @@ extern "C" int qm2_probe_subslabs_device(qm2_ctx *c, const uint64_t *d_slabs, ui
     while ((1u << lg_subs) < n_subs) lg_subs++;
     /* the plan: level 0 = the sub-slabs (its children are the senders' sub-regions), the rest as usual */
     PartPlan &p = c->part;
-    if (!p.ext0 || p.levels == 0 || p.bits[0] != lg_subs) {
-        HIP_OK(hipStreamSynchronize(c->stream));
-        qm2_part_free(p);
-        if (p.shared) { (void)hipFree(p.shared); p.shared = nullptr; }
-        p.runs = 0;
-        p.refused = 0;
-        part_init(c, p.max_bits, (int)lg_subs);
-    }
+    if (lg_subs == 0) return fail("qm2_probe_subslabs_device: one sub-slab per peer is qm2_probe_slabs_device's case");
+    if (part_plan_kind(c, (int)lg_subs)) return 1;
     if (p.levels < 2 || (c->flags & QM2_FLAG_DIRECT))
         return fail("qm2_probe_subslabs_device: %u sub-slabs leave this context's range nothing to split (or QM2_FLAG_DIRECT is set): use qm2_probe_slabs_device", n_subs);
     bool ok = false;

@@ -8,10 +8,18 @@
  * single host thread, one communicator per GPU (ncclCommInitAll) — the host knows every rank's slab fills, so only the
  * filled parts of the slabs go over the wire, in one ncclGroupStart / ncclGroupEnd per round.
  *
- * NOT YET RUN ON TWO PHYSICAL GPUs (no lease so far had more than one): the round logic, the turn dealing, the overflow
- * re-route and the fold are exercised on one GPU with QM2_SHARDS_FAKE_EXCHANGE=1 (the ncclSend / ncclRecv pairs
- * replaced by device-to-device copies, G = 2 / 4 logical ranks on one device) and with G = 1; the RCCL calls themselves
- * only by a G = 1 run.
+ * EXPERIMENTAL for more than one GPU — NOT YET RUN ON TWO PHYSICAL GPUs (no lease so far had more than one): the round
+ * logic, the dealing, the overflow re-route and the fold are exercised on one GPU with QM2_SHARDS_FAKE_EXCHANGE=1 (the
+ * ncclSend / ncclRecv pairs replaced by device-to-device copies, G = 2 / 4 logical ranks on one device) and with G = 1;
+ * the RCCL calls themselves only by a G = 1 run.  Until a run on two cards is on record, qm2_shards_open refuses G > 1
+ * over RCCL unless QM2_SHARDS_EXPERIMENTAL=1 is set (the CLI's help says the same).
+ *
+ * Dealing: the reader's commits (whole sequence lines, at most a staging buffer each) go to the ranks ROUND-ROBIN, so a
+ * small input is routed by all GPUs, not by the first one alone; when the rank whose turn it is cannot take a commit,
+ * the round runs with what every rank holds.  A line longer than a staging buffer (a chromosome per line) arrives
+ * through qm2_shards_submit, is cut into staging-sized pieces that stay on ONE rank, back to back — cuts of a round only
+ * ever fall on line ends — and, if the rank's batch fills in the middle of it, goes on behind a round with its last
+ * bytes as look-back (qm2_route_device_carry), like a line that qm2_submit has to cut.
  */
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -68,7 +76,8 @@ struct Rank {
     uint64_t    own_lo = 0, own_hi = 0, lo = 0, hi = 0;
     uint8_t    *text = nullptr;         /* this round's sequence lines */
     size_t      fill = 0;
-    std::vector<size_t> cuts;           /* ends of the commits in `text`: where a round may be cut */
+    size_t      carry0 = 0;             /* the first bytes of `text` are the look-back of a line cut by the previous round */
+    std::vector<size_t> cuts;           /* line ends at the ends of commits in `text`: where a round may be cut */
     std::vector<uint64_t> wraps;        /* where the reference's uint16 run counter wraps (:402; lines of >= 65536 bases), in `text` */
     uint64_t   *d_wraps = nullptr;
     size_t      wraps_cap = 0;
@@ -90,8 +99,8 @@ struct qm2_shards {
     std::vector<Rank> r;
     std::vector<Slot> slots;
     uint32_t  next_slot = 0;
-    int       feed = 0;                 /* the rank whose batch is being filled */
-    int       turn = 0;                 /* exchange set of the next round */
+    int       feed = 0;                 /* the rank whose turn it is (round-robin by commit) */
+    qm2::LineStream ls;             /* an over-long line across staged pieces: run-counter wraps, look-back */
     qm2_ctx  *result = nullptr;
     unsigned long long n_bases = 0, n_kmers = 0;
     qm2_shards_info info = {0, 0, 0};
@@ -132,6 +141,11 @@ extern "C" int qm2_shards_open(qm2_shards **out, int dict_fd, uint64_t hash_size
     s->H = hash_size;
     s->k = k;
     s->fake = getenv("QM2_SHARDS_FAKE_EXCHANGE") != nullptr;
+    if (n_devices > 1 && !s->fake && !getenv("QM2_SHARDS_EXPERIMENTAL")) {
+        delete s;
+        return fail("--shards on more than one GPU is experimental: its RCCL exchange has not been run on two physical GPUs yet "
+                    "(set QM2_SHARDS_EXPERIMENTAL=1 to use it; --devices a,b,.. is the tested multi-GPU path)");
+    }
     for (int i = 0; i < n_devices && !s->fake; i++)
         for (int j = 0; j < i; j++)
             if (devices[i] == devices[j]) {
@@ -237,8 +251,9 @@ static int round_range(qm2_shards *s, const std::vector<size_t> &lo, const std::
                 S_OK(hipStreamSynchronize(R.s_route));             /* (an earlier route may still read the list) */
                 S_OK(hipMemcpy(R.d_wraps, sup.data(), sup.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
             }
-            if (qm2_route_device(R.rctx, R.text + lo[(size_t)g], hi[(size_t)g] - lo[(size_t)g], sup.empty() ? nullptr : R.d_wraps, sup.size(),
-                                 e.slabs, s->cap, (uint32_t)G, e.fill, (uint64_t *)e.call))
+            /* (a piece that starts at the text's first byte may start with the look-back of a cut line) */
+            if (qm2_route_device_carry(R.rctx, R.text + lo[(size_t)g], hi[(size_t)g] - lo[(size_t)g], lo[(size_t)g] == 0 ? (uint32_t)R.carry0 : 0u,
+                                       sup.empty() ? nullptr : R.d_wraps, sup.size(), e.slabs, s->cap, (uint32_t)G, e.fill, (uint64_t *)e.call))
                 return 1;
         }
         S_OK(hipSetDevice(R.dev));
@@ -273,7 +288,7 @@ static int round_range(qm2_shards *s, const std::vector<size_t> &lo, const std::
              * k-mer): half of the ranks now, the others in a round of their own; one rank's one commit always fits */
             std::vector<int> live;
             for (int g = 0; g < G; g++) if (hi[(size_t)g] > lo[(size_t)g]) live.push_back(g);
-            if (live.size() < 2) return fail("qm2 shards: one commit does not fit a slab");
+            if (live.size() < 2) return fail("qm2 shards: the k-mers between two line ends do not fit an owner's slab (one line of a single repeated k-mer, longer than a rank's share of a batch?)");
             std::vector<size_t> hi_a(hi), lo_b(lo);
             for (size_t i = 0; i < live.size(); i++) {
                 const size_t g = (size_t)live[i];
@@ -357,7 +372,7 @@ static int run_round(qm2_shards *s)
     }
     if (round_range(s, lo, hi, 0)) return 1;
     /* (the routes have finished — the host waited for their verdict — so the text buffers are free again) */
-    for (Rank &R : s->r) { R.fill = 0; R.cuts.clear(); R.wraps.clear(); }
+    for (Rank &R : s->r) { R.fill = 0; R.carry0 = 0; R.cuts.clear(); R.wraps.clear(); }
     s->feed = 0;
     return 0;
 }
@@ -384,13 +399,24 @@ extern "C" int qm2_shards_acquire(qm2_shards *s, char **buf, size_t *capacity)
     return fail("qm2_shards_acquire: every staging buffer is held");
 }
 
-/* n bytes of whole lines at `src` (pinned: `owner`) into the batch of the rank being fed */
-static int stage(qm2_shards *s, const char *src, size_t n, Slot *owner)
+/* n bytes at `src` (pinned: `owner`) into the batch of the rank whose turn it is.  ends_line: the last byte is a line
+ * end (every commit of the reader; the last piece of an over-long line) — only there may a round be cut, and only then
+ * does the turn pass on. */
+static int stage(qm2_shards *s, const char *src, size_t n, Slot *owner, bool ends_line)
 {
     if (n > s->staging_bytes) return fail("qm2 shards: more bytes than a staging buffer holds");
-    if (s->r[(size_t)s->feed].fill + n > s->batch_bytes) {               /* this rank's batch is full: the next one's turn */
-        if (s->feed + 1 < s->G) s->feed++;
-        else if (run_round(s)) return 1;
+    if (s->r[(size_t)s->feed].fill + n > s->batch_bytes) {
+        /* this rank's batch is full: the round runs with what every rank holds (they were dealt the same amounts) */
+        if (run_round(s)) return 1;
+        /* ... under a line: it goes on in the empty batch behind its last bytes, which only serve as look-back */
+        Rank &R0 = s->r[(size_t)s->feed];
+        char look[qm2::kCarry];
+        const size_t carry = s->ls.carry_into(look, R0.wraps);
+        if (carry) {
+            S_OK(hipSetDevice(R0.dev));
+            S_OK(hipMemcpy(R0.text, look, carry, hipMemcpyHostToDevice));    /* (rare, 32 bytes; the text is free: run_round waited for the routes) */
+            R0.fill = R0.carry0 = carry;
+        }
     }
     Rank &R = s->r[(size_t)s->feed];
     S_OK(hipSetDevice(R.dev));
@@ -399,11 +425,14 @@ static int stage(qm2_shards *s, const char *src, size_t n, Slot *owner)
     owner->busy = true;
     {
         std::vector<uint64_t> w;
-        qm2::find_wraps(src, n, w);
+        s->ls.piece(src, n, ends_line, w);
         for (uint64_t p : w) R.wraps.push_back(p + R.fill);
     }
     R.fill += n;
-    R.cuts.push_back(R.fill);
+    if (ends_line) {
+        R.cuts.push_back(R.fill);
+        s->feed = (s->feed + 1) % s->G;
+    }
     return 0;
 }
 
@@ -416,27 +445,28 @@ extern "C" int qm2_shards_commit(qm2_shards *s, char *buf, size_t n)
     owner->lent = false;
     if (n == 0) return 0;
     if (buf[n - 1] != '\n') return fail("qm2_shards_commit: buffer must end with a newline (whole sequence lines only)");
-    return stage(s, buf, n, owner);
+    if (s->ls.open) return fail("qm2_shards_commit: a line is still open (qm2_shards_submit)");   /* (cannot happen: submit closes what it opens) */
+    return stage(s, buf, n, owner, true);
 }
 
 extern "C" int qm2_shards_submit(qm2_shards *s, const char *lines, size_t n)
 {
     if (!s || (!lines && n)) return fail("qm2_shards_submit: null argument");
     if (n && lines[n - 1] != '\n') return fail("qm2_shards_submit: buffer must end with a newline (whole sequence lines only)");
-    /* (a pageable buffer: through the staging ring, cut at line ends; a line longer than a staging buffer is not supported here) */
+    /* a pageable buffer: through the staging ring, cut at line ends; a line longer than a staging buffer in pieces that
+     * stay on one rank (stage) */
     size_t at = 0;
     while (at < n) {
         char *buf;
         size_t cap;
         if (qm2_shards_acquire(s, &buf, &cap)) return 1;
-        size_t take = std::min(cap, n - at);
-        if (at + take < n) {
-            const void *nl = memrchr(lines + at, '\n', take);
-            if (!nl) { (void)qm2_shards_commit(s, buf, 0); return fail("qm2 shards: a line longer than a staging buffer"); }
-            take = (size_t)((const char *)nl - (lines + at)) + 1;
-        }
+        Slot *owner = nullptr;
+        for (Slot &sl : s->slots) if (sl.lent && sl.host == buf) owner = &sl;
+        owner->lent = false;
+        bool ends_line = true;
+        const size_t take = qm2::next_piece(lines + at, n - at, cap, s->ls.open, &ends_line);
         memcpy(buf, lines + at, take);
-        if (qm2_shards_commit(s, buf, take)) return 1;
+        if (stage(s, buf, take, owner, ends_line)) return 1;
         at += take;
     }
     return 0;

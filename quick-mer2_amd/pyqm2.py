@@ -54,7 +54,7 @@ class Dup(C.Structure):
 
 
 # every symbol include/qm2.h and include/qm2_tools.h declare
-ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_probe_slabs_device", "qm2_probe_subslabs_device", "qm2_route_xcd_device", "qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
+ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_route_device_carry", "qm2_probe_slabs_device", "qm2_probe_subslabs_device", "qm2_route_xcd_device", "qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
                "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_chain_gc_sums_fd", "qm2_submit_raw_device", "qm2_staging_commit_raw", "qm2_raw_verdict",
                "qm2_shard_span", "qm2_last_error",
@@ -122,6 +122,8 @@ def lib():
     L.qm2_merge_counters.argtypes = [vp, vp]
     L.qm2_route_device.restype = C.c_int
     L.qm2_route_device.argtypes = [vp, vp, C.c_size_t, vp, u64, vp, u64, u32, vp, vp]
+    L.qm2_route_device_carry.restype = C.c_int
+    L.qm2_route_device_carry.argtypes = [vp, vp, C.c_size_t, u32, vp, u64, vp, u64, u32, vp, vp]
     L.qm2_probe_slabs_device.restype = C.c_int
     L.qm2_probe_slabs_device.argtypes = [vp, vp, u64, u32, vp]
     L.qm2_probe_subslabs_device.restype = C.c_int
@@ -277,6 +279,10 @@ class Counter:
     def route_device(self, ptr, n, slabs_ptr, slab_cap, n_owners, fill_ptr, call_ptr, suppress_ptr=None, n_suppress=0):
         _check(lib().qm2_route_device(self._h, ptr, n, suppress_ptr, n_suppress, slabs_ptr, slab_cap, n_owners, fill_ptr,
                                       call_ptr), "qm2_route_device")
+
+    def route_device_carry(self, ptr, n, carry, slabs_ptr, slab_cap, n_owners, fill_ptr, call_ptr, suppress_ptr=None, n_suppress=0):
+        _check(lib().qm2_route_device_carry(self._h, ptr, n, carry, suppress_ptr, n_suppress, slabs_ptr, slab_cap, n_owners,
+                                            fill_ptr, call_ptr), "qm2_route_device_carry")
 
     def probe_slabs_device(self, slabs_ptr, slab_cap, n_slabs, fill_ptr):
         _check(lib().qm2_probe_slabs_device(self._h, slabs_ptr, slab_cap, n_slabs, fill_ptr), "qm2_probe_slabs_device")

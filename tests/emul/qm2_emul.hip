@@ -72,6 +72,68 @@ uint64_t qm2e_extract(const char *buf, size_t n, uint32_t k, size_t staging_byte
     return km.size();
 }
 
+/* Emulates the dealing of quick-mer2_amd/csrc/qm2_shards.hip (qm2_shards_submit -> stage -> run_round) with the product's
+ * own planner pieces (qm2_plan.h: next_piece, LineStream): the stream is staged in pieces of at most `piece_cap` bytes,
+ * round-robin over `n_ranks` texts of `batch_bytes` each; an over-long line stays on one rank and, when that rank's batch
+ * ends under it, goes on behind a round with its look-back.  Every round "routes" each rank's text through the encoder
+ * (carry bytes emit nothing, wraps as suppress entries).  Returns the k-mers of all rounds (order: by round and rank). */
+uint64_t qm2e_extract_dealt(const char *buf, size_t n, uint32_t k, size_t piece_cap, size_t batch_bytes, int n_ranks,
+                            uint64_t *out, uint64_t cap, uint64_t *n_bases, uint64_t *n_rounds)
+{
+    struct RankText { std::vector<uint8_t> text; size_t carry0 = 0; std::vector<uint64_t> wraps; };
+    std::vector<RankText> R((size_t)n_ranks);
+    std::vector<uint64_t> km;
+    uint64_t bases = 0, rounds = 0;
+    LineStream ls;
+    int feed = 0;
+    auto run_round = [&]() {
+        bool any = false;
+        for (RankText &r : R) {
+            if (r.text.empty()) continue;
+            any = true;
+            std::vector<uint8_t> dev(r.text.size() + 64 + 32, 0x41);
+            uint8_t *data = (uint8_t *)(((uintptr_t)dev.data() + 15) & ~(uintptr_t)15) + 5;       /* (misaligned on purpose) */
+            memcpy(data, r.text.data(), r.text.size());
+            SeqView sv;
+            sv.lead = (uintptr_t)data & 15u;
+            sv.base = data - sv.lead;
+            sv.emit_from = sv.lead + r.carry0;
+            sv.n_total = sv.lead + r.text.size();
+            sv.suppress = r.wraps.empty() ? nullptr : r.wraps.data();
+            sv.n_suppress = r.wraps.size();
+            if (k == 30) emul_part<true>(sv, k, km, &bases);
+            else emul_part<false>(sv, k, km, &bases);
+            r.text.clear(); r.carry0 = 0; r.wraps.clear();
+        }
+        if (any) rounds++;
+        feed = 0;
+    };
+    size_t at = 0;
+    while (at < n) {
+        bool ends_line = true;
+        const size_t take = next_piece(buf + at, n - at, piece_cap, ls.open, &ends_line);
+        if (R[(size_t)feed].text.size() + take > batch_bytes) {
+            run_round();
+            char look[kCarry];
+            RankText &r0 = R[(size_t)feed];
+            const size_t carry = ls.carry_into(look, r0.wraps);
+            if (carry) { r0.text.assign(look, look + carry); r0.carry0 = carry; }
+        }
+        RankText &r = R[(size_t)feed];
+        std::vector<uint64_t> w;
+        ls.piece(buf + at, take, ends_line, w);
+        for (uint64_t p : w) r.wraps.push_back(p + r.text.size());
+        r.text.insert(r.text.end(), buf + at, buf + at + take);
+        if (ends_line) feed = (feed + 1) % n_ranks;
+        at += take;
+    }
+    run_round();
+    for (uint64_t i = 0; i < km.size() && i < cap; i++) out[i] = km[i];
+    if (n_bases) *n_bases = bases;
+    if (n_rounds) *n_rounds = rounds;
+    return km.size();
+}
+
 uint32_t qm2e_djb32(uint64_t kmer) { return djb32(kmer); }
 
 /* the buffer layouts of a partition level (slot_of): where k-mer e of region r goes */

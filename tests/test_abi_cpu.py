@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(pkg):
         assert hasattr(L, n), n
     assert sorted(pkg.pyqm2.ABI_SYMBOLS) == declared("qm2.h")
     assert sorted(pkg.pyqm2.TOOL_SYMBOLS) == declared("qm2_tools.h")
-    assert L.qm2_abi_version() == 4
+    assert L.qm2_abi_version() == 5
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "quick-mer2_amd", "libqm2_hip.so")],
                          stdout=subprocess.PIPE, check=True).stdout.decode()
     exported = set(re.findall(r" T (qm2t?_[a-z_0-9]+)", out))

@@ -162,3 +162,42 @@ def test_partition_buffer_layouts_are_one_to_one():
     # a region's segment s starts at row s, column region
     assert L.qm2e_slot_of(1, 5, 2 * seg + 7, cap, lg_row) == (2 << lg_row) + 5 * seg + 7
     assert L.qm2e_slot_of(0, 5, 2 * seg + 7, cap, lg_row) == 5 * cap + 2 * seg + 7
+
+
+def emul_extract_dealt(blob, k, piece_cap, batch_bytes, n_ranks):
+    L = emul()
+    L.qm2e_extract_dealt.restype = C.c_uint64
+    L.qm2e_extract_dealt.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
+                                     C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    nb, nr = C.c_uint64(0), C.c_uint64(0)
+    cap = len(blob) + 16
+    out = np.empty(cap, dtype=np.uint64)
+    n = L.qm2e_extract_dealt(blob, len(blob), k, piece_cap, batch_bytes, n_ranks, out.ctypes.data, cap, C.byref(nb), C.byref(nr))
+    return out[:n], int(nb.value), int(nr.value)
+
+
+@pytest.mark.parametrize("k", [30, 25, 31, 12])
+def test_shards_dealing_of_long_lines(k):
+    """`quicKmer2 count --shards` deals the stream of sequence lines to its ranks in staged pieces (qm2_shards.hip with
+    qm2_plan.h's next_piece / LineStream): round-robin by commit, a line longer than a staging buffer in pieces that stay
+    on one rank, and — when that rank's batch ends under the line — on behind a round with its last 32 bytes as look-back
+    (which emit nothing), the uint16 run-counter wraps followed across pieces and batches.  The k-mers of all rounds are
+    the oracle's, as a multiset (the ranks' order is not the stream's), and so are the bases."""
+    tile = synth.kat_reference().tobytes()
+    s = bytearray((tile * 60)[:250000])
+    for p in (1234, 65500, 70000, 70001, 135535, 200000):
+        s[p] = ord("N")
+    long_n = bytes(s)
+    blobs = [fuzz_blob(7 + k, n_lines=120),
+             b"ACGT\n" + (tile * 30)[:140000] + b"\n" + tile[:100] + b"\n" + (tile * 30)[7:131100] + b"\n",
+             long_n + b"\n" + long_n[:66000] + b"\n" + fuzz_blob(3, n_lines=40) + long_n[100:70000] + b"\n"]
+    for bi, blob in enumerate(blobs):
+        exp, exp_nb = ol.extract(blob, k)
+        exp = np.sort(exp)
+        for piece, batch, ranks in ((1 << 20, 1 << 22, 1), (20000, 40000, 4), (4096, 65536, 2), (97, 500, 3), (33, 66, 1),
+                                    (65536, 65536, 2), (50000, 1 << 22, 4)):
+            got, nb, rounds = emul_extract_dealt(blob, k, piece, batch, ranks)
+            assert nb == exp_nb, (k, bi, piece, batch, ranks)
+            assert np.array_equal(np.sort(got), exp), (k, bi, piece, batch, ranks)
+            if batch * ranks < len(blob) // 2:
+                assert rounds >= 2

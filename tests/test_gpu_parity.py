@@ -245,13 +245,17 @@ def test_cli_shards_config4_from_the_c_host(tmp_path):
     for name, c in MAN["sets"]["kat"]["cases"].items():
         rp = _reads_path("kat", name, str(tmp_path))
         out = str(tmp_path / ("shk_" + name))
-        r = subprocess.run([CLI, "count", "-t", "2", "--shards", "0,0,0,0", os.path.join(GOLD, "kat", "ref.fa"), rp, out],
-                           env=dict(fake, QM2_SHARDS_BATCH_BYTES="600000"),      # (a staging buffer must hold the longest line: 140 kb here)
-                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-        assert r.returncode == 0, (name, r.stdout)
-        assert ("total %d kmers" % c["n_kmers"]).encode() in r.stdout, name
-        assert open(out + ".bin", "rb").read() == open(os.path.join(GOLD, "kat", name + ".bin"), "rb").read(), name
-        assert md5_file(out + ".txt") == c["txt_md5"], name
+        # 600000: a staging buffer holds the longest line (140 kb).  The long-line cases once more with batches of 40 kB: the line
+        # arrives through qm2_shards_submit, is staged in 20 kB pieces that stay on one rank, and the rank's batch ends under
+        # it, so it goes on behind a round with its last 32 bytes as look-back (qm2_route_device_carry) — around the uint16
+        # run-counter wraps at base 65536 / 131072 as well
+        for bb in ("600000", "40000") if name.startswith("long") else ("600000",):
+            r = subprocess.run([CLI, "count", "-t", "2", "--shards", "0,0,0,0", os.path.join(GOLD, "kat", "ref.fa"), rp, out],
+                               env=dict(fake, QM2_SHARDS_BATCH_BYTES=bb), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            assert r.returncode == 0, (name, bb, r.stdout)
+            assert ("total %d kmers" % c["n_kmers"]).encode() in r.stdout, (name, bb)
+            assert open(out + ".bin", "rb").read() == open(os.path.join(GOLD, "kat", name + ".bin"), "rb").read(), (name, bb)
+            assert md5_file(out + ".txt") == c["txt_md5"], (name, bb)
     # skew: 4000 poly-A reads in front of the mini reads send whole rounds to the owner of k-mer 0's home slot
     qm = ol.load_qm(ref_prefix + ".qm")
     lines = (b"A" * 150 + b"\n") * 4000 + ol.strip_reads(rfq)
@@ -266,8 +270,12 @@ def test_cli_shards_config4_from_the_c_host(tmp_path):
     assert ("total %d kmers" % exp_st["n_kmers"]) in text
     assert int(text.split(" cut and routed again")[0].split()[-1]) >= 1, text
     assert open(out + ".bin", "rb").read() == exp_depth[ol.chain_order(qm)].astype("<u2").tobytes()
-    # the same GPU twice is refused when the exchange is RCCL's
+    # more than one GPU over RCCL is experimental until a run on two cards is on record: refused without the opt-in ...
     r = subprocess.run([CLI, "count", "--shards", "0,0", ref_prefix, rfq, str(tmp_path / "dup")], stdout=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"experimental" in r.stdout
+    # ... and with it, the same GPU twice is refused when the exchange is RCCL's
+    r = subprocess.run([CLI, "count", "--shards", "0,0", ref_prefix, rfq, str(tmp_path / "dup")], stdout=subprocess.PIPE, timeout=120,
+                       env=dict(os.environ, QM2_SHARDS_EXPERIMENTAL="1"))
     assert r.returncode != 0 and b"listed twice" in r.stdout
 
 
@@ -277,7 +285,7 @@ def test_cli_shards_on_two_physical_gpus(tmp_path):
     m = MAN["sets"]["mini"]
     fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
     ref_prefix = os.path.join(GOLD, "mini", "ref.fa")
-    env = dict(os.environ, QM2_SHARDS_BATCH_BYTES="300000", QM2_TIMING="1")
+    env = dict(os.environ, QM2_SHARDS_BATCH_BYTES="300000", QM2_TIMING="1", QM2_SHARDS_EXPERIMENTAL="1")
     for tag, reads in (("fa", rfa), ("fq", rfq)):
         out = str(tmp_path / ("sh2_" + tag))
         r = subprocess.run([CLI, "count", "-t", "3", "--shards", "0,1", ref_prefix, reads, out], stdout=subprocess.PIPE, timeout=600, env=env)
@@ -1248,6 +1256,67 @@ def test_route_by_sub_slabs_is_the_receivers_first_level(qm2, torch_cuda, tmp_pa
         f = torch.zeros(8, dtype=torch.int32, device="cuda")
         with pytest.raises(qm2.Qm2Error):
             pc.probe_subslabs_device(z.data_ptr(), 64, 1, 8, f.data_ptr())
+
+
+def test_entry_points_mixed_on_one_context_replan(qm2, torch_cuda, tmp_path):
+    """qm2_probe_subslabs_device plans the context with level 0 given from outside (no buffer, no cursors of its own
+    there); sequence text or one-slab-per-owner input afterwards needs the context's own level 0 again.  The calls may be
+    mixed in any order on one context: every one re-plans when the kind changes (a launch on the other kind's plan would
+    reserve in the wrong cursors and count stale buffer contents), and the counts add up exactly."""
+    torch = torch_cuda
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    keys, H = qm["keys"], len(qm["keys"])
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    blob = ol.strip_reads(rfa)
+    d_text = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+    exp_kmers, nb = ol.extract(blob, 30)
+    exp_depth, exp_st = ol.count_lines(keys, 30, blob)
+    n_subs = 4
+    cap = (len(exp_kmers) // n_subs * 2 + 4096) & ~1
+    sub = torch.zeros(n_subs * cap, dtype=torch.int64, device="cuda")
+    sub_fill = torch.zeros(n_subs, dtype=torch.int32, device="cuda")
+    one = torch.zeros(n_subs * cap, dtype=torch.int64, device="cuda")
+    one_fill = torch.zeros(1, dtype=torch.int32, device="cuda")
+    call = torch.zeros(3, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    with qm2.Counter(None, hash_size=H, k=30, flags=qm2.FLAG_KEYS_LATER, span=(0, 64)) as router:
+        router.route_device(d_text.data_ptr(), d_text.numel(), sub.data_ptr(), cap, n_subs, sub_fill.data_ptr(), call.data_ptr())
+        router.route_device(d_text.data_ptr(), d_text.numel(), one.data_ptr(), n_subs * cap, 1, one_fill.data_ptr(), call.data_ptr())
+        router.sync()
+    assert int(call[2]) == 0 and int(one_fill[0]) == len(exp_kmers)
+    orders = [("sub", "text", "sub", "slab", "text", "sub"), ("text", "sub", "slab", "sub"), ("slab", "sub", "text")]
+    for order in orders:
+        with qm2.Counter(keys, hash_size=H, k=30, own=(0, H), span=(0, H), flags=qm2.FLAG_PARTITION | qm2.FLAG_TIMING) as pc:
+            for what in order:
+                if what == "sub":
+                    pc.probe_subslabs_device(sub.data_ptr(), cap, 1, n_subs, sub_fill.data_ptr())
+                elif what == "slab":
+                    pc.probe_slabs_device(one.data_ptr(), n_subs * cap, 1, one_fill.data_ptr())
+                else:
+                    pc.submit_device(d_text.data_ptr(), d_text.numel())
+            d, st = pc.finish()
+            prof = pc.profile()
+        n = len(order)
+        assert prof["partitioned_batches"] == n and prof["fallback_batches"] == 0 and prof["spilled_kmers"] == 0, (order, prof)
+        assert st["n_hits"] == n * exp_st["n_hits"] and st["n_probes"] == n * exp_st["n_probes"], order
+        assert np.array_equal(d.astype(np.uint32), (n * exp_depth.astype(np.uint32)) & 0xFFFF), order
+
+
+def test_bench_replicas_two_ranks_on_one_gpu(torch_cuda, tmp_path):
+    """bench.py's N > 1 replica path with TWO ranks (both on this card, collectives over gloo: QM2_REHEARSE_ON_ONE_GPU):
+    every rank must complete its counters (fold the 2-byte bucket interiors: qm2_finish) BEFORE the job's one reduce,
+    or the merged table lacks the other ranks' interior counts — `counts_conserved` is the check, on the merged result."""
+    env = dict(os.environ, QM2_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "c2", "--reads-per-step", "4000000", "--mode", "partition", "--no-streamed",
+                        "--no-cpu-baseline", "--no-geometry-check"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["counts_conserved"] is True, line["config"]
+    assert line["roofline"]["mode"] == "partitioned" and line["config"]["final_reduce_ms"] is not None
+    assert line["value"] > 0
 
 
 def test_multi_drivers_on_the_gpu_single_rank(qm2, torch_cuda, tmp_path):
