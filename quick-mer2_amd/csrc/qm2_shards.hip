@@ -100,6 +100,7 @@ struct qm2_shards {
     std::vector<Slot> slots;
     uint32_t  next_slot = 0;
     int       feed = 0;                 /* the rank whose turn it is (round-robin by commit) */
+    int       turn = 0;                 /* exchange set of the next round */
     qm2::LineStream ls;             /* an over-long line across staged pieces: run-counter wraps, look-back */
     qm2_ctx  *result = nullptr;
     unsigned long long n_bases = 0, n_kmers = 0;
