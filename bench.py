@@ -570,12 +570,12 @@ def main():
         fn(acc)
         nl, npw = max(1, acc[8]), max(1, acc[9])
         lt = sum(acc[i] for i in (0, 1, 2, 3, 10))
-        ptot = sum(acc[i] for i in (4, 5, 6, 7))
+        ptot = sum(acc[i] for i in (4, 5, 6, 7, 11))
         sys.stderr.write("STAMPS loaders=%d cycles/wave=%.0f flush=%.1f%% wait_regs=%.1f%% stage=%.1f%% fetch_issue=%.1f%% barrier=%.1f%% | "
-                         "probers=%d cycles/wave=%.0f kmer_loads=%.1f%% phase_a=%.1f%% phase_b=%.1f%% barrier=%.1f%%\n"
+                         "probers=%d cycles/wave=%.0f kmer_arrival_wait=%.1f%% kmer_load_issue=%.1f%% phase_a=%.1f%% phase_b=%.1f%% barrier=%.1f%%\n"
                          % (nl, lt / nl, 100.0 * acc[0] / max(1, lt), 100.0 * acc[10] / max(1, lt), 100.0 * acc[1] / max(1, lt),
                             100.0 * acc[2] / max(1, lt), 100.0 * acc[3] / max(1, lt),
-                            npw, ptot / npw, 100.0 * acc[4] / max(1, ptot), 100.0 * acc[5] / max(1, ptot),
+                            npw, ptot / npw, 100.0 * acc[11] / max(1, ptot), 100.0 * acc[4] / max(1, ptot), 100.0 * acc[5] / max(1, ptot),
                             100.0 * acc[6] / max(1, ptot), 100.0 * acc[7] / max(1, ptot)))
         if acc[20]:
             tot = sum(acc[16:20])

@@ -94,6 +94,13 @@ struct qm2_ctx {
      * adds the small array into the big one before anybody looks (qm2_finish, merge, the chain gather). */
     uint16_t   *interior16 = nullptr;
     bool        interior_dirty = false;
+    /* The table image (qm2_partition.hip.h, table_image_kernel): every resident slot as a bucket record — 4 bytes of R
+     * and a second word of rec_bytes - 4 — made once per key table, behind the look at the runs of occupied slots.  It
+     * is what bucket_count streams instead of the keys (6 bytes a slot at hg38 scale, nothing to hash). */
+    uint32_t   *img_r = nullptr;
+    void       *img_w = nullptr;
+    bool        img_ready = false;
+    uint32_t    rec_bytes = 0;              /* 6 or 8: a bucket record (finest level of the partition, table image); 0: no plan */
     bool        keys_consumed = false;      /* the chain was uploaded over the key table */
     std::atomic<bool> keys_pending{false};  /* QM2_FLAG_KEYS_LATER: qm2_keys_from_fd has not run yet */
     std::atomic<uint64_t> n_allocations{0}; /* hipMalloc / hipHostMalloc calls so far (qm2_profile.allocations; counted from both threads) */

@@ -37,6 +37,8 @@ struct TableView {
     const uint64_t *keys;      /* slots [span_lo, span_hi) of the table          */
     uint32_t       *counters;  /* same span, 32-bit accumulators                 */
     uint16_t       *interior16;/* same span: the private bucket interiors of bucket_count (qm2_ctx.h); else unused */
+    const uint32_t *img_r;     /* same span: the table image bucket_count stages — every slot as a bucket record, */
+    const void     *img_w;     /* ... R and second word (2 or 4 bytes; qm2_partition.hip.h); else unused          */
     uint64_t        span_lo;   /* global slot index of keys[0]                   */
     uint32_t        hmask;     /* H - 1 (H <= 2^32)                              */
     uint32_t        hhalf;     /* H >> 1                                         */
@@ -172,6 +174,38 @@ __host__ __device__ __forceinline__ uint32_t djb32(uint64_t kmer)
 #endif
     return x + djb_s4((uint32_t)(kmer >> 32)) + 0x7BB34A05u;                     /* + 5381 * 33^8 mod 2^32 */
 }
+
+/* ---- bucket records: a k-mer inside its finest bucket, in 6 bytes instead of 8 ----------------------------------
+ *
+ * The finest level of the partition (qm2_partition.hip.h) holds the k-mers of ONE bucket of S = 2^lg_s home slots,
+ * so the bucket bits of their hash (home slot, :92) are known from where they lie.  The DJB hash (:66-76) is linear in
+ * the k-mer's bytes b0..b7 (b0 lowest):
+ *       h = C + 33^3 * V + (1089 b5 + 33 b6 + b7)   (mod 2^32),     V = 33^4 b0 + 33^3 b1 + 33^2 b2 + 33 b3 + b4,
+ * and V < 2^29 never wraps, so (33^3 being odd) the FULL hash and b5..b7 give V exactly.  V is a number in base 33
+ * whose digits b1..b4 run up to 255; a digit is known from its residue (V mod 33) as soon as its top three bits are:
+ * the values of one residue lie 33 apart and a top-three-bit class is 32 wide.  b0 is what is left.  Hence
+ *       k-mer (60 bits at k = 30)  <->  ( h (32 bits),  R = b5, b6, low half of b7 and the top three bits of b1..b4 (32 bits) )
+ * is one to one: 28 bits of the k-mer are never written.  (k = 31: the two bits above R's 20 travel beside the hash
+ * as `x`.)  A bucket record is R plus what the bucket does not say about h — its low lg_s bits (which is the home
+ * slot inside the bucket: bucket_count does not hash at all), and the bits above log2 H for tables below 2^32 slots:
+ *       w = (h & (S - 1)) | 0 << lg_s (two code bits, see table_image_kernel) | ((x:h) >> lgH) << (lg_s + 2)
+ * as 16 bits when that fits (hg38 scale: 12 + 2 + 0..2), else 32.  Checked against a decoder in tests/emul. */
+__host__ __device__ __forceinline__ uint32_t rec_r(uint64_t key)
+{
+    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    /* bits 0..2 b4 >> 5, 3..22 b5 b6 b7 & 15 (hi's bits 5..27 as they lie), 23..25 b2 >> 5, 26..28 b1 >> 5, 29..31 b3 >> 5 */
+    return ((hi >> 5) & 0x7FFFFFu) | (((lo >> 21) & 7u) << 23) | (((lo >> 13) & 7u) << 26) | (lo & 0xE0000000u);
+}
+/* the record's second word for a k-mer of hash h (code bits 0) */
+__host__ __device__ __forceinline__ uint32_t rec_w(uint64_t key, uint32_t h, uint32_t lgH, uint32_t lg_s)
+{
+    const uint32_t x = (uint32_t)(key >> 60);                               /* k = 31 only */
+    const uint32_t ext = (uint32_t)((((uint64_t)x << 32) | h) >> lgH);      /* lgH <= 32 */
+    const uint32_t home = lgH >= 32 ? h : h & ((1u << lgH) - 1u);
+    return (home & ((1u << lg_s) - 1u)) | (ext << (lg_s + 2u));
+}
+/* bits of w beside the slot and the code: what must fit 16 - (lg_s + 2) bits for the 2-byte form, 32 - (lg_s + 2) at all */
+__host__ __device__ __forceinline__ uint32_t rec_ext_bits(uint32_t k, uint32_t lgH) { return (32u - lgH) + (k > 30 ? 2u * (k - 30u) : 0u); }
 
 /* The 16 bytes of lane-slot `g` (byte offset from sv.base, a multiple of 16; may be negative
  * or beyond the end), in two steps so that the load can be issued early (software prefetch)

@@ -71,6 +71,8 @@ static TableView table_view(const qm2_ctx *c)
     tv.keys = c->keys;
     tv.counters = c->counters;
     tv.interior16 = c->interior16;
+    tv.img_r = c->img_r;
+    tv.img_w = c->img_w;
     tv.span_lo = c->span_lo;
     tv.hmask = (uint32_t)(c->H - 1);
     tv.hhalf = (uint32_t)(c->H >> 1);
@@ -151,6 +153,11 @@ static void part_init(qm2_ctx *c, int max_bits, int first_bits = 0)
     while ((1ull << p.lg_range) < c->own_hi - c->own_lo) p.lg_range++;
     const int nb = (int)p.lg_range - kLgS;                           /* bits of the finest bucket id */
     if (nb < 1 || c->lgH <= (uint32_t)kLgS) return;   /* fewer than two buckets: counted by the direct kernel */
+    /* the finest level and the table image hold bucket records (qm2_device.hip.h): 6 bytes when the hash bits a bucket
+     * does not imply fit 16 bits beside the slot and the two code bits (hg38 scale: H = 2^32), else 8 */
+    const uint32_t ext = rec_ext_bits(c->k, c->lgH);
+    if ((uint32_t)kLgS + 2u + ext > 32u) return;      /* (k = 31 with fewer than 2^16 slots: the direct kernel) */
+    c->rec_bytes = (uint32_t)kLgS + 2u + ext <= 16u ? 6u : 8u;
     if (first_bits) {
         if (nb - first_bits < 1) return;                             /* nothing left to split behind the given level */
         p.levels = 1 + (nb - first_bits + max_bits - 1) / max_bits;
@@ -242,6 +249,8 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
             if (p.seg0) p.cap[0] = (p.cap[0] + kSegKmers - 1u) & ~(kSegKmers - 1u);
         }
         slots[l] = p.buckets[l] * (l == 0 ? p.subs0 : 1u) * (uint64_t)p.cap[l];
+        /* (the finest level: records of 6 or 8 bytes, two arrays behind each other; counted in 8-byte units here) */
+        if (l == p.levels - 1) slots[l] = (slots[l] * c->rec_bytes + 7) / 8;
     }
     p.buf_slots[0] = std::max(slots[0], slots[2]);
     p.buf_slots[1] = slots[1];
@@ -262,6 +271,18 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess && c->interior16) { (void)hipFree(c->interior16); c->interior16 = nullptr; }
         c->n_allocations++;
+    }
+    if (e == hipSuccess && !c->img_r) {
+        /* the table image (qm2_ctx.h): once per context as well; filled behind the look at the runs (runs_fit) */
+        const uint64_t n_slots = c->span_hi - c->span_lo;
+        e = hipMalloc((void **)&c->img_r, n_slots * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&c->img_w, n_slots * (c->rec_bytes - 4u));
+        if (e != hipSuccess) {
+            if (c->img_r) (void)hipFree(c->img_r);
+            c->img_r = nullptr; c->img_w = nullptr;
+        }
+        c->img_ready = false;
+        c->n_allocations += 2;
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -327,6 +348,25 @@ struct PartSource {
     uint64_t n_bytes = 0;           /* bytes launched (what kmers_per_byte is measured against) */
 };
 
+/* The split kernels by what their destination is: a level of k-mers (fin = 0; segmented or region-major), or the finest
+ * level, written as bucket records with a second word of `fin` = 2 or 4 bytes (always region-major). */
+template <bool K30, bool SEG, uint32_t FX, typename... A>
+static void launch_text_split(int fin, int grid, hipStream_t s, A... a)
+{
+    if constexpr (FX != 0) split_text_kernel<K30, SEG, FX, 0><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);   /* (a level above the finest) */
+    else if (fin == 2)     split_text_kernel<K30, false, 0, 2><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
+    else if (fin == 4)     split_text_kernel<K30, false, 0, 4><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
+    else                   split_text_kernel<K30, SEG, 0, 0><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
+}
+template <bool FLAT, bool SRC_SEG, bool DST_SEG, uint32_t FX, typename... A>
+static void launch_kmer_split(int fin, uint32_t grid, hipStream_t s, A... a)
+{
+    if constexpr (FX != 0) split_kmer_kernel<FLAT, SRC_SEG, false, FX, 2><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...); /* (the finest level of an hg38-scale table) */
+    else if (fin == 2)     split_kmer_kernel<FLAT, SRC_SEG, false, 0, 2><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
+    else if (fin == 4)     split_kmer_kernel<FLAT, SRC_SEG, false, 0, 4><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
+    else                   split_kmer_kernel<FLAT, SRC_SEG, DST_SEG, 0, 0><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
+}
+
 static int launch_partitioned(qm2_ctx *c, const PartSource &src)
 {
     PartPlan &p = c->part;
@@ -336,43 +376,45 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
     HIP_OK(hipGetLastError());
 
     TimedLaunch t;
+    const int L = p.levels - 1;                       /* the finest level: bucket records, R array then second words */
+    const int fin_w = (int)c->rec_bytes - 4;
+    uint32_t *const fin_r = (uint32_t *)p.buf[L & 1];
+    void *const fin_w_at = (void *)(fin_r + p.buckets[L] * (uint64_t)p.cap[L]);
     /* level 1: text or slabs -> buckets[0] */
     if (!src.n_subs) {
         uint32_t lg_subs = 0;
         while ((1u << lg_subs) < p.subs0) lg_subs++;
+        const int fin = L == 0 ? fin_w : 0;
         SplitDst d = {p.buf[0], p.cursors + p.cursor_off[0], p.cap[0], p.spill, p.spill_count, p.spill_cap,
-                      p.bits[0] + lg_subs + kSegLg, p.subs0};
+                      p.bits[0] + lg_subs + kSegLg, p.subs0, fin ? fin_w_at : nullptr, c->lgH, (uint32_t)kLgS};
         if (src.sv) {
             const SeqView &sv = *src.sv;
             const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
             const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * kSplitWgPerCu);
             if (time_begin(c, &t, QM2_K_SPLIT_TEXT)) return 1;
-#define QM2_LAUNCH_TEXT(K30_, SEG_)                                                                                      \
-            hipLaunchKernelGGL((split_text_kernel<K30_, SEG_>), dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k,       \
-                               p.shift[0], p.bits[0], n_chunks, d, c->stats, (unsigned long long *)nullptr)
             /* (the hg38-scale split with its shift and width as constants: split_text 21.57 -> 21.37, split_kmer 24.47 -> 24.17 ms) */
             constexpr uint32_t kFx1 = (22u << 8) | 10u;       /* H = 2^32: level 1 takes bits 22..31 of the home slot */
-            if (c->k == 30 && p.seg0 && p.shift[0] == 22 && p.bits[0] == 10)
-                hipLaunchKernelGGL((split_text_kernel<true, true, kFx1>), dim3(grid), dim3(kSplitThreads), 0, s, sv, c->k,
-                                   p.shift[0], p.bits[0], n_chunks, d, c->stats, (unsigned long long *)nullptr);
-            else if (c->k == 30) { if (p.seg0) QM2_LAUNCH_TEXT(true, true); else QM2_LAUNCH_TEXT(true, false); }
-            else            { if (p.seg0) QM2_LAUNCH_TEXT(false, true); else QM2_LAUNCH_TEXT(false, false); }
-#undef QM2_LAUNCH_TEXT
+#define QM2_TEXT_ARGS sv, c->k, p.shift[0], p.bits[0], n_chunks, d, c->stats, (unsigned long long *)nullptr
+            if (c->k == 30 && !fin && p.seg0 && p.shift[0] == 22 && p.bits[0] == 10) launch_text_split<true, true, kFx1>(0, grid, s, QM2_TEXT_ARGS);
+            else if (c->k == 30) { if (p.seg0) launch_text_split<true, true, 0>(fin, grid, s, QM2_TEXT_ARGS); else launch_text_split<true, false, 0>(fin, grid, s, QM2_TEXT_ARGS); }
+            else                 { if (p.seg0) launch_text_split<false, true, 0>(fin, grid, s, QM2_TEXT_ARGS); else launch_text_split<false, false, 0>(fin, grid, s, QM2_TEXT_ARGS); }
+#undef QM2_TEXT_ARGS
         } else {
             const uint32_t chunks = (uint32_t)std::max<uint64_t>(1, ((src.slab_cap + kSplitSlots - 1) / kSplitSlots + 3) / 4);
             if (time_begin(c, &t, QM2_K_SPLIT_KMER)) return 1;
-#define QM2_LAUNCH_FLAT(SEG_)                                                                                            \
-            hipLaunchKernelGGL((split_kmer_kernel<true, false, SEG_>), dim3(chunks * src.n_slabs), dim3(kSplitThreads), 0, s, \
-                               src.slabs, src.fill, src.slab_cap, 0u, ~0u, p.shift[0], p.bits[0], chunks, src.n_slabs, d, c->stats)
-            if (p.seg0) QM2_LAUNCH_FLAT(true); else QM2_LAUNCH_FLAT(false);
-#undef QM2_LAUNCH_FLAT
+#define QM2_FLAT_ARGS src.slabs, src.fill, src.slab_cap, 0u, ~0u, p.shift[0], p.bits[0], chunks, src.n_slabs, d, c->stats, 0u
+            if (p.seg0) launch_kmer_split<true, false, true, 0>(fin, chunks * src.n_slabs, s, QM2_FLAT_ARGS);
+            else        launch_kmer_split<true, false, false, 0>(fin, chunks * src.n_slabs, s, QM2_FLAT_ARGS);
+#undef QM2_FLAT_ARGS
         }
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
     }
     /* deeper levels: buckets[l-1] -> buckets[l], ping-pong between the two buffers */
     for (int l = 1; l < p.levels; l++) {
-        SplitDst d = {p.buf[l & 1], p.cursors + p.cursor_off[l], p.cap[l], p.spill, p.spill_count, p.spill_cap, 0, 1};
+        const int fin = l == L ? fin_w : 0;
+        SplitDst d = {p.buf[l & 1], p.cursors + p.cursor_off[l], p.cap[l], p.spill, p.spill_count, p.spill_cap, 0, 1,
+                      fin ? fin_w_at : nullptr, c->lgH, (uint32_t)kLgS};
         const uint32_t n_parents = (uint32_t)p.buckets[l - 1] * (l == 1 ? p.subs0 : 1u);
         uint32_t lg_subs = 0;
         while ((1u << lg_subs) < p.subs0) lg_subs++;
@@ -382,11 +424,8 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
         static const uint32_t per_wg = getenv("QM2_SPLIT_CHUNKS_PER_WG") ? std::max(1, atoi(getenv("QM2_SPLIT_CHUNKS_PER_WG"))) : 2u;
         const uint32_t chunks = std::max<uint32_t>(1u, ((p.cap[l - 1] + kSplitSlots - 1) / kSplitSlots + per_wg - 1) / per_wg);
         if (time_begin(c, &t, QM2_K_SPLIT_KMER)) return 1;
-#define QM2_LAUNCH_LEVEL(SRC_SEG_)                                                                                       \
-        hipLaunchKernelGGL((split_kmer_kernel<false, SRC_SEG_, false>), dim3(chunks * n_parents), dim3(kSplitThreads),  \
-                           0, s, p.buf[(l - 1) & 1], p.cursors + p.cursor_off[l - 1], (uint64_t)p.cap[l - 1],         \
-                           p.bits[0] + lg_subs + kSegLg, (uint32_t)p.buckets[l - 1] - 1u, p.shift[l], p.bits[l], chunks, \
-                           n_parents, d, c->stats)
+#define QM2_LEVEL_ARGS p.buf[(l - 1) & 1], p.cursors + p.cursor_off[l - 1], (uint64_t)p.cap[l - 1], p.bits[0] + lg_subs + kSegLg, \
+                       (uint32_t)p.buckets[l - 1] - 1u, p.shift[l], p.bits[l], chunks, n_parents, d, c->stats, 0u
         if (l == 1 && src.n_subs) {
             /* the received sub-slabs are the parents: region (peer, sub) feeds the children of sub — the layout of the
              * per-XCD sub-regions with the sender in the XCD's place */
@@ -394,28 +433,24 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
             const uint32_t ch = std::max<uint32_t>(1u, (uint32_t)(((src.slab_cap + kSplitSlots - 1) / kSplitSlots + 3) / 4));
             uint32_t lg_ns = 0;
             while ((1u << lg_ns) < src.n_subs) lg_ns++;
-            hipLaunchKernelGGL((split_kmer_kernel<false, false, false>), dim3(ch * np), dim3(kSplitThreads), 0, s, src.slabs, src.fill,
-                               src.slab_cap, lg_ns, src.n_subs - 1u, p.shift[l], p.bits[l], ch, np, d, c->stats,
-                               src.peer_stride && src.peer_stride != src.n_subs ? src.peer_stride : 0u);
-        } else if (l == 1 && p.seg0 && p.shift[l] == 12 && p.bits[l] == 10) {
-            constexpr uint32_t kFx2 = (12u << 8) | 10u;       /* ... level 2 bits 12..21 */
-            hipLaunchKernelGGL((split_kmer_kernel<false, true, false, kFx2>), dim3(chunks * n_parents), dim3(kSplitThreads),
-                               0, s, p.buf[(l - 1) & 1], p.cursors + p.cursor_off[l - 1], (uint64_t)p.cap[l - 1],
-                               p.bits[0] + lg_subs + kSegLg, (uint32_t)p.buckets[l - 1] - 1u, p.shift[l], p.bits[l], chunks,
-                               n_parents, d, c->stats, 0u);
-        } else if (l == 1 && p.seg0) QM2_LAUNCH_LEVEL(true); else QM2_LAUNCH_LEVEL(false);
-#undef QM2_LAUNCH_LEVEL
+            launch_kmer_split<false, false, false, 0>(fin, ch * np, s, src.slabs, src.fill, src.slab_cap, lg_ns, src.n_subs - 1u, p.shift[l], p.bits[l], ch, np, d,
+                                                      c->stats, src.peer_stride && src.peer_stride != src.n_subs ? src.peer_stride : 0u);
+        } else if (l == 1 && p.seg0 && fin == 2 && p.shift[l] == 12 && p.bits[l] == 10) {
+            constexpr uint32_t kFx2 = (12u << 8) | 10u;       /* ... level 2 bits 12..21: the finest level of an hg38-scale table */
+            launch_kmer_split<false, true, false, kFx2>(2, chunks * n_parents, s, QM2_LEVEL_ARGS);
+        } else if (l == 1 && p.seg0) launch_kmer_split<false, true, false, 0>(fin, chunks * n_parents, s, QM2_LEVEL_ARGS);
+        else                         launch_kmer_split<false, false, false, 0>(fin, chunks * n_parents, s, QM2_LEVEL_ARGS);
+#undef QM2_LEVEL_ARGS
         HIP_OK(hipGetLastError());
         if (time_end(c, &t)) return 1;
     }
     /* finest buckets + table slices -> counters (skipped on device if the batch lost k-mers) */
     {
-        const int L = p.levels - 1;
         const uint32_t n_buckets = (uint32_t)p.buckets[L];
         const int grid = (int)std::min<uint64_t>(n_buckets, (uint64_t)c->n_cu * QM2_COUNT_GRID_MULT);
         if (time_begin(c, &t, QM2_K_BUCKET_COUNT)) return 1;
         c->interior_dirty = true;
-        /* the group size (16-byte k-mer loads per prober thread) is picked so that a bucket's fill (mean
+        /* the group size (rows of 2 k-mers per prober thread) is picked so that a bucket's fill (mean
          * + 3 sigma of uniform hashing; k-mers per byte measured on earlier batches through an asynchronous
          * copy of the stats block) wastes the fewest rows */
         stats_peek_harvest(c);
@@ -444,11 +479,14 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
             if (env_g >= 2 && env_g <= 6) g = env_g;
         }
         const CountGeo cg = {c->own_lo, c->span_lo, c->span_hi, c->H >> 1};
-#define QM2_LAUNCH_COUNT(G_, LW_)                                                                               \
-        hipLaunchKernelGGL((bucket_count_kernel<kLgS, G_, LW_>), dim3(grid), dim3(kCountThreads), 0, s,        \
-                           p.buf[L & 1], p.cursors + p.cursor_off[L], p.cap[L], table_view(c), cg, n_buckets,   \
+#define QM2_LAUNCH_COUNT(G_, LW_, WT_)                                                                          \
+        hipLaunchKernelGGL((bucket_count_kernel<kLgS, G_, LW_, WT_>), dim3(grid), dim3(kCountThreads), 0, s,   \
+                           (const uint32_t *)fin_r, (const WT_ *)fin_w_at, p.cursors + p.cursor_off[L], p.cap[L], table_view(c), cg, n_buckets, \
                            p.shared, c->stats)
-#define QM2_LAUNCH_COUNT_LW(G_) do { if (lw == 3) QM2_LAUNCH_COUNT(G_, 3); else QM2_LAUNCH_COUNT(G_, 4); } while (0)
+#define QM2_LAUNCH_COUNT_LW(G_) do {                                                                            \
+            if (fin_w == 2) { if (lw == 3) QM2_LAUNCH_COUNT(G_, 3, uint16_t); else QM2_LAUNCH_COUNT(G_, 4, uint16_t); }  \
+            else            { if (lw == 3) QM2_LAUNCH_COUNT(G_, 3, uint32_t); else QM2_LAUNCH_COUNT(G_, 4, uint32_t); }  \
+        } while (0)
         switch (g) {
             case 2: QM2_LAUNCH_COUNT_LW(2); break;
             case 3: QM2_LAUNCH_COUNT_LW(3); break;
@@ -542,6 +580,25 @@ static int runs_fit(qm2_ctx *c, bool *ok)
     return 0;
 }
 
+/* Fill the table image (qm2_ctx.h) once the keys are there and part_reserve has made room for it: stream-ordered in front
+ * of every bucket_count launch, a 56-GB pass at hg38 scale (~15 ms), once per context. */
+static int table_image(qm2_ctx *c)
+{
+    std::lock_guard<std::mutex> guard(c->runs_mu);
+    if (c->img_ready || !c->img_r || c->keys_pending) return 0;
+    const uint64_t n_slots = c->span_hi - c->span_lo;
+    const int grid = (int)std::min<uint64_t>((n_slots + 255) / 256, (uint64_t)c->n_cu * 32);
+    if (c->rec_bytes == 6)
+        hipLaunchKernelGGL(table_image_kernel<uint16_t>, dim3(grid), dim3(256), 0, c->stream, (const uint64_t *)c->keys, n_slots, c->span_lo,
+                           (uint32_t)(c->H - 1), (uint32_t)kLgS, c->img_r, (uint16_t *)c->img_w);
+    else
+        hipLaunchKernelGGL(table_image_kernel<uint32_t>, dim3(grid), dim3(256), 0, c->stream, (const uint64_t *)c->keys, n_slots, c->span_lo,
+                           (uint32_t)(c->H - 1), (uint32_t)kLgS, c->img_r, (uint32_t *)c->img_w);
+    HIP_OK(hipGetLastError());
+    c->img_ready = true;
+    return 0;
+}
+
 /* Snapshot of the statistics behind the batch just launched, copied to pinned memory by the
  * stream itself: qm2_stats_peek and the group-size choice of the next batches read it once it
  * has landed, nobody waits for it. */
@@ -587,6 +644,7 @@ static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry,
     }
     const uint64_t bound = seq_bound && seq_bound < n ? seq_bound : (uint64_t)n;
     if (part && part_reserve(c, bound)) part = false;                /* no memory: direct */
+    if (part && table_image(c)) return 1;
     if (part) {
         c->prof.partitioned_batches++;
         PartSource src;
@@ -750,6 +808,8 @@ extern "C" void qm2_close(qm2_ctx *c)
     if (c->own_keys && c->keys) (void)hipFree(c->keys);
     if (c->own_counters && c->counters) (void)hipFree(c->counters);
     if (c->interior16) (void)hipFree(c->interior16);
+    if (c->img_r) (void)hipFree(c->img_r);
+    if (c->img_w) (void)hipFree(c->img_w);
     if (c->narrow) (void)hipFree(c->narrow);
     if (c->stats) (void)hipFree(c->stats);
     if (c->stats_peek) (void)hipHostFree(c->stats_peek);
@@ -1111,6 +1171,7 @@ extern "C" int qm2_keys_from_fd(qm2_ctx *c, int fd, uint64_t file_offset)
     if (c->part.reserved) {                                   /* prepared: look at the runs of occupied slots now, not in the first batch */
         bool ok = false;
         if (runs_fit(c, &ok)) return 1;
+        if (table_image(c)) return 1;
     }
     return 0;
 }
@@ -1256,6 +1317,7 @@ extern "C" int qm2_prepare(qm2_ctx *c, uint64_t batch_bytes, uint32_t what)
         if (!c->keys_pending && !c->keys_consumed) {
             bool ok = false;
             if (runs_fit(c, &ok)) return 1;
+            if (table_image(c)) return 1;
         }
     }
     return 0;
@@ -1454,6 +1516,7 @@ extern "C" int qm2_probe_slabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint6
         if (!ok) part = false;
     }
     if (part && part_reserve(c, n_upper)) part = false;
+    if (part && table_image(c)) return 1;
     c->bytes_launched += n_upper;
     if (part) {
         c->prof.partitioned_batches++;
@@ -1512,6 +1575,7 @@ extern "C" int qm2_probe_subslabs_device(qm2_ctx *c, const uint64_t *d_slabs, ui
         HIP_OK(hipGetLastError());
         return time_end(c, &t, true);
     }
+    if (table_image(c)) return 1;
     c->prof.partitioned_batches++;
     PartSource src;
     src.slabs = d_slabs; src.slab_cap = sub_cap; src.n_slabs = n_peers; src.n_subs = n_subs; src.peer_stride = peer_stride; src.fill = d_fill;

@@ -54,6 +54,12 @@ constexpr uint64_t kPad      = ~0ull;                /* never a k-mer (k <= 31 u
 constexpr int kHalo          = QM2_HALO;             /* table slots staged past a bucket's
                                                         middle-facing edge                      */
 constexpr int kCountThreads  = QM2_COUNT_THREADS;
+#ifndef QM2_COUNT_BLOCKED
+#define QM2_COUNT_BLOCKED 0
+#endif
+#ifndef QM2_PREFETCH_LATE
+#define QM2_PREFETCH_LATE 0       /* experiment: ask for the next group behind the first probe set instead of in front of it */
+#endif
 #ifndef QM2_COUNT_SET
 #define QM2_COUNT_SET 6           /* k-mers probed together (measured at C3: 2 -> 23.2, 4 -> 22.9, 6 -> 22.0 ms) */
 #endif
@@ -106,6 +112,10 @@ struct SplitDst {
     uint64_t            spill_cap;
     uint32_t            lg_row;     /* segmented layout: log2(k-mers per row of segments)        */
     uint32_t            subs;       /* 1, or 8: every child's region is cut into one sub-region per XCD (below) */
+    /* the FINEST level (FIN = 2 or 4 in the kernels below) is written as bucket records (qm2_device.hip.h): `kmers` is then
+     * an array of 32-bit words R, region-major like the k-mers would be, and fin_w the array of second words beside it */
+    void               *fin_w;
+    uint32_t            lgH, lg_s;  /* log2 of the table's slots / of a bucket's (rec_w) */
 };
 
 /* Sub-regions (the level the text — or the slabs — are split into, when another split reads it).
@@ -272,20 +282,41 @@ __device__ __forceinline__ uint64_t copy_fetch(const SplitLds &L)
     return L.sorted[threadIdx.x + PIECE * kSplitThreads];
 }
 
-template <int PIECE, bool SEG>
-__device__ __forceinline__ void copy_store(const SplitLds &L, uint64_t km, const SplitDst &d, uint64_t child0, uint32_t shift,
-                                           uint32_t bits)
+/* The child's {offset, limit} is asked for early (copy_lookup) and used late (copy_finish), with the k-mer's own work of
+ * the chunk loop in between — as one piece, the LDS read and the wait for it sit back to back, one exposed round trip
+ * per k-mer of every lane.  h: the k-mer's hash, which the finest level writes into its records. */
+__device__ __forceinline__ uint64_t copy_lookup(const SplitLds &L, uint64_t km, uint32_t shift, uint32_t bits, uint32_t &child, uint32_t &h)
+{
+    h = djb32(km);
+    child = __builtin_amdgcn_ubfe(h, shift, bits);
+    return *reinterpret_cast<const uint64_t *>(&L.dl[child]);      /* one 8-byte read: x = low, y = high */
+}
+
+/* FIN = 0: the level holds k-mers (8 bytes).  FIN = 2 / 4: it is the finest level and holds bucket records, R in a
+ * 4-byte array and the second word in a 2- / 4-byte array beside it (6 instead of 8 bytes per k-mer written here and read
+ * by bucket_count, which then needs no hash either). */
+template <int PIECE, bool SEG, int FIN>
+__device__ __forceinline__ void copy_finish(uint64_t km, uint32_t child, uint32_t h, uint64_t dlw, const SplitDst &d, uint64_t child0)
 {
     const uint32_t i = threadIdx.x + PIECE * kSplitThreads;
     /* no bounds test on i: beyond the chunk's last k-mer L.sorted holds stale k-mers, and whatever child such
      * a one hashes to, that child's limit (offset + fit <= the chunk's total <= i) keeps it from being stored */
-    const uint32_t child = child_of(km, shift, bits);
-    const uint64_t dlw = *reinterpret_cast<const uint64_t *>(&L.dl[child]);      /* one 8-byte read: x = low, y = high */
     const uint32_t dx = (uint32_t)dlw, dy = (uint32_t)(dlw >> 32);
-    /* (an address-space-1 pointer: a generic one would make this a flat_store, which also counts on
+    /* (address-space-1 pointers: a generic one would make this a flat_store, which also counts on
      * lgkmcnt — and every LDS wait and lds_barrier() of these kernels would wait for the stores) */
     typedef uint64_t __attribute__((address_space(1))) global_u64;
-    if constexpr (SEG) {
+    typedef uint32_t __attribute__((address_space(1))) global_u32;
+    typedef uint16_t __attribute__((address_space(1))) global_u16;
+    if constexpr (FIN != 0) {
+        static_assert(!SEG, "the finest level is region-major");
+        const uint64_t at = (child0 + child) * (uint64_t)d.cap + (i + dx);
+        if (i < dy) {
+            ((global_u32 *)(uintptr_t)d.kmers)[at] = rec_r(km);
+            const uint32_t w = rec_w(km, h, d.lgH, d.lg_s);
+            if constexpr (FIN == 2) ((global_u16 *)(uintptr_t)d.fin_w)[at] = (uint16_t)w;
+            else                    ((global_u32 *)(uintptr_t)d.fin_w)[at] = w;
+        }
+    } else if constexpr (SEG) {
         global_u64 *dst = (global_u64 *)(uintptr_t)d.kmers;
         if (i < dy) dst[slot_of<true>(child0 + child, i + dx, d.cap, d.lg_row)] = km;
     } else {
@@ -294,40 +325,19 @@ __device__ __forceinline__ void copy_store(const SplitLds &L, uint64_t km, const
     }
 }
 
-/* copy_store in two halves as well: the child's {offset, limit} is asked for early (copy_lookup) and used late
- * (copy_finish), with the k-mer's own work of the chunk loop in between — as one piece, the LDS read and the wait for
- * it sit back to back, one exposed round trip per k-mer of every lane */
-__device__ __forceinline__ uint64_t copy_lookup(const SplitLds &L, uint64_t km, uint32_t shift, uint32_t bits, uint32_t &child)
-{
-    child = child_of(km, shift, bits);
-    return *reinterpret_cast<const uint64_t *>(&L.dl[child]);
-}
-
-template <int PIECE, bool SEG>
-__device__ __forceinline__ void copy_finish(uint64_t km, uint32_t child, uint64_t dlw, const SplitDst &d, uint64_t child0)
-{
-    const uint32_t i = threadIdx.x + PIECE * kSplitThreads;
-    const uint32_t dx = (uint32_t)dlw, dy = (uint32_t)(dlw >> 32);
-    typedef uint64_t __attribute__((address_space(1))) global_u64;
-    if constexpr (SEG) {
-        global_u64 *dst = (global_u64 *)(uintptr_t)d.kmers;
-        if (i < dy) dst[slot_of<true>(child0 + child, i + dx, d.cap, d.lg_row)] = km;
-    } else {
-        global_u64 *dst = (global_u64 *)(uintptr_t)(d.kmers + (child0 + child) * (uint64_t)d.cap);
-        if (i < dy) dst[i + dx] = km;
-    }
-}
-
-template <int PIECE, bool SEG>
+template <int PIECE, bool SEG, int FIN>
 __device__ __forceinline__ void copy_piece(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
 {
-    copy_store<PIECE, SEG>(L, copy_fetch<PIECE>(L), d, child0, shift, bits);
+    const uint64_t km = copy_fetch<PIECE>(L);
+    uint32_t child, h;
+    const uint64_t dlw = copy_lookup(L, km, shift, bits, child, h);
+    copy_finish<PIECE, SEG, FIN>(km, child, h, dlw, d, child0);
 }
 
-template <bool SEG>
+template <bool SEG, int FIN>
 __device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, uint64_t child0, uint32_t shift, uint32_t bits)
 {
-#define QM2_CP(J) copy_piece<J, SEG>(L, d, child0, shift, bits);
+#define QM2_CP(J) copy_piece<J, SEG, FIN>(L, d, child0, shift, bits);
     QM2_CP(0) QM2_CP(1) QM2_CP(2) QM2_CP(3) QM2_CP(4) QM2_CP(5) QM2_CP(6) QM2_CP(7)
     QM2_CP(8) QM2_CP(9) QM2_CP(10) QM2_CP(11) QM2_CP(12) QM2_CP(13) QM2_CP(14) QM2_CP(15)
 #undef QM2_CP
@@ -341,7 +351,7 @@ __device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, u
 /* FX: 0, or (shift << 8 | bits) as compile-time constants — the split of an hg38-scale table (H = 2^32: 10 + 10 bucket
  * bits above 12 slot bits).  v_bfe_u32 takes one scalar operand; with both in SGPRs hipcc moves one into a VGPR in
  * front of EVERY hash (it has no register to keep it in): two instructions per k-mer. */
-template <bool K30, bool SEG, uint32_t FX = 0>
+template <bool K30, bool SEG, uint32_t FX = 0, int FIN = 0>
 __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_kernel(SeqView sv, uint32_t k, uint32_t shift, uint32_t bits,
                                                                    uint64_t n_chunks, SplitDst d, DevStats *stats,
                                                                    unsigned long long *call)
@@ -379,13 +389,13 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
         {                                                                          \
             /* piece J + 1 is fetched a step ahead; piece J's child is looked up before the k-mer's own work and used behind it */ \
             const uint64_t out_next = pend ? copy_fetch<(J + 1 < kKpt ? J + 1 : J)>(L) : 0; \
-            uint32_t oc = 0;                                                       \
-            const uint64_t dlw = pend ? copy_lookup(L, out, shift, bits, oc) : 0;  \
+            uint32_t oc = 0, oh = 0;                                               \
+            const uint64_t dlw = pend ? copy_lookup(L, out, shift, bits, oc, oh) : 0; \
             km[J] = kmer_at<K30, J>(W, k);                                         \
             /* (a select without the branch around the hash was measured: no difference) */ \
             const uint32_t b = (W.emit & (0x8000u >> J)) ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | atomicAdd(&L.hist[b], 1u);      /* (a count: < 2^15) */ \
-            if (pend) copy_finish<J, SEG>(out, oc, dlw, d, child0);                \
+            if (pend) copy_finish<J, SEG, FIN>(out, oc, oh, dlw, d, child0);       \
             out = out_next;                                                        \
         }
         QM2_T(0) QM2_T(1) QM2_T(2) QM2_T(3) QM2_T(4) QM2_T(5) QM2_T(6) QM2_T(7)
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
         QM2_STAMP(19);
         pend = true;
     }
-    if (pend) copy_all<SEG>(L, d, child0, shift, bits);
+    if (pend) copy_all<SEG, FIN>(L, d, child0, shift, bits);
 #ifdef QM2_STAMPS
     if (lane == 0) {
         for (int i = 16; i < 20; i++) atomicAdd(&qm2_stamp_acc[i], st_acc[i]);
@@ -421,7 +431,7 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
  * takes its chunks x, x + wgs_per_parent, ...
  * FLAT (level 1 of a shard, qm2_probe_slabs_device): the parents are the slabs a shard received from its
  * peers — src_cap apart, src_cursors[slab] k-mers in each — and they all feed the same children 0 .. fan-1. */
-template <bool FLAT, bool SRC_SEG, bool DST_SEG, uint32_t FX = 0>
+template <bool FLAT, bool SRC_SEG, bool DST_SEG, uint32_t FX = 0, int FIN = 0>
 __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_kernel(const uint64_t *src, const uint32_t *src_cursors,
                                                                    uint64_t src_cap, uint32_t src_lg_row, uint32_t parent_mask, uint32_t shift, uint32_t bits,
                                                                    uint32_t wgs_per_parent, uint32_t n_parents,
@@ -484,11 +494,11 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
 #define QM2_K(J)                                                                   \
         {                                                                          \
             const uint64_t out_next = pend ? copy_fetch<(J + 1 < kKpt ? J + 1 : J)>(L) : 0; \
-            uint32_t oc = 0;                                                       \
-            const uint64_t dlw = pend ? copy_lookup(L, out, shift, bits, oc) : 0;  \
+            uint32_t oc = 0, oh = 0;                                               \
+            const uint64_t dlw = pend ? copy_lookup(L, out, shift, bits, oc, oh) : 0; \
             const uint32_t b = km[J] != kPad ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
             tag[J] = (b << 16) | atomicAdd(&L.hist[b], 1u);      /* (a count: < 2^15) */ \
-            if (pend) copy_finish<J, DST_SEG>(out, oc, dlw, d, child0);            \
+            if (pend) copy_finish<J, DST_SEG, FIN>(out, oc, oh, dlw, d, child0);   \
             out = out_next;                                                        \
         }
         QM2_K(0) QM2_K(1) QM2_K(2) QM2_K(3) QM2_K(4) QM2_K(5) QM2_K(6) QM2_K(7)
@@ -497,25 +507,31 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
         sort_chunk(L, km, tag, child0, fan, d, lost);
         pend = true;
     }
-    if (pend) copy_all<DST_SEG>(L, d, child0, shift, bits);
+    if (pend) copy_all<DST_SEG, FIN>(L, d, child0, shift, bits);
     lost = wave_sum(lost);
     if (lane == 0 && lost) atomicAdd(&stats->part_lost, lost);
 }
 
 /* Finest level: one bucket of S = 2^LG_S table slots at a time per workgroup, one workgroup per CU.
  *
+ * Everything here is in RECORD form (qm2_device.hip.h, "bucket records"): the bucket's k-mers arrive as
+ * (R, w) — 32 bits of the k-mer the hash does not determine, and the hash bits the bucket does not say, whose low
+ * LG_S bits are the home slot inside the bucket: this kernel never hashes — and the table slice comes from the
+ * context's TABLE IMAGE (table_image_kernel), the same two words per slot, 6 instead of 8 bytes.  Two keys of one
+ * bucket are equal iff their records are (one to one, given the bucket's hash bits).
+ *
  * The slice of a bucket (its S slots + kHalo slots on the side probe walks leave through, i.e.
  * towards the middle of the table, :94-95) is staged in LDS MIRRORED for the upper half of the
- * table, so that in LDS every walk is p, p+1, p+2, ... whatever its direction in the table.  Next to
- * the keys and the counter tile sits one FINGERPRINT byte per slot: 0 = empty, 1..253 = a function
- * of the key, 0xFF = beyond the staged slice.
+ * table, so that in LDS every walk is p, p+1, p+2, ... whatever its direction in the table, and a k-mer's
+ * home position is w & (S - 1), XOR (S - 1) in the upper half.  Next to the records and the counter tile sits
+ * one FINGERPRINT byte per slot: 0 = empty, odd 1..255 = a function of R, 0xFE = beyond the staged slice.
  *
  * Roles (measured with in-kernel stamps on the one-role kernels of round 1 / early round 2: 18-25 %
  * of a wave's time went into ISSUING the slice loads — the per-CU fetch path takes ~10 B/clk, the
  * issuing wave stalls — and the prefetch registers left the probe code no room to overlap its LDS
  * round trips):
  *   waves 0..3   LOADERS: stream the table slice of the bucket after next into registers, stage the
- *                next bucket's slice (keys, fingerprints, old counter values) into the OTHER LDS
+ *                next bucket's slice (records, fingerprints, old counter values) into the OTHER LDS
  *                buffer, and flush the counter tile of the previous bucket;
  *   waves 4..15  PROBERS: probe the current bucket's k-mers against the current buffer.
  * One workgroup barrier per bucket: behind barrier k the probers are done with bucket k-1 and the
@@ -526,11 +542,11 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
  * on average, the slowest of a wave's 64 lanes ~12).  So:
  *   A  straight-line, kSet k-mers at a time: the fingerprints of the 4 slots from the home slot on
  *      (two aligned dwords + v_alignbyte) are compared SWAR-wise with the k-mer's own fingerprint;
- *      the first match at or before the first empty slot is verified against the full key (exact:
- *      equal keys have equal fingerprints; k-mer 0 has fingerprint 0 and so "matches" the first
- *      empty slot exactly like :96-98).  ~90 % of the k-mers end here at 53 % fill.
+ *      the first match at or before the first empty slot is verified against the full record (exact:
+ *      equal keys have equal fingerprints).  ~90 % of the k-mers end here at 53 % fill.  k-mer 0 (the
+ *      reference counts it ON the first empty slot, :96-98) is left to B.
  *   B  the rest (no match and no empty slot among the 4, or a false fingerprint match) are
- *      compacted into a per-wave LDS queue and finished once per bucket in dense rows, again four
+ *      compacted into a per-wave LDS queue and finished once per bucket in dense rows, eight
  *      fingerprints per step.
  *
  * Counter tile: starts from the old values of the bucket's private interior (0 elsewhere), so the
@@ -538,47 +554,65 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
  * at either end of the owned range and the staged halo can also receive a neighbour's counts, so
  * there the tile holds deltas that are added atomically.
  *
- * G2 = 16-byte k-mer loads per prober thread per group (2 k-mers each), chosen per launch. */
+ * G2 = rows of 2 k-mers per prober thread per group, chosen per launch; two rows share a 16-byte load of R. */
 struct CountGeo {
     uint64_t range_lo;      /* first slot of bucket 0 (0, or a shard's own_lo)                   */
     uint64_t lim_lo, lim_hi;/* the slots that are resident: [0, H) or the shard's span          */
     uint64_t half;          /* H >> 1: buckets at or above walk down                            */
 };
 
-/* fingerprint of a stored key: odd, 1..255; of an empty slot: 0; beyond the staged slice: 0xFE.
- * A fold of the whole k-mer.  (-DQM2_FP_BYTE=1: just byte 1 of it, two instructions instead of five for the four
- * copies a window compares against — measured at C3: 25.5 instead of 22.8 ms, the k-mers of a genome are not
- * uniform in any one byte and every false match is a queue entry.) */
-#ifndef QM2_FP_BYTE
-#define QM2_FP_BYTE 0
-#endif
-__device__ __forceinline__ uint32_t fp8(uint64_t key)
-{
-#if QM2_FP_BYTE
-    return (((uint32_t)key >> 8) & 0xFFu) | 1u;
-#else
-    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-    return ((lo ^ hi ^ (lo >> 13)) & 0xFFu) | 1u;
-#endif
-}
+/* The second word of a record carries two CODE bits above the slot bits.
+ *   k-mers:       0.
+ *   table image:  where the key's home bucket lies from the slot's own: 0 the same, 1 the one before (lower slots),
+ *                 2 the one behind, 3 = no key that any k-mer of this or a neighbouring bucket could equal: with slot
+ *                 bits 0 an EMPTY slot, with slot bits 1 a key from further away (a run of > S occupied slots).
+ *   staged (LDS): 0 = may equal a k-mer of the bucket being counted (home bucket = that bucket: code 0 in its own slots,
+ *                 1 / 2 in the halo of a bucket that walks up / down), 1 = occupied by a key of another bucket,
+ *                 3 = empty.  So one 64-bit compare of a staged record with a k-mer's is the reference's T[i] == key. */
+constexpr uint32_t kCodeEmpty = 3u, kCodeOther = 1u;
+
+/* fingerprint of a record: odd, 1..255, a function of R alone (the slot bits are what neighbours in a probe window have
+ * in common, not what tells them apart); of an empty slot: 0; beyond the staged slice: 0xFE.  One v_dot4_u32_u8 folds
+ * R's four bytes with odd weights.  (A single byte of the k-mer as fingerprint was measured in round 2: 25.5 instead of
+ * 22.8 ms — the k-mers of a genome are not uniform in any one byte and every false match is a queue entry.) */
+__device__ __forceinline__ uint32_t fp_word(uint32_t r) { return __builtin_amdgcn_udot4(r, 0x9D7B3D25u, 0u, false); }
+__device__ __forceinline__ uint32_t fp8(uint32_t r) { return (fp_word(r) & 0xFFu) | 1u; }
 /* the same in all four bytes of a word */
-__device__ __forceinline__ uint32_t fp8x4(uint64_t key)
-{
-#if QM2_FP_BYTE
-    return __builtin_amdgcn_perm(0u, (uint32_t)key, 0x01010101u) | 0x01010101u;
-#else
-    return __builtin_amdgcn_perm(0u, fp8(key), 0u);
-#endif
-}
+__device__ __forceinline__ uint32_t fp8x4(uint32_t r) { return __builtin_amdgcn_perm(0u, fp_word(r), 0u) | 0x01010101u; }
 constexpr uint32_t kFpPad = 0xFEu;
+
+/* The table image: (R, w) of every resident slot — what bucket_count's loader waves stage, 6 bytes a slot (8 when the
+ * second word needs 32 bits) instead of the 8-byte key, with the hashing done once per context instead of once per batch. */
+template <typename WT>
+__global__ void table_image_kernel(const uint64_t *keys, uint64_t n_slots, uint64_t span_lo, uint32_t hmask, uint32_t lg_s,
+                                   uint32_t *img_r, WT *img_w)
+{
+    const uint32_t lgH = (uint32_t)__builtin_popcount(hmask);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i];
+        uint32_t r = 0, w = kCodeEmpty << lg_s;
+        if (key) {
+            const uint32_t h = djb32(key);
+            const uint64_t bh = (h & hmask) >> lg_s, bp = (span_lo + i) >> lg_s;
+            r = rec_r(key);
+            w = rec_w(key, h, lgH, lg_s);
+            if (bh + 1 == bp) w |= 1u << lg_s;
+            else if (bh == bp + 1) w |= 2u << lg_s;
+            else if (bh != bp) w = (kCodeEmpty << lg_s) | 1u;
+        }
+        img_r[i] = r;
+        img_w[i] = (WT)w;
+    }
+}
 
 /* LW loader waves (3 or 4; the rest of the 16 probe): chosen per launch so that a bucket's fill takes the fewest
  * rows of 2 k-mers per prober thread — measured at C3: 50 M reads per launch 24.5 (3) vs 23.5 ms (4), 40 M reads
- * 22.0 vs 24.4; 2 loader waves: 51 ms (their prefetch registers spill). */
-template <int LG_S, int G2, int LW>
+ * 22.0 vs 24.4; 2 loader waves: 51 ms (their prefetch registers spill).
+ * WT: uint16_t / uint32_t, the width of the records' second word (k-mers and table image alike). */
+template <int LG_S, int G2, int LW, typename WT>
 __global__ __launch_bounds__(kCountThreads)
-void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_t cap, TableView tv, CountGeo cg,
-                         uint32_t n_buckets, const uint32_t *shared, DevStats *stats)
+void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_t *cursors, uint32_t cap, TableView tv, CountGeo cg,
+                         uint32_t n_buckets_all, const uint32_t *shared, DevStats *stats)
 {
     if (stats->part_lost != 0) return;       /* this batch is recounted by the direct kernel */
     constexpr int kLoaderWaves = LW, kLoaderThreads = LW * kWave;
@@ -586,14 +620,25 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
     constexpr int S = 1 << LG_S;
     constexpr int kSeg = S + kHalo;
     constexpr int kQueueCap = 128;                    /* per wave and bucket; what does not fit is finished in place */
-    __shared__ uint64_t skey[2][kSeg];
+    constexpr bool W16 = sizeof(WT) == 2;
+    constexpr uint32_t kCodeMask = 3u << LG_S;
+    __shared__ uint64_t skey[2][kSeg];                /* staged records: R low, second word high */
     __shared__ uint32_t scnt[2][kSeg];
     __shared__ uint32_t sfp[2][kSeg / 4 + 4];         /* one byte per slot + 16 bytes of kFpPad */
     __shared__ uint64_t qk[kProberWaves][kQueueCap];
     __shared__ uint16_t qa[kProberWaves][kQueueCap];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t stride = gridDim.x;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    /* Which buckets a workgroup takes.  Round-robin (b, b + grid, ...) every bucket of a workgroup lies ~10 MB from its
+     * last one in each of the six arrays it streams; QM2_COUNT_BLOCKED gives it a run of consecutive buckets instead. */
+#if QM2_COUNT_BLOCKED
+    const uint32_t per_wg = (n_buckets_all + gridDim.x - 1) / gridDim.x;
+    const uint32_t stride = 1u, b_first = blockIdx.x * per_wg;
+    const uint32_t n_buckets = b_first + per_wg < n_buckets_all ? b_first + per_wg : n_buckets_all;   /* this workgroup's end */
+#else
+    const uint32_t stride = gridDim.x, b_first = blockIdx.x, n_buckets = n_buckets_all;
+#endif
 
     /* geometry of bucket b: staged slice, walk direction, private interior.  Everything is a
      * multiple of 4 slots (buckets, halo and spans are), so 16-byte accesses never straddle an edge.
@@ -622,57 +667,68 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
     if (wave < kLoaderWaves) {
         /* ============================ LOADERS ============================ */
         __builtin_amdgcn_s_setprio(2);
-        constexpr int kKeySteps = (kSeg / 2 + 8 + kLoaderThreads - 1) / kLoaderThreads;   /* 2 keys per lane and step (+ the 0xFF pad) */
-        constexpr int kCntSteps = (kSeg / 4 + kLoaderThreads - 1) / kLoaderThreads;       /* 4 counters per lane and step */
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        u32x4 kv[kKeySteps];
-        u32x2 ov[kCntSteps];                     /* four 16-bit interior counters a step (tv.interior16) */
+        /* four slots per lane and step of everything: 16 bytes of R, 8 (16) of second words, 8 of 2-byte counters */
+        constexpr int kSteps = (kSeg / 4 + 4 + kLoaderThreads - 1) / kLoaderThreads;      /* (+ the 16 pad fingerprints) */
+        typedef typename std::conditional<W16, u32x2, u32x4>::type wvec;
+        u32x4 rv[kSteps];
+        wvec  wv[kSteps];
+        u32x2 ov[kSteps];                        /* four 16-bit interior counters a step (tv.interior16) */
         auto fetch = [&](uint32_t b) {
             if (b >= n_buckets) return;
             const Geo g = geo(b);
-            const u32x4 *kp = reinterpret_cast<const u32x4 *>(tv.keys + (g.seg_lo - tv.span_lo));
-#pragma unroll
-            for (int st = 0; st < kKeySteps; st++) {
-                const uint32_t i2 = tid + st * kLoaderThreads;
-                kv[st] = 2 * i2 < g.seg ? kp[i2] : u32x4{0, 0, 0, 0};
-            }
-            /* (g.seg_lo is a multiple of 4 slots: 8-byte aligned in the 2-byte array) */
+            /* (g.seg_lo is a multiple of 4 slots: 16 / 8 / 8-byte aligned in the three arrays) */
+            const u32x4 *rp = reinterpret_cast<const u32x4 *>(tv.img_r + (g.seg_lo - tv.span_lo));
+            const wvec *wp = reinterpret_cast<const wvec *>(reinterpret_cast<const WT *>(tv.img_w) + (g.seg_lo - tv.span_lo));
             const u32x2 *cp2 = reinterpret_cast<const u32x2 *>(tv.interior16 + (g.seg_lo - tv.span_lo));
 #pragma unroll
-            for (int st = 0; st < kCntSteps; st++) {
+            for (int st = 0; st < kSteps; st++) {
                 const uint32_t i4 = tid + st * kLoaderThreads;
+                const bool in = 4 * i4 < g.seg;
+                rv[st] = in ? rp[i4] : u32x4{0, 0, 0, 0};
+                if constexpr (W16) wv[st] = in ? wp[i4] : wvec{0, 0};
+                else               wv[st] = in ? wp[i4] : wvec{0, 0, 0, 0};
                 ov[st] = 4 * i4 - g.int_lo < g.int_len ? cp2[i4] : u32x2{0, 0};
             }
         };
-        /* registers -> LDS buffer `bf`: keys, fingerprints, counter tile; mirrored when the bucket walks down */
+        /* registers -> LDS buffer `bf`: records, fingerprints, counter tile; mirrored when the bucket walks down */
         auto stage = [&](uint32_t b, int bf) {
             const Geo g = geo(b);
-            uint8_t *const fpb = reinterpret_cast<uint8_t *>(sfp[bf]);
+            /* the code a key that a k-mer of THIS bucket can equal carries in the image: 0 in the bucket's own slots,
+             * in its halo (the next bucket's slots, walking up; the previous one's, walking down) 1 resp. 2 */
+            const uint32_t halo_code = (g.down ? 2u : 1u) << LG_S;
+            const uint32_t own_from = g.down ? g.seg - (uint32_t)S : 0u;          /* own slots: [own_from, own_from + S) */
 #pragma unroll
-            for (int st = 0; st < kKeySteps; st++) {
-                const uint32_t i = 2u * (tid + st * kLoaderThreads);
-                if (i < g.seg) {
-                    const uint64_t k0 = ((uint64_t)kv[st].y << 32) | kv[st].x, k1 = ((uint64_t)kv[st].w << 32) | kv[st].z;
-                    const uint32_t f0 = k0 ? fp8(k0) : 0u, f1 = k1 ? fp8(k1) : 0u;
-                    if (g.down) {
-                        const uint32_t m = g.seg - 2u - i;                 /* slots i+1, i land at m, m+1 */
-                        *reinterpret_cast<u32x4 *>(&skey[bf][m]) = u32x4{kv[st].z, kv[st].w, kv[st].x, kv[st].y};
-                        *reinterpret_cast<uint16_t *>(fpb + m) = (uint16_t)(f1 | (f0 << 8));
-                    } else {
-                        *reinterpret_cast<u32x4 *>(&skey[bf][i]) = kv[st];
-                        *reinterpret_cast<uint16_t *>(fpb + i) = (uint16_t)(f0 | (f1 << 8));
-                    }
-                } else if (i < (uint32_t)kSeg + 16u) {
-                    *reinterpret_cast<uint16_t *>(fpb + i) = (uint16_t)(kFpPad | (kFpPad << 8));   /* beyond the slice (positions, not mirrored) */
-                }
-            }
-#pragma unroll
-            for (int st = 0; st < kCntSteps; st++) {
+            for (int st = 0; st < kSteps; st++) {
                 const uint32_t i = 4u * (tid + st * kLoaderThreads);
                 if (i < g.seg) {
+                    const uint32_t want = i - own_from < (uint32_t)S ? 0u : halo_code;
+                    uint32_t w[4];
+                    if constexpr (W16) { w[0] = wv[st].x & 0xFFFFu; w[1] = wv[st].x >> 16; w[2] = wv[st].y & 0xFFFFu; w[3] = wv[st].y >> 16; }
+                    else               { w[0] = wv[st].x; w[1] = wv[st].y; w[2] = wv[st].z; w[3] = wv[st].w; }
+                    const uint32_t r[4] = {rv[st].x, rv[st].y, rv[st].z, rv[st].w};
+                    uint32_t f[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t code = w[j] & kCodeMask;
+                        const bool empty = code == kCodeMask && (w[j] & (uint32_t)(S - 1)) == 0u;
+                        f[j] = empty ? 0u : fp8(r[j]);
+                        w[j] = empty ? kCodeMask : (w[j] & ~kCodeMask) | (code == want ? 0u : kCodeOther << LG_S);
+                    }
+                    if (g.down) {
+                        const uint32_t m = g.seg - 4u - i;                 /* slots i+3 .. i land at m .. m+3 */
+                        *reinterpret_cast<u32x4 *>(&skey[bf][m]) = u32x4{r[3], w[3], r[2], w[2]};
+                        *reinterpret_cast<u32x4 *>(&skey[bf][m + 2]) = u32x4{r[1], w[1], r[0], w[0]};
+                        sfp[bf][m >> 2] = f[3] | (f[2] << 8) | (f[1] << 16) | (f[0] << 24);
+                    } else {
+                        *reinterpret_cast<u32x4 *>(&skey[bf][i]) = u32x4{r[0], w[0], r[1], w[1]};
+                        *reinterpret_cast<u32x4 *>(&skey[bf][i + 2]) = u32x4{r[2], w[2], r[3], w[3]};
+                        sfp[bf][i >> 2] = f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24);
+                    }
                     const u32x4 o = u32x4{ov[st].x & 0xFFFFu, ov[st].x >> 16, ov[st].y & 0xFFFFu, ov[st].y >> 16};
                     if (g.down) *reinterpret_cast<u32x4 *>(&scnt[bf][g.seg - 4u - i]) = u32x4{o.w, o.z, o.y, o.x};
                     else        *reinterpret_cast<u32x4 *>(&scnt[bf][i]) = o;
+                } else if (i < (uint32_t)kSeg + 16u) {
+                    sfp[bf][i >> 2] = kFpPad * 0x01010101u;                /* beyond the slice (positions, not mirrored) */
                 }
             }
         };
@@ -683,7 +739,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
             uint32_t *const cp = tv.counters + (g.seg_lo - tv.span_lo);
             uint16_t *const cp16 = tv.interior16 + (g.seg_lo - tv.span_lo);
 #pragma unroll
-            for (int st = 0; st < kCntSteps; st++) {
+            for (int st = 0; st < kSteps; st++) {
                 const uint32_t i = 4u * (tid + st * kLoaderThreads);
                 if (i < g.seg) {
                     u32x4 cv;
@@ -712,7 +768,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                 }
             }
         };
-        uint32_t b = blockIdx.x;
+        uint32_t b = b_first;
         if (b < n_buckets) { fetch(b); stage(b, 0); }
         fetch(b + stride);
         lds_barrier();                                            /* barrier 0: bucket 0 is staged */
@@ -753,28 +809,48 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
     uint32_t w_hits_a = 0;
     constexpr uint32_t kGroupKmers = 2u * G2 * kProberThreads;
     constexpr int kSet = QM2_COUNT_SET;               /* k-mers probed together in phase A (even) */
-    /* 16 bytes = k-mers e, e+1 of the bucket at `src` (cap is a multiple of 64: 16-byte aligned).
-     * UNCONDITIONAL loads: lanes beyond the fill re-read the bucket's first 16 bytes (a hot line; what
+    /* A group's records: rows 2q, 2q + 1 of a thread are the four k-mers e .. e + 3 of one 16-byte load of R (and one
+     * 8- / 16-byte load of second words), e = 4 (q T + pt); an odd last row is two k-mers of an 8-byte load behind them
+     * (regions start 128-byte aligned: capacities are multiples of 64).
+     * UNCONDITIONAL loads: lanes beyond the fill re-read the bucket's first bytes (a hot line; what
      * they get is ignored, `live` is decided from e < n at use).  Conditional loads make hipcc wait
      * with vmcnt(0) at the first use of a k-mer — i.e. for the NEXT group's prefetch as well. */
-    u32x4 nq[G2];
-    auto load_group = [&](const uint64_t *src, uint32_t first, uint32_t n_src) {
+    constexpr int kQuads = G2 / 2, kOdd = G2 & 1;
+    typedef typename std::conditional<W16, u32x2, u32x4>::type w4vec;
+    typedef typename std::conditional<W16, uint32_t, u32x2>::type w2vec;
+    struct Group { u32x4 r4[kQuads ? kQuads : 1]; w4vec w4[kQuads ? kQuads : 1]; u32x2 r2; w2vec w2; };
+    Group nq;
+    auto load_group = [&](const uint32_t *src_r, const WT *src_w, uint32_t first, uint32_t n_src) {
 #pragma unroll
-        for (int q = 0; q < G2; q++) {
-            const uint32_t e = first + 2u * (q * kProberThreads + pt);
-            nq[q] = *reinterpret_cast<const u32x4 *>(src + (e < n_src ? e : 0u));
+        for (int q = 0; q < kQuads; q++) {
+            const uint32_t e = first + 4u * (q * kProberThreads + pt);
+            const uint32_t at = e < n_src ? e : 0u;
+            nq.r4[q] = *reinterpret_cast<const u32x4 *>(src_r + at);
+            nq.w4[q] = *reinterpret_cast<const w4vec *>(src_w + at);
+        }
+        if constexpr (kOdd != 0) {
+            const uint32_t e = first + 4u * kQuads * kProberThreads + 2u * pt;
+            const uint32_t at = e < n_src ? e : 0u;
+            nq.r2 = *reinterpret_cast<const u32x2 *>(src_r + at);
+            nq.w2 = *reinterpret_cast<const w2vec *>(src_w + at);
         }
     };
-    uint32_t n_next = fill_of(blockIdx.x);                    /* fill of the bucket about to start */
-    if (blockIdx.x < n_buckets) load_group(kmers + (uint64_t)blockIdx.x * cap, 0, n_next);
-    uint32_t n_after = fill_of(blockIdx.x + stride);          /* ... and of the one after it */
+    /* k-mer 0 (poly-A): the reference counts it ON the first empty slot behind its home slot (:96-98).  Its record in the
+     * one bucket that can hold it; a value no record equals (code bits set) everywhere else */
+    const uint32_t lgH = (uint32_t)__builtin_popcount(tv.hmask);
+    const uint32_t h_zero = 0x7BB34A05u;                                          /* djb32(0) */
+    const uint64_t home_zero = h_zero & tv.hmask;
+    const uint64_t rec_zero = (uint64_t)rec_w(0, h_zero, lgH, LG_S) << 32;        /* rec_r(0) = 0 */
+    uint32_t n_next = fill_of(b_first);                       /* fill of the bucket about to start */
+    if (b_first < n_buckets) load_group(recs_r + (uint64_t)b_first * cap, recs_w + (uint64_t)b_first * cap, 0, n_next);
+    uint32_t n_after = fill_of(b_first + stride);             /* ... and of the one after it */
     lds_barrier();                                            /* barrier 0 */
 #ifdef QM2_STAMPS
     unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now();
 #endif
 
     uint32_t k = 0;
-    for (uint32_t b = blockIdx.x; b < n_buckets; b += stride, k++) {
+    for (uint32_t b = b_first; b < n_buckets; b += stride, k++) {
         const uint32_t n = n_next;
         const Geo g = geo(b);
         const uint64_t seg_lo = g.seg_lo;
@@ -784,9 +860,11 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         const uint64_t *const bkey = skey[bf];
         uint32_t *const bcnt = scnt[bf];
         const uint32_t *const bfp = sfp[bf];
-        /* LDS position of home slot h: (h ^ xm) + ad  (up: h - seg_lo; down: seg_lo + seg - 1 - h) */
-        const uint32_t xm = down ? ~0u : 0u;
-        const uint32_t ad = down ? (uint32_t)(seg_lo + seg) : (uint32_t)(0u - (uint32_t)seg_lo);
+        /* LDS position of the home slot with bucket offset o: o going up (the slice starts at the bucket's first slot),
+         * S - 1 - o going down (it ends behind its last) */
+        const uint32_t xs = down ? (uint32_t)(S - 1) : 0u;
+        const uint64_t own_lo = cg.range_lo + ((uint64_t)b << LG_S);
+        const uint64_t zrec = home_zero >> LG_S == own_lo >> LG_S ? rec_zero : ~0ull;
         const uint32_t bn = b + stride;
         n_next = n_after;
         n_after = fill_of(bn + stride);
@@ -796,15 +874,15 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         /* Decision on the 4 slots from position p on, from their fingerprint word w (slot p in the low
          * byte).  lm / le: bit index of the first fingerprint match / first empty slot, 0xFFFFFFFF if
          * none (the LOWEST flagged byte of the borrow trick is exact).
-         *   lm <= le: a candidate at slot c = lm >> 3 — to be verified against the key; this also covers
-         *             "neither" (lm = le = none): c reads as 3, the key there cannot be equal (its
+         *   lm <= le: a candidate at slot c = lm >> 3 — to be verified against the record; this also covers
+         *             "neither" (lm = le = none): c reads as 3, the record there cannot be equal (its
          *             fingerprint is not), and the walk goes on behind slot 3, as it should;
          *   lm >  le: an empty slot comes first: not in the dictionary (:96-98) — except for k-mer 0,
          *             which the reference counts ON that empty slot; k-mer 0 is left to walk().
          * Slots the reference has inspected by then: min(c, e, 3) + 1. */
 #define QM2_WINDOW(W, KM, LM, LE)                                                            \
         {                                                                                    \
-            const uint32_t x_ = (W) ^ fp8x4(KM);                                             \
+            const uint32_t x_ = (W) ^ fp8x4((uint32_t)(KM));                                 \
             const uint32_t zm_ = (x_ - 0x01010101u) & ~x_ & 0x80808080u;                     \
             const uint32_t ze_ = ((W) - 0x01010101u) & ~(W) & 0x80808080u;                   \
             LM = (uint32_t)__ffs((int)zm_) - 1u;                                             \
@@ -813,48 +891,50 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         /* the same over EIGHT slots (two fingerprint words): bit indices 0..63 */
 #define QM2_WINDOW8(W0, W1, KM, LM, LE)                                                      \
         {                                                                                    \
-            const uint32_t f_ = fp8x4(KM);                                                   \
+            const uint32_t f_ = fp8x4((uint32_t)(KM));                                       \
             const uint32_t x0_ = (W0) ^ f_, x1_ = (W1) ^ f_;                                 \
             const uint64_t zm_ = ((uint64_t)((x1_ - 0x01010101u) & ~x1_ & 0x80808080u) << 32) | ((x0_ - 0x01010101u) & ~x0_ & 0x80808080u); \
             const uint64_t ze_ = ((uint64_t)(((W1) - 0x01010101u) & ~(W1) & 0x80808080u) << 32) | (((W0) - 0x01010101u) & ~(W0) & 0x80808080u); \
             LM = (uint32_t)__ffsll((long long)zm_) - 1u;                                     \
             LE = (uint32_t)__ffsll((long long)ze_) - 1u;                                     \
         }
-#ifndef QM2_WALK8
-#define QM2_WALK8 1         /* 8 fingerprints per step in the queue walk (phase B) */
-#endif
-#ifndef QM2_WIN8
-#define QM2_WIN8 0          /* 8 fingerprints per k-mer in phase A: queue 10 % -> 2 %, but 3 % SLOWER at C3 (25.2 vs 24.5 ms, same box) */
-#endif
         /* finish a walk that stands at staged position p; adds the slots it inspects from there on.
          * Beyond the slice — only behind a run of >= kHalo occupied slots — it goes on in global
-         * memory like the direct kernel. */
+         * memory, against the keys themselves (their records are made on the spot: rare). */
         auto walk = [&](uint64_t km, uint32_t p) {
             uint32_t seen = 0;
+            const bool zero = km == zrec;
             for (;;) {
-                if (p + (QM2_WALK8 ? 8u : 4u) > seg || km == 0) {
+                if (p + 8u > seg || zero) {
                     for (;;) {
-                        uint64_t v;
-                        uint32_t *ctr;
-                        if (p < seg) { v = bkey[p]; ctr = nullptr; }
-                        else {
+                        bool hit, empty;
+                        uint32_t *ctr = nullptr;
+                        if (p < seg) {
+                            const uint64_t v = bkey[p];
+                            empty = ((uint32_t)(v >> 32) & kCodeMask) == kCodeMask;
+                            hit = zero ? empty : v == km;
+                        } else {
                             const uint64_t slot = (down ? seg_lo + seg - 1u - (uint64_t)p : seg_lo + p) - tv.span_lo;
-                            v = tv.keys[slot];
+                            const uint64_t v = tv.keys[slot];
                             ctr = tv.counters + slot;
+                            empty = v == 0;
+                            const uint32_t hv = djb32(v);
+                            hit = zero ? empty
+                                       : !empty && rec_r(v) == (uint32_t)km && rec_w(v, hv, lgH, LG_S) == (uint32_t)(km >> 32) &&
+                                         (hv & tv.hmask) >> LG_S == (uint32_t)(own_lo >> LG_S);
                         }
                         seen++;
-                        if (v == km) {                                      /* :98, :291 */
+                        if (hit) {                                          /* :98, :291 */
                             if (ctr) atomicAdd(ctr, 1u); else atomicAdd(&bcnt[p], 1u);
                             n_hits++;
                             break;
                         }
-                        if (v == 0) break;
+                        if (empty) break;
                         p++;                                                /* :97 */
                     }
                     break;
                 }
                 uint32_t lm, le;
-#if QM2_WALK8
                 /* eight fingerprints a step: a wave's queue is finished when its LONGEST walk is, and every step
                  * is three dependent LDS round trips */
                 const uint32_t f0 = bfp[p >> 2], f1 = bfp[(p >> 2) + 1], f2 = bfp[(p >> 2) + 2];
@@ -864,63 +944,45 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                 seen += (min(min(lm, le), 63u) >> 3) + 1u;
                 if (lm > le) break;                                         /* an empty slot first */
                 if (lm <= 63u && bkey[p + c] == km) { atomicAdd(&bcnt[p + c], 1u); n_hits++; break; }
-#else
-                const uint32_t w = __builtin_amdgcn_alignbyte(bfp[(p >> 2) + 1], bfp[p >> 2], p);
-                QM2_WINDOW(w, km, lm, le)
-                const uint32_t c = __builtin_amdgcn_ubfe(lm, 3, 2);
-                seen += (min(min(lm, le), 31u) >> 3) + 1u;
-                if (lm > le) break;                                         /* an empty slot first */
-                if (lm <= 31u && bkey[p + c] == km) { atomicAdd(&bcnt[p + c], 1u); n_hits++; break; }
-#endif
                 p += c + 1u;
             }
             n_probes += seen;
         };
 
-        const uint64_t *in = kmers + (uint64_t)b * cap;
-        const uint64_t *in_next = kmers + (uint64_t)bn * cap;
+        const uint32_t *in_r = recs_r + (uint64_t)b * cap, *in_r_next = recs_r + (uint64_t)bn * cap;
+        const WT *in_w = recs_w + (uint64_t)b * cap, *in_w_next = recs_w + (uint64_t)bn * cap;
         uint32_t queued = 0;                                                /* wave-uniform */
         /* ---- phase A: K k-mers at a time, four slots each, no loop and no branch until the queue
-         * pushes: all fingerprint reads are issued before the first is used, then all key reads,
+         * pushes: all fingerprint reads are issued before the first is used, then all record reads,
          * then the compares and the (unconditional: + 0 or + 1) counter adds, so the LDS round trips
          * of the K k-mers overlap instead of adding up.  Idle lanes (beyond the bucket's fill) hold
          * a real k-mer of the bucket (load_group) and run along; only their effects are masked. ---- */
         auto probe_set = [&](const auto &km, const auto &live) {
             constexpr int K = (int)(sizeof(km) / sizeof(km[0]));
             uint32_t pp[K], d0[K], d1[K], lm[K], le[K];
-#if QM2_WIN8
-            uint32_t d2[K];
-#endif
             uint64_t vv[K];
-            constexpr uint32_t kWinBits = QM2_WIN8 ? 3u : 2u, kWinLast = QM2_WIN8 ? 63u : 31u;
+            constexpr uint32_t kWinBits = 2u, kWinLast = 31u;
 #pragma unroll
             for (int j = 0; j < K; j++) {
-                pp[j] = ((djb32(km[j]) & tv.hmask) ^ xm) + ad;              /* :92 */
+                pp[j] = ((uint32_t)(km[j] >> 32) & (uint32_t)(S - 1)) ^ xs;   /* :92, done by the level above */
                 d0[j] = bfp[pp[j] >> 2];
                 d1[j] = bfp[(pp[j] >> 2) + 1];
-#if QM2_WIN8
-                d2[j] = bfp[(pp[j] >> 2) + 2];
-#endif
             }
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 const uint32_t w = __builtin_amdgcn_alignbyte(d1[j], d0[j], pp[j]);   /* fingerprints of p .. p+3 */
-#if QM2_WIN8
-                const uint32_t w1 = __builtin_amdgcn_alignbyte(d2[j], d1[j], pp[j]);  /* ... and of p+4 .. p+7 */
-                QM2_WINDOW8(w, w1, km[j], lm[j], le[j])
-#else
                 QM2_WINDOW(w, km[j], lm[j], le[j])
-#endif
                 vv[j] = bkey[pp[j] + __builtin_amdgcn_ubfe(lm[j], 3, kWinBits)];
             }
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 const uint32_t c = __builtin_amdgcn_ubfe(lm[j], 3, kWinBits);
-                const bool on = live[j] && km[j] != 0;                      /* k-mer 0: everything is left to walk() */
+                const bool zero = km[j] == zrec;
+                const bool on = live[j] & !zero;                            /* k-mer 0: everything is left to walk() */
                 const bool cand = lm[j] <= le[j];
-                /* (lm <= kWinLast: a real fingerprint match — with none, slot c holds a key of another fingerprint,
+                /* (lm <= kWinLast: a real fingerprint match — with none, slot c holds a record of another fingerprint,
                  *  or, in a slice cut short by its span, whatever the buffer held before) */
-                /* (& and not &&: with && hipcc sinks the first key read of a set into the branch and waits for it there,
+                /* (& and not &&: with && hipcc sinks the first record read of a set into the branch and waits for it there,
                  *  one exposed LDS round trip per set: bucket_count 26.2 -> 25.5 ms at C3) */
                 const bool hit = on & cand & (lm[j] <= kWinLast) & (vv[j] == km[j]);  /* :98 */
                 atomicAdd(&bcnt[pp[j] + c], hit ? 1u : 0u);                 /* :291 */
@@ -929,13 +991,13 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                  * divided by 8 once per wave at the end */
                 probes8 += on ? min(min(lm[j], le[j]), kWinLast) + 1u : 0u;
                 /* a false fingerprint match, or nothing decisive in 4 slots: this wave's queue */
-                const bool more = live[j] && (km[j] == 0 || (cand && !hit));
+                const bool more = live[j] && (zero || (cand && !hit));
                 const unsigned long long m = __ballot(more);
                 if (m) {
                     const uint32_t slot = queued + __popcll(m & ((1ull << lane) - 1));
                     if (more && slot < (uint32_t)kQueueCap) {               /* (beyond the capacity: the redo pass below) */
                         qk[pw][slot] = km[j];
-                        qa[pw][slot] = (uint16_t)(km[j] ? pp[j] + c + 1u : pp[j]);
+                        qa[pw][slot] = (uint16_t)(zero ? pp[j] : pp[j] + c + 1u);
                     }
                     queued += __popcll(m);
                 }
@@ -944,12 +1006,22 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
         uint32_t base = 0;
         /* runs once even for an empty bucket: it carries the next bucket's prefetch */
         while (base == 0 || base < n) {
-            u32x4 kq[G2];
-#pragma unroll
-            for (int q = 0; q < G2; q++) kq[q] = nq[q];
+            const Group kq = nq;
+            /* The group about to be probed has to have arrived before the next one is asked for: hipcc gives the prefetch
+             * fresh registers and then waits for the group in hand with vmcnt(0) BEHIND the prefetch's loads — i.e. for
+             * the prefetch as well, a whole memory round trip per group (bucket_count 25.0 -> 25.9 ms when the records came
+             * in).  Waiting here costs nothing: these are the only loads a prober has in flight. */
+            __builtin_amdgcn_s_waitcnt(0x0F70);            /* vmcnt(0) — as the builtin: hipcc's own wait insertion reads it, an asm statement it does not */
+            QM2_STAMP(11);
             /* next group of this bucket, or behind the last one the first group of the next bucket */
-            if (base + kGroupKmers >= n) load_group(bn < n_buckets ? in_next : in, 0, n_next);   /* workgroup-uniform */
-            else load_group(in, base + kGroupKmers, n);
+            auto prefetch = [&]() {
+                if (base + kGroupKmers >= n) {                               /* workgroup-uniform */
+                    if (bn < n_buckets) load_group(in_r_next, in_w_next, 0, n_next); else load_group(in_r, in_w, 0, n_next);
+                } else load_group(in_r, in_w, base + kGroupKmers, n);
+            };
+#if !QM2_PREFETCH_LATE
+            prefetch();
+#endif
             QM2_STAMP(4);
             /* All G2 rows run as straight-line blocks even when the last ones hold no k-mer
              * (skipping rows was measured slower in round 1): the host picks G2 to fit the fill. */
@@ -959,24 +1031,45 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
                 bool live[2 * R];
 #pragma unroll
                 for (int t = 0; t < R; t++) {
-                    const uint32_t e = base + 2u * ((Q0 + t) * kProberThreads + pt);
-                    km[2 * t] = ((uint64_t)kq[Q0 + t].y << 32) | kq[Q0 + t].x;
-                    km[2 * t + 1] = ((uint64_t)kq[Q0 + t].w << 32) | kq[Q0 + t].z;
+                    const int row = Q0 + t;
+                    uint32_t e, r0, r1, w0, w1;
+                    if (row < 2 * kQuads) {
+                        const int q = row >> 1, hf = row & 1;
+                        e = base + 4u * (q * kProberThreads + pt) + 2u * hf;
+                        r0 = hf ? kq.r4[q].z : kq.r4[q].x;
+                        r1 = hf ? kq.r4[q].w : kq.r4[q].y;
+                        if constexpr (W16) {
+                            const uint32_t ww = hf ? kq.w4[q].y : kq.w4[q].x;
+                            w0 = ww & 0xFFFFu; w1 = ww >> 16;
+                        } else {
+                            w0 = hf ? kq.w4[q].z : kq.w4[q].x;
+                            w1 = hf ? kq.w4[q].w : kq.w4[q].y;
+                        }
+                    } else {
+                        e = base + 4u * kQuads * kProberThreads + 2u * pt;
+                        r0 = kq.r2.x; r1 = kq.r2.y;
+                        if constexpr (W16) { w0 = kq.w2 & 0xFFFFu; w1 = kq.w2 >> 16; }
+                        else               { w0 = kq.w2.x; w1 = kq.w2.y; }
+                    }
+                    km[2 * t] = ((uint64_t)w0 << 32) | r0;
+                    km[2 * t + 1] = ((uint64_t)w1 << 32) | r1;
                     live[2 * t] = e < n;
                     live[2 * t + 1] = e + 1u < n;
                 }
                 probe_set(km, live);
             };
-            constexpr int kR = kSet / 2;               /* 16-byte rows per set */
+            constexpr int kR = kSet / 2;               /* rows per set */
 #define QM2_SET(I)                                                                                     \
             if constexpr (G2 > (I) * kR)                                                                   \
                 probe_rows(std::integral_constant<int, (I) * kR>{},                                        \
                            std::integral_constant<int, (G2 - (I) * kR < kR ? G2 - (I) * kR : kR)>{});
-            QM2_SET(0) QM2_SET(1) QM2_SET(2) QM2_SET(3) QM2_SET(4) QM2_SET(5)
+            QM2_SET(0)
+#if QM2_PREFETCH_LATE
+            prefetch();
+#endif
+            QM2_SET(1) QM2_SET(2) QM2_SET(3) QM2_SET(4) QM2_SET(5)
 #undef QM2_SET
             static_assert(G2 <= 6 * kR, "at most six sets per group");
-            /* (the two sets of a group interleaved — the second set's hashes and fingerprint reads issued before the first
-             *  set's compares — measured: 25.47 -> 25.38 ms, nothing: the other prober waves already cover those waits) */
             QM2_STAMP(5);
             base += kGroupKmers;
         }
@@ -995,26 +1088,23 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
             for (uint32_t base2 = 0; base2 < n; base2 += kGroupKmers) {
 #pragma unroll 1
                 for (uint32_t q = 0; q < 2u * G2; q++) {
-                    const uint32_t e = base2 + 2u * ((q >> 1) * kProberThreads + pt) + (q & 1u);
+                    /* (phase A's order: row q >> 1, k-mer q & 1 of it; rows 2 Q, 2 Q + 1 are the halves of quad Q) */
+                    const uint32_t row = q >> 1;
+                    const uint32_t e = row < 2u * kQuads ? base2 + 4u * ((row >> 1) * kProberThreads + pt) + 2u * (row & 1u) + (q & 1u)
+                                                         : base2 + 4u * kQuads * kProberThreads + 2u * pt + (q & 1u);
                     const bool live = e < n;
-                    const uint64_t km = live ? in[e] : 0;
+                    const uint64_t km = live ? ((uint64_t)in_w[e] << 32) | in_r[e] : 0;
                     uint32_t at = 0;
                     bool more = false;
                     if (live) {
-                        const uint32_t p = ((djb32(km) & tv.hmask) ^ xm) + ad;
+                        const uint32_t p = ((uint32_t)(km >> 32) & (uint32_t)(S - 1)) ^ xs;
                         uint32_t lm, le;
                         const uint32_t w = __builtin_amdgcn_alignbyte(bfp[(p >> 2) + 1], bfp[p >> 2], p);
-#if QM2_WIN8
-                        const uint32_t w1 = __builtin_amdgcn_alignbyte(bfp[(p >> 2) + 2], bfp[(p >> 2) + 1], p);
-                        QM2_WINDOW8(w, w1, km, lm, le)
-                        const uint32_t c = __builtin_amdgcn_ubfe(lm, 3, 3);
-                        more = km == 0 || (lm <= le && !(lm <= 63u && bkey[p + c] == km));
-#else
                         QM2_WINDOW(w, km, lm, le)
                         const uint32_t c = __builtin_amdgcn_ubfe(lm, 3, 2);
-                        more = km == 0 || (lm <= le && !(lm <= 31u && bkey[p + c] == km));
-#endif
-                        at = km ? p + c + 1u : p;
+                        const bool zero = km == zrec;
+                        more = zero || (lm <= le && !(lm <= 31u && bkey[p + c] == km));
+                        at = zero ? p : p + c + 1u;
                     }
                     const unsigned long long m = __ballot(more);           /* every lane: the same count as phase A's */
                     const uint32_t slot = q2 + __popcll(m & ((1ull << lane) - 1));
@@ -1032,6 +1122,7 @@ void bucket_count_kernel(const uint64_t *kmers, const uint32_t *cursors, uint32_
 #ifdef QM2_STAMPS
     if (lane == 0) {
         for (int i = 4; i < 8; i++) atomicAdd(&qm2_stamp_acc[i], st_acc[i]);
+        atomicAdd(&qm2_stamp_acc[11], st_acc[11]);
         atomicAdd(&qm2_stamp_acc[9], 1ull);
     }
 #endif

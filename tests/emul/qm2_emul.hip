@@ -136,6 +136,13 @@ uint64_t qm2e_extract_dealt(const char *buf, size_t n, uint32_t k, size_t piece_
 
 uint32_t qm2e_djb32(uint64_t kmer) { return djb32(kmer); }
 
+/* bucket records (qm2_device.hip.h): the two words of n k-mers */
+void qm2e_records(const uint64_t *kmers, uint64_t n, uint32_t lgH, uint32_t lg_s, uint32_t *r, uint32_t *w)
+{
+    for (uint64_t i = 0; i < n; i++) { r[i] = rec_r(kmers[i]); w[i] = rec_w(kmers[i], djb32(kmers[i]), lgH, lg_s); }
+}
+uint32_t qm2e_rec_ext_bits(uint32_t k, uint32_t lgH) { return rec_ext_bits(k, lgH); }
+
 /* the buffer layouts of a partition level (slot_of): where k-mer e of region r goes */
 uint64_t qm2e_slot_of(int segmented, uint64_t region, uint32_t e, uint32_t cap, uint32_t lg_row)
 {

@@ -134,6 +134,63 @@ def test_kat_case_streams():
             assert nb == exp_nb and np.array_equal(got, exp), name
 
 
+def _decode_record(r, w, bucket, lgH, lg_s):
+    """The k-mer of bucket record (r, w) in bucket `bucket` of a table of 2^lgH slots, by the argument of
+    qm2_device.hip.h ("bucket records"): the hash from bucket + w, V from the hash and b5..b7, its base-33 digits
+    b4..b1 each from its residue and its top three bits, b0 what is left."""
+    C33 = (5381 * pow(33, 8, 2 ** 32)) % 2 ** 32
+    slot = w & ((1 << lg_s) - 1)
+    assert (w >> lg_s) & 3 == 0                      # a k-mer's code bits
+    ext = w >> (lg_s + 2)                            # (x : h) >> lgH
+    h = ((ext << lgH) | (bucket << lg_s) | slot) & 0xFFFFFFFF
+    x = ((ext << lgH) >> 32) & 3
+    t4, mid, t2, t1, t3 = r & 7, (r >> 3) & 0xFFFFF, (r >> 23) & 7, (r >> 26) & 7, (r >> 29) & 7
+    b5, b6, b7 = mid & 0xFF, (mid >> 8) & 0xFF, (mid >> 16) | (x << 4)
+    V = ((h - C33 - (1089 * b5 + 33 * b6 + b7)) * pow(33 ** 3, -1, 2 ** 32)) % 2 ** 32
+    digits = {}
+    for i, t in ((4, t4), (3, t3), (2, t2), (1, t1)):
+        cand = [v for v in range(32 * t, 32 * t + 32) if v % 33 == V % 33]
+        assert len(cand) == 1
+        digits[i] = cand[0]
+        V = (V - cand[0]) // 33
+    assert 0 <= V < 256
+    return (V | digits[1] << 8 | digits[2] << 16 | digits[3] << 24 | digits[4] << 32 | b5 << 40 | b6 << 48 | b7 << 56)
+
+
+@pytest.mark.parametrize("k,lgH,lg_s", [(30, 32, 12), (31, 32, 12), (30, 28, 12), (25, 21, 12), (31, 20, 12), (12, 16, 12), (30, 30, 12)])
+def test_bucket_records_are_one_to_one(k, lgH, lg_s):
+    """rec_r / rec_w (qm2_device.hip.h): the 6- or 8-byte record of a k-mer inside its finest bucket — what the
+    partition's last level writes and bucket_count compares — decodes back to the k-mer, so two k-mers of one bucket
+    are equal iff their records are; the record's slot bits are the home slot inside the bucket (QuicKmer.c:92); and
+    the bits beside slot and code fit the width rec_ext_bits promises."""
+    L = emul()
+    L.qm2e_records.restype = None
+    L.qm2e_records.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.qm2e_rec_ext_bits.restype = C.c_uint32
+    L.qm2e_rec_ext_bits.argtypes = [C.c_uint32, C.c_uint32]
+    rng = np.random.default_rng(k * 100 + lgH)
+    mask = (1 << (2 * k)) - 1
+    kmers = rng.integers(0, 2 ** 63, 20000, dtype=np.uint64) & np.uint64(mask)
+    # corner cases: poly-A, all ones, single bytes, neighbours of a random k-mer in every byte
+    extra = [0, mask, 1, 0xFF, 0xFF00, 0xFF << 32, 0x1F << 8, 0x20 << 8, 0x21 << 8]
+    base = int(kmers[0])
+    for byte in range(8):
+        for d in (1, 32, 33, 66, 255):
+            extra.append((base ^ (d << (8 * byte))) & mask)
+    kmers = np.concatenate([kmers, np.array(extra, dtype=np.uint64) & np.uint64(mask)])
+    r = np.zeros(len(kmers), dtype=np.uint32)
+    w = np.zeros(len(kmers), dtype=np.uint32)
+    L.qm2e_records(kmers.ctypes.data, len(kmers), lgH, lg_s, r.ctypes.data, w.ctypes.data)
+    ext_bits = int(L.qm2e_rec_ext_bits(k, lgH))
+    assert ext_bits == (32 - lgH) + (2 if k == 31 else 0)
+    assert int(w.max()) >> (lg_s + 2 + ext_bits) == 0
+    for km, ri, wi in zip(kmers.tolist(), r.tolist(), w.tolist()):
+        h = int(L.qm2e_djb32(km))
+        home = h & ((1 << lgH) - 1)
+        assert wi & ((1 << lg_s) - 1) == home & ((1 << lg_s) - 1)
+        assert _decode_record(ri, wi, (home >> lg_s), lgH, lg_s) == km
+
+
 def test_partition_buffer_layouts_are_one_to_one():
     """slot_of (qm2_device.hip.h): the child-major and the segmented [segment][region] layout of a partition
     level's buffer each map (region, k-mer index) one-to-one onto the buffer's slots, and in the segmented one
