@@ -582,6 +582,10 @@ def main():
             sys.stderr.write("STAMPS split_text waves=%d kcycles/wave: window=%.0f zero+barrier=%.0f kmers+copy_out=%.0f sort=%.0f total=%.0f\n"
                              % (acc[20], acc[16] / acc[20] / 1e3, acc[17] / acc[20] / 1e3, acc[18] / acc[20] / 1e3, acc[19] / acc[20] / 1e3,
                                 tot / acc[20] / 1e3))
+        if acc[27]:
+            w = acc[27]
+            sys.stderr.write("STAMPS sort_chunk (split_text) waves=%d kcycles/wave: hist_barrier=%.0f scan=%.0f reserve+barrier=%.0f scatter=%.0f atomics_return=%.0f dl+barrier=%.0f\n"
+                             % (w, acc[21] / w / 1e3, acc[22] / w / 1e3, acc[23] / w / 1e3, acc[24] / w / 1e3, acc[25] / w / 1e3, acc[26] / w / 1e3))
     except AttributeError:
         pass
 
@@ -611,6 +615,9 @@ def main():
         piece = 1 << 28                      # (summed in pieces: torch widens the operand of an int64 sum)
         total = sum(int(counters[a:a + piece].sum(dtype=torch.int64)) for a in range(0, counters.numel(), piece))
         counts_conserved = bool(total == hits_all)
+        if not counts_conserved:
+            sys.stderr.write("COUNTS NOT CONSERVED: sum of the merged counters %d, hits of all ranks %d, this rank: %s, profile %s\n"
+                             % (total, hits_all, st1, prof1))
 
     # ---- parity at the benchmarked geometry: batch 0 once more through the partitioned pipeline (the plan
     #      the steps above ran with: sub-regions, bucket capacities, buffers all sized for THIS batch) and once

@@ -54,11 +54,15 @@ constexpr uint64_t kPad      = ~0ull;                /* never a k-mer (k <= 31 u
 constexpr int kHalo          = QM2_HALO;             /* table slots staged past a bucket's
                                                         middle-facing edge                      */
 constexpr int kCountThreads  = QM2_COUNT_THREADS;
+#ifndef QM2_STAMPS_SORT
+#define QM2_STAMPS_SORT 0         /* diagnostic build (-DQM2_STAMPS): 1 = also the phases of sort_chunk in split_text_kernel */
+#endif
 #ifndef QM2_COUNT_BLOCKED
 #define QM2_COUNT_BLOCKED 0
 #endif
 #ifndef QM2_PREFETCH_LATE
-#define QM2_PREFETCH_LATE 0       /* experiment: ask for the next group behind the first probe set instead of in front of it */
+#define QM2_PREFETCH_LATE 1       /* the next group is asked for behind the first probe set, not in front of it: away from the loaders' burst
+                                     at the start of a bucket (C3, same box: bucket_count 23.83 -> 23.45 ms; 23.73 -> 23.40 with QM2_COUNT_BLOCKED) */
 #endif
 #ifndef QM2_COUNT_SET
 #define QM2_COUNT_SET 6           /* k-mers probed together (measured at C3: 2 -> 23.2, 4 -> 22.9, 6 -> 22.0 ms) */
@@ -178,12 +182,21 @@ __device__ __attribute__((noinline)) void copy_spills(const SplitLds &L, uint64_
  * L.total say where every element goes; the copy-out (copy_piece) is left to the caller, which
  * interleaves it with the NEXT chunk's compute so that the stores (HBM-bound, ~2 ms per 10 GB)
  * drain behind VALU work instead of stalling every wave at once. */
+/* (diagnostic build, -DQM2_STAMPS -DQM2_STAMPS_SORT=1: the phases of sort_chunk inside split_text_kernel) */
+#ifdef QM2_STAMPS
+#define QM2_SORT_STAMP_ARGS , unsigned long long *st_acc, unsigned long long &st_last, bool st_on
+#define QM2_SORT_STAMP(I) do { if (st_on) QM2_STAMP(I); } while (0)
+#else
+#define QM2_SORT_STAMP_ARGS
+#define QM2_SORT_STAMP(I) do { } while (0)
+#endif
 __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKpt], const uint32_t (&tag)[kKpt],
                                            uint64_t child0, uint32_t fan, const SplitDst &d,
-                                           unsigned long long &lost)
+                                           unsigned long long &lost QM2_SORT_STAMP_ARGS)
 {
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     lds_barrier();                 /* hist complete; every wave is done reading the previous L.sorted / L.dl */
+    QM2_SORT_STAMP(21);
     if (tid == 0) L.spill_n = 0;
     /* exclusive scan of hist[0..fan): thread t takes children t, t + kSplitThreads, ... (kChildPerThread of them:
      * consecutive lanes = consecutive children, so the reservations below are the contiguous, full-rate atomic shape) */
@@ -204,6 +217,7 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
         if (holder && lane == kWave - 1) L.wsum[i * kScanWaves + wave] = incl[i];
     }
     lds_barrier();
+    QM2_SORT_STAMP(22);
     uint32_t g[C], off[C];
     {
         /* sums of the waves before this one: every wave scans the (at most 16) wave totals itself */
@@ -232,12 +246,21 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
         if (tid == 0) { L.total = tot; L.off[kMaxFan] = (uint16_t)tot; }
     }
     lds_barrier();
+    QM2_SORT_STAMP(23);
 #pragma unroll
     for (int j = 0; j < kKpt; j++) {
         /* empty slots carry child id kMaxFan: they land behind the chunk's last k-mer, no branch */
         const uint32_t pos = (uint32_t)L.off[tag[j] >> 16] + (tag[j] & 0xFFFFu);
         L.sorted[pos] = km[j];
     }
+#ifdef QM2_STAMPS
+    if (st_on) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        QM2_STAMP(24);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* the reservations' return (behind everything older of this wave) */
+        QM2_STAMP(25);
+    }
+#endif
     uint32_t f[C];
 #pragma unroll
     for (int i = 0; i < C; i++) {
@@ -265,6 +288,7 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
         }
     }
     lds_barrier();
+    QM2_SORT_STAMP(26);
     if (L.spill_n) copy_spills(L, d.spill);               /* workgroup-uniform, rare */
 }
 
@@ -367,7 +391,7 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
     /* the 16 bytes of this lane for the NEXT chunk are fetched while the current one is processed */
     uint4 bytes = load16_raw(sv, lane_offset(((uint64_t)blockIdx.x * kSplitWaves + wave) * kTileBytes, lane));
 #ifdef QM2_STAMPS
-    unsigned long long st_acc[24] = {0}, st_last = stamp_now();
+    unsigned long long st_acc[28] = {0}, st_last = stamp_now();
 #endif
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint64_t tile = chunk * kSplitWaves + wave;
@@ -402,7 +426,11 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
         QM2_T(8) QM2_T(9) QM2_T(10) QM2_T(11) QM2_T(12) QM2_T(13) QM2_T(14) QM2_T(15)
 #undef QM2_T
         QM2_STAMP(18);
+#ifdef QM2_STAMPS
+        sort_chunk(L, km, tag, child0, fan, d, lost, st_acc, st_last, QM2_STAMPS_SORT == 1);
+#else
         sort_chunk(L, km, tag, child0, fan, d, lost);
+#endif
         QM2_STAMP(19);
         pend = true;
     }
@@ -410,6 +438,7 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
 #ifdef QM2_STAMPS
     if (lane == 0) {
         for (int i = 16; i < 20; i++) atomicAdd(&qm2_stamp_acc[i], st_acc[i]);
+        if (QM2_STAMPS_SORT == 1) { for (int i = 21; i < 27; i++) atomicAdd(&qm2_stamp_acc[i], st_acc[i]); atomicAdd(&qm2_stamp_acc[27], 1ull); }
         atomicAdd(&qm2_stamp_acc[20], 1ull);
     }
 #endif
@@ -504,7 +533,11 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
         QM2_K(0) QM2_K(1) QM2_K(2) QM2_K(3) QM2_K(4) QM2_K(5) QM2_K(6) QM2_K(7)
         QM2_K(8) QM2_K(9) QM2_K(10) QM2_K(11) QM2_K(12) QM2_K(13) QM2_K(14) QM2_K(15)
 #undef QM2_K
+#ifdef QM2_STAMPS
+        { unsigned long long st_none[1], st_t = 0; sort_chunk(L, km, tag, child0, fan, d, lost, st_none, st_t, false); }
+#else
         sort_chunk(L, km, tag, child0, fan, d, lost);
+#endif
         pend = true;
     }
     if (pend) copy_all<DST_SEG, FIN>(L, d, child0, shift, bits);
@@ -631,7 +664,9 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     /* Which buckets a workgroup takes.  Round-robin (b, b + grid, ...) every bucket of a workgroup lies ~10 MB from its
-     * last one in each of the six arrays it streams; QM2_COUNT_BLOCKED gives it a run of consecutive buckets instead. */
+     * last one in each of the six arrays it streams; QM2_COUNT_BLOCKED gives it a run of consecutive buckets instead
+     * (measured at C3, same box: 23.73 vs 23.62 ms, and 18.91 vs 18.75 at 10 M reads per launch — no difference: the
+     * translation caches are not what this kernel waits for). */
 #if QM2_COUNT_BLOCKED
     const uint32_t per_wg = (n_buckets_all + gridDim.x - 1) / gridDim.x;
     const uint32_t stride = 1u, b_first = blockIdx.x * per_wg;

@@ -1345,7 +1345,7 @@ def test_bench_replicas_two_ranks_on_one_gpu(torch_cuda, tmp_path):
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["counts_conserved"] is True, line["config"]
+    assert line["n_gpus"] == 2 and line["config"]["counts_conserved"] is True, (line["config"], r.stderr[-3000:])
     assert line["roofline"]["mode"] == "partitioned" and line["config"]["final_reduce_ms"] is not None
     assert line["value"] > 0
 
