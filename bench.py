@@ -653,11 +653,16 @@ def main():
     b_survey = d["n_bases"] + 8 * d["n_probes"] + 4 * d["n_hits"]        # SURVEY 8(d), whole timed region
     levels_kmer = (cls_n["split_kmer"] // max(1, part_batches)) if part_batches else 0
     # bytes each kernel class must move over the timed region by ITS OWN model
+    # (the finest level and the table pass hold bucket records, DESIGN.md section 3: 6 bytes from 2^30 slots on, else 8)
+    rec = 6 if H >= (1 << 30) else 8
     alg = {
         "count_direct": b_survey if part_batches == 0 else 0,
-        "split_text": d["n_bases"] + 8 * d["n_kmers"],                     # text in, k-mers out
-        "split_kmer": 16 * d["n_kmers"] * levels_kmer,                     # k-mers in + out, per level
-        "bucket_count": (8 * d["n_kmers"] + args.steps * (8 * H + 8 * n_unique)) if part_batches else 0,
+        # text in, k-mers out (records, when the text level is the finest one)
+        "split_text": d["n_bases"] + (8 if levels_kmer else rec) * d["n_kmers"],
+        # k-mers in + out per level, the last one writing records
+        "split_kmer": (16 * (levels_kmer - 1) + 8 + rec) * d["n_kmers"] if levels_kmer else 0,
+        # records in; per launch the table image of every slot + its 2-byte interior counter read and written
+        "bucket_count": (rec * d["n_kmers"] + args.steps * (rec * H + 4 * H)) if part_batches else 0,
         "probe": 0, "encode": 0, "lines": 0,
     }
     # HBM bytes per launch measured by PMC counters: written by tools/summarize_profile.py from the rocprofv3
