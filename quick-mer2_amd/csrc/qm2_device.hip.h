@@ -204,6 +204,35 @@ __host__ __device__ __forceinline__ uint32_t rec_w(uint64_t key, uint32_t h, uin
     const uint32_t home = lgH >= 32 ? h : h & ((1u << lgH) - 1u);
     return (home & ((1u << lg_s) - 1u)) | (ext << (lg_s + 2u));
 }
+/* The two CODE bits above the slot bits of a record's second word.
+ *   k-mers:       0.
+ *   table image:  where the key's home bucket lies from the slot's own: 0 the same, 1 the one before (lower slots),
+ *                 2 the one behind, 3 = no key that any k-mer of this or a neighbouring bucket could equal: with slot
+ *                 bits 0 an EMPTY slot, with slot bits 1 a key from further away (a run of > S occupied slots).
+ *   staged (LDS): 0 = may equal a k-mer of the bucket being counted (home bucket = that bucket: code 0 in its own slots,
+ *                 1 / 2 in the halo of a bucket that walks up / down), 1 = occupied by a key of another bucket,
+ *                 3 = empty.  So one 64-bit compare of a staged record with a k-mer's is the reference's T[i] == key. */
+constexpr uint32_t kCodeEmpty = 3u, kCodeOther = 1u;
+/* the image's second word for `key` in table slot `slot` (R is rec_r(key), 0 for an empty slot) */
+__host__ __device__ __forceinline__ uint32_t rec_image_w(uint64_t key, uint64_t slot, uint32_t hmask, uint32_t lgH, uint32_t lg_s)
+{
+    if (key == 0) return kCodeEmpty << lg_s;
+    const uint32_t h = djb32(key);
+    const uint64_t bh = (h & hmask) >> lg_s, bp = slot >> lg_s;
+    const uint32_t w = rec_w(key, h, lgH, lg_s);
+    if (bh == bp) return w;
+    if (bh + 1 == bp) return w | (1u << lg_s);
+    if (bh == bp + 1) return w | (2u << lg_s);
+    return (kCodeEmpty << lg_s) | 1u;
+}
+/* an image word as bucket_count stages it for a bucket that walks down / up, in that bucket's own slots or its halo */
+__host__ __device__ __forceinline__ uint32_t rec_staged_w(uint32_t w, bool halo, bool down, uint32_t lg_s)
+{
+    const uint32_t mask = 3u << lg_s, code = w & mask, want = halo ? (down ? 2u : 1u) << lg_s : 0u;
+    const bool empty = code == mask && (w & ((1u << lg_s) - 1u)) == 0u;
+    return empty ? mask : (w & ~mask) | (code == want ? 0u : kCodeOther << lg_s);
+}
+__host__ __device__ __forceinline__ bool rec_staged_empty(uint32_t staged_w, uint32_t lg_s) { return ((staged_w >> lg_s) & 3u) == kCodeEmpty; }
 /* bits of w beside the slot and the code: what must fit 16 - (lg_s + 2) bits for the 2-byte form, 32 - (lg_s + 2) at all */
 __host__ __device__ __forceinline__ uint32_t rec_ext_bits(uint32_t k, uint32_t lgH) { return (32u - lgH) + (k > 30 ? 2u * (k - 30u) : 0u); }
 

@@ -594,15 +594,8 @@ struct CountGeo {
     uint64_t half;          /* H >> 1: buckets at or above walk down                            */
 };
 
-/* The second word of a record carries two CODE bits above the slot bits.
- *   k-mers:       0.
- *   table image:  where the key's home bucket lies from the slot's own: 0 the same, 1 the one before (lower slots),
- *                 2 the one behind, 3 = no key that any k-mer of this or a neighbouring bucket could equal: with slot
- *                 bits 0 an EMPTY slot, with slot bits 1 a key from further away (a run of > S occupied slots).
- *   staged (LDS): 0 = may equal a k-mer of the bucket being counted (home bucket = that bucket: code 0 in its own slots,
- *                 1 / 2 in the halo of a bucket that walks up / down), 1 = occupied by a key of another bucket,
- *                 3 = empty.  So one 64-bit compare of a staged record with a k-mer's is the reference's T[i] == key. */
-constexpr uint32_t kCodeEmpty = 3u, kCodeOther = 1u;
+/* (the two CODE bits above the slot bits of a record's second word, and the rules that set them: qm2_device.hip.h,
+ * rec_image_w / rec_staged_w — compiled for the host too and pinned by tests/emul) */
 
 /* fingerprint of a record: odd, 1..255, a function of R alone (the slot bits are what neighbours in a probe window have
  * in common, not what tells them apart); of an empty slot: 0; beyond the staged slice: 0xFE.  One v_dot4_u32_u8 folds
@@ -623,18 +616,8 @@ __global__ void table_image_kernel(const uint64_t *keys, uint64_t n_slots, uint6
     const uint32_t lgH = (uint32_t)__builtin_popcount(hmask);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t key = keys[i];
-        uint32_t r = 0, w = kCodeEmpty << lg_s;
-        if (key) {
-            const uint32_t h = djb32(key);
-            const uint64_t bh = (h & hmask) >> lg_s, bp = (span_lo + i) >> lg_s;
-            r = rec_r(key);
-            w = rec_w(key, h, lgH, lg_s);
-            if (bh + 1 == bp) w |= 1u << lg_s;
-            else if (bh == bp + 1) w |= 2u << lg_s;
-            else if (bh != bp) w = (kCodeEmpty << lg_s) | 1u;
-        }
-        img_r[i] = r;
-        img_w[i] = (WT)w;
+        img_r[i] = key ? rec_r(key) : 0u;
+        img_w[i] = (WT)rec_image_w(key, span_lo + i, hmask, lgH, lg_s);
     }
 }
 
@@ -730,13 +713,12 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
             const Geo g = geo(b);
             /* the code a key that a k-mer of THIS bucket can equal carries in the image: 0 in the bucket's own slots,
              * in its halo (the next bucket's slots, walking up; the previous one's, walking down) 1 resp. 2 */
-            const uint32_t halo_code = (g.down ? 2u : 1u) << LG_S;
             const uint32_t own_from = g.down ? g.seg - (uint32_t)S : 0u;          /* own slots: [own_from, own_from + S) */
 #pragma unroll
             for (int st = 0; st < kSteps; st++) {
                 const uint32_t i = 4u * (tid + st * kLoaderThreads);
                 if (i < g.seg) {
-                    const uint32_t want = i - own_from < (uint32_t)S ? 0u : halo_code;
+                    const bool halo = i - own_from >= (uint32_t)S;
                     uint32_t w[4];
                     if constexpr (W16) { w[0] = wv[st].x & 0xFFFFu; w[1] = wv[st].x >> 16; w[2] = wv[st].y & 0xFFFFu; w[3] = wv[st].y >> 16; }
                     else               { w[0] = wv[st].x; w[1] = wv[st].y; w[2] = wv[st].z; w[3] = wv[st].w; }
@@ -744,10 +726,8 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
                     uint32_t f[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const uint32_t code = w[j] & kCodeMask;
-                        const bool empty = code == kCodeMask && (w[j] & (uint32_t)(S - 1)) == 0u;
-                        f[j] = empty ? 0u : fp8(r[j]);
-                        w[j] = empty ? kCodeMask : (w[j] & ~kCodeMask) | (code == want ? 0u : kCodeOther << LG_S);
+                        w[j] = rec_staged_w(w[j], halo, g.down, LG_S);
+                        f[j] = rec_staged_empty(w[j], LG_S) ? 0u : fp8(r[j]);
                     }
                     if (g.down) {
                         const uint32_t m = g.seg - 4u - i;                 /* slots i+3 .. i land at m .. m+3 */

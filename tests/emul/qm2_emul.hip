@@ -142,6 +142,20 @@ void qm2e_records(const uint64_t *kmers, uint64_t n, uint32_t lgH, uint32_t lg_s
     for (uint64_t i = 0; i < n; i++) { r[i] = rec_r(kmers[i]); w[i] = rec_w(kmers[i], djb32(kmers[i]), lgH, lg_s); }
 }
 uint32_t qm2e_rec_ext_bits(uint32_t k, uint32_t lgH) { return rec_ext_bits(k, lgH); }
+/* the table image of a whole table (what table_image_kernel makes), and image words as bucket_count's loaders stage them */
+void qm2e_table_image(const uint64_t *keys, uint64_t H, uint32_t lg_s, uint32_t *img_r, uint32_t *img_w)
+{
+    uint32_t lgH = 0;
+    while ((1ull << lgH) < H) lgH++;
+    for (uint64_t i = 0; i < H; i++) {
+        img_r[i] = keys[i] ? rec_r(keys[i]) : 0u;
+        img_w[i] = rec_image_w(keys[i], i, (uint32_t)(H - 1), lgH, lg_s);
+    }
+}
+void qm2e_stage_words(const uint32_t *w, uint64_t n, int halo, int down, uint32_t lg_s, uint32_t *out, uint8_t *empty)
+{
+    for (uint64_t i = 0; i < n; i++) { out[i] = rec_staged_w(w[i], halo != 0, down != 0, lg_s); empty[i] = rec_staged_empty(out[i], lg_s); }
+}
 
 /* the buffer layouts of a partition level (slot_of): where k-mer e of region r goes */
 uint64_t qm2e_slot_of(int segmented, uint64_t region, uint32_t e, uint32_t cap, uint32_t lg_row)

@@ -191,6 +191,92 @@ def test_bucket_records_are_one_to_one(k, lgH, lg_s):
         assert _decode_record(ri, wi, (home >> lg_s), lgH, lg_s) == km
 
 
+@pytest.mark.parametrize("lgH,lg_s,halo,fill,seed", [(14, 8, 32, 0.80, 1), (14, 8, 32, 0.93, 2), (13, 6, 16, 0.90, 3), (16, 12, 256, 0.85, 4)])
+def test_record_compare_is_the_references_compare(lgH, lg_s, halo, fill, seed):
+    """bucket_count's rule on the CPU, slot for slot: a k-mer walks the slice of its bucket (own slots + halo on the side
+    walks leave through, QuicKmer.c:93-97) and "equals" a staged table-image record iff R and the second word are equal
+    (rec_image_w as the loaders stage it, rec_staged_w).  Against Find_hash on the keys themselves (:90-99) for every
+    dictionary k-mer and as many absent ones, on tables filled until runs of occupied slots cross bucket edges, several
+    buckets and the middle of the table: the same slot or the same miss, whenever the walk stays inside the slice (the
+    kernel finishes the others in global memory on the keys)."""
+    L = emul()
+    u32p = C.c_void_p
+    L.qm2e_table_image.restype = None
+    L.qm2e_table_image.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, u32p, u32p]
+    L.qm2e_stage_words.restype = None
+    L.qm2e_stage_words.argtypes = [u32p, C.c_uint64, C.c_int, C.c_int, C.c_uint32, u32p, C.c_void_p]
+    L.qm2e_records.restype = None
+    L.qm2e_records.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    H, S = 1 << lgH, 1 << lg_s
+    rng = np.random.default_rng(seed)
+    cand = np.unique(rng.integers(1, 1 << 60, int(H * fill * 2.2), dtype=np.uint64))
+    rng.shuffle(cand)
+    n_dict = int(H * fill)
+    present, absent = cand[:n_dict], cand[n_dict:2 * n_dict]
+    homes = lambda a: np.array([int(L.qm2e_djb32(int(x))) & (H - 1) for x in a], dtype=np.int64)
+    keys = np.zeros(H, dtype=np.uint64)
+    for key, i in zip(present.tolist(), homes(present).tolist()):          # the reference's insertion (:846-860)
+        step = -1 if i & (H >> 1) else 1
+        while keys[i] != 0:
+            i += step
+        keys[i] = key
+    img_r = np.zeros(H, dtype=np.uint32)
+    img_w = np.zeros(H, dtype=np.uint32)
+    L.qm2e_table_image(keys.ctypes.data, H, lg_s, img_r.ctypes.data, img_w.ctypes.data)
+    # every image word staged all four ways
+    staged, empty = {}, {}
+    for hl in (0, 1):
+        for dn in (0, 1):
+            o = np.zeros(H, dtype=np.uint32)
+            e = np.zeros(H, dtype=np.uint8)
+            L.qm2e_stage_words(img_w.ctypes.data, H, hl, dn, lg_s, o.ctypes.data, e.ctypes.data)
+            staged[hl, dn], empty[hl, dn] = o, e
+    assert np.array_equal(empty[0, 0] != 0, keys == 0) and np.array_equal(empty[1, 1] != 0, keys == 0)
+    probes = np.concatenate([present, absent])
+    pr = np.zeros(len(probes), dtype=np.uint32)
+    pw = np.zeros(len(probes), dtype=np.uint32)
+    L.qm2e_records(probes.ctypes.data, len(probes), lgH, lg_s, pr.ctypes.data, pw.ctypes.data)
+    inside = crossed_middle = in_halo = 0
+    for key, r, w, home in zip(probes.tolist(), pr.tolist(), pw.tolist(), homes(probes).tolist()):
+        b = home >> lg_s
+        down = 1 if home & (H >> 1) else 0
+        step = -1 if down else 1
+        lo, hi = (b * S - halo, b * S + S) if down else (b * S, b * S + S + halo)        # the staged slice
+        # the reference
+        i, ref = home, None
+        while True:
+            if keys[i] == key:
+                ref = i
+                break
+            if keys[i] == 0:
+                break
+            i += step
+        last = i
+        # the records, while the walk is inside the slice
+        i, got, left = home, None, False
+        while True:
+            if not (max(lo, 0) <= i < min(hi, H)):
+                left = True
+                break
+            hl = 0 if b * S <= i < b * S + S else 1
+            if img_r[i] == r and staged[hl, down][i] == w:
+                got = i
+                break
+            if empty[hl, down][i]:
+                break
+            i += step
+        if left:
+            assert not (max(lo, 0) <= last < min(hi, H))           # ... only when the reference's walk leaves it too
+            continue
+        inside += 1
+        assert got == ref, (hex(key), home, ref, got)
+        in_halo += 1 if ref is not None and not (b * S <= ref < b * S + S) else 0
+        crossed_middle += 1 if ref is not None and (ref >> (lgH - 1)) != (home >> (lgH - 1)) else 0
+    assert inside > 0.6 * len(probes) and in_halo > 0      # (at 93 % fill a tenth of the walks outrun a 32-slot halo)
+    if fill >= 0.9:
+        assert crossed_middle > 0
+
+
 def test_partition_buffer_layouts_are_one_to_one():
     """slot_of (qm2_device.hip.h): the child-major and the segmented [segment][region] layout of a partition
     level's buffer each map (region, k-mer index) one-to-one onto the buffer's slots, and in the segmented one
