@@ -14,6 +14,11 @@
  *   split_text_kernel   text -> canonical k-mers, scattered into 2^b1 level-1 buckets
  *   split_kmer_kernel   level l-1 bucket -> its 2^bl children          (0..2 times)
  *   bucket_count_kernel finest bucket + table slice -> counters
+ *   table_image_kernel  once per key table: every slot as a bucket record, what bucket_count streams
+ *
+ * The finest level and the table slices are in RECORD form (qm2_device.hip.h, "bucket records"): 6 bytes per k-mer /
+ * slot at hg38 scale instead of 8, with the home slot inside the bucket in the clear — whichever split writes the
+ * finest level makes the records (it has the hash in hand), bucket_count compares records and hashes nothing.
  *   probe_kernel        (direct path) for the rare spill: k-mers that do not fit their
  *                       bucket (skewed input, e.g. poly-A)
  *   count_kernel        (direct path) recount of the whole batch, decided on the device,
