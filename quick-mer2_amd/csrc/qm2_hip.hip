@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -258,11 +259,21 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
     for (int l = 0; l < p.levels; l++) { p.cursor_off[l] = p.n_cursors; p.n_cursors += l == 0 && p.ext0 ? 0 : p.buckets[l] * (l == 0 ? p.subs0 : 1u); }
     p.spill_cap = std::min<uint64_t>((uint64_t)want_kmers / 4 + 4096, 0xFFFFFFFFull);  /* 2 B of HBM per input byte; places are 32-bit in sort_chunk's announcements */
     hipError_t e = hipSuccess;
+    /* (QM2_TIMING: what each allocation took — tens of GB of hipMalloc are the driver's time, seconds on some boxes) */
+    const bool timing = getenv("QM2_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = now();
+    auto lap = [&](const char *what, double gb) {
+        const double t = now();
+        if (timing) printf("QM2 prepare: %s %.1f GB in %.3f s\n", what, gb, t - t_last);
+        t_last = t;
+    };
     for (int i = 0; i < 2 && e == hipSuccess; i++)
-        if (p.buf_slots[i]) { e = hipMalloc((void **)&p.buf[i], p.buf_slots[i] * sizeof(uint64_t)); c->n_allocations++; }
+        if (p.buf_slots[i]) { e = hipMalloc((void **)&p.buf[i], p.buf_slots[i] * sizeof(uint64_t)); c->n_allocations++; lap("partition buffer", p.buf_slots[i] * 8e-9); }
     if (e == hipSuccess) e = hipMalloc((void **)&p.cursors, p.n_cursors * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p.spill, p.spill_cap * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc((void **)&p.spill_count, sizeof(unsigned long long));
+    lap("cursors + spill list", p.spill_cap * 8e-9);
     if (e == hipSuccess && !c->interior16) {
         /* the 2-byte counters of the bucket interiors (qm2_ctx.h): once per context, they outlive a re-plan */
         const uint64_t n_slots = c->span_hi - c->span_lo;
@@ -271,6 +282,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess && c->interior16) { (void)hipFree(c->interior16); c->interior16 = nullptr; }
         c->n_allocations++;
+        lap("interior counters (cleared)", n_slots * 2e-9);
     }
     if (e == hipSuccess && !c->img_r) {
         /* the table image (qm2_ctx.h): once per context as well; filled behind the look at the runs (runs_fit) */
@@ -283,6 +295,7 @@ static int part_reserve(qm2_ctx *c, uint64_t n)
         }
         c->img_ready = false;
         c->n_allocations += 2;
+        lap("table image", n_slots * (double)c->rec_bytes * 1e-9);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
