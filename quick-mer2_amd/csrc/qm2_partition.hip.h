@@ -573,8 +573,8 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
  *                buffer, and flush the counter tile of the previous bucket;
  *   waves 4..15  PROBERS: probe the current bucket's k-mers against the current buffer.
  * One workgroup barrier per bucket: behind barrier k the probers are done with bucket k-1 and the
- * loaders have staged bucket k.  A loader thread flushes exactly the counter slots it later stages,
- * so flush (k-1) -> stage (k+1) into the same buffer needs no second barrier.
+ * loaders have staged bucket k.  A loader thread flushes exactly the LDS quads it later stages — whichever
+ * way the two buckets walk: slice_quad — so flush (k-1) -> stage (k+1) into the same buffer needs no second barrier.
  *
  * Probing is cheap per step but DIVERGENT as a per-lane loop (at 53 % fill a k-mer needs 1.75 slots
  * on average, the slowest of a wave's 64 lanes ~12).  So:
@@ -682,6 +682,13 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
         g.int_len = sh ? 0u : (uint32_t)S - 2u * kHalo;
         return g;
     };
+    /* The slice quad (4 slots) that LDS quad q holds: the same one, or — the slice of a bucket that walks down is staged
+     * mirrored — the one as far from the slice's end.  The thread <-> LDS quad assignment of fetch / stage / flush never
+     * depends on the bucket, so a thread only ever stages over counter slots it has flushed itself: with the mapping taken
+     * on the LDS side instead (until round 4) the two buckets either side of the table's middle — one walks up, the next
+     * one of the same buffer down — had thread A staging over a quad that thread B had not flushed yet, unless the loader
+     * waves happened to run in step. */
+    auto slice_quad = [](const Geo &g, uint32_t q) { return g.down ? g.seg / 4u - 1u - q : q; };
     auto fill_of = [&](uint32_t b) {
         uint32_t n = b < n_buckets ? cursors[b] : 0;
         return n > cap ? cap : n;
@@ -705,15 +712,18 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
             const u32x2 *cp2 = reinterpret_cast<const u32x2 *>(tv.interior16 + (g.seg_lo - tv.span_lo));
 #pragma unroll
             for (int st = 0; st < kSteps; st++) {
+                /* LDS quad i4 (positions 4 i4 .. 4 i4 + 3) is this thread's in EVERY bucket; a bucket that walks down is staged
+                 * mirrored, so there the quad holds the slice's quad seg / 4 - 1 - i4, reversed (slice_quad) */
                 const uint32_t i4 = tid + st * kLoaderThreads;
                 const bool in = 4 * i4 < g.seg;
-                rv[st] = in ? rp[i4] : u32x4{0, 0, 0, 0};
-                if constexpr (W16) wv[st] = in ? wp[i4] : wvec{0, 0};
-                else               wv[st] = in ? wp[i4] : wvec{0, 0, 0, 0};
-                ov[st] = 4 * i4 - g.int_lo < g.int_len ? cp2[i4] : u32x2{0, 0};
+                const uint32_t gq = slice_quad(g, i4);
+                rv[st] = in ? rp[gq] : u32x4{0, 0, 0, 0};
+                if constexpr (W16) wv[st] = in ? wp[gq] : wvec{0, 0};
+                else               wv[st] = in ? wp[gq] : wvec{0, 0, 0, 0};
+                ov[st] = in && 4 * gq - g.int_lo < g.int_len ? cp2[gq] : u32x2{0, 0};
             }
         };
-        /* registers -> LDS buffer `bf`: records, fingerprints, counter tile; mirrored when the bucket walks down */
+        /* registers -> LDS buffer `bf`: records, fingerprints, counter tile (fetch has already taken the mirror image of a bucket that walks down) */
         auto stage = [&](uint32_t b, int bf) {
             const Geo g = geo(b);
             /* the code a key that a k-mer of THIS bucket can equal carries in the image: 0 in the bucket's own slots,
@@ -721,9 +731,9 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
             const uint32_t own_from = g.down ? g.seg - (uint32_t)S : 0u;          /* own slots: [own_from, own_from + S) */
 #pragma unroll
             for (int st = 0; st < kSteps; st++) {
-                const uint32_t i = 4u * (tid + st * kLoaderThreads);
+                const uint32_t i = 4u * (tid + st * kLoaderThreads);          /* LDS position */
                 if (i < g.seg) {
-                    const bool halo = i - own_from >= (uint32_t)S;
+                    const bool halo = 4u * slice_quad(g, i >> 2) - own_from >= (uint32_t)S;
                     uint32_t w[4];
                     if constexpr (W16) { w[0] = wv[st].x & 0xFFFFu; w[1] = wv[st].x >> 16; w[2] = wv[st].y & 0xFFFFu; w[3] = wv[st].y >> 16; }
                     else               { w[0] = wv[st].x; w[1] = wv[st].y; w[2] = wv[st].z; w[3] = wv[st].w; }
@@ -734,21 +744,19 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
                         w[j] = rec_staged_w(w[j], halo, g.down, LG_S);
                         f[j] = rec_staged_empty(w[j], LG_S) ? 0u : fp8(r[j]);
                     }
-                    if (g.down) {
-                        const uint32_t m = g.seg - 4u - i;                 /* slots i+3 .. i land at m .. m+3 */
-                        *reinterpret_cast<u32x4 *>(&skey[bf][m]) = u32x4{r[3], w[3], r[2], w[2]};
-                        *reinterpret_cast<u32x4 *>(&skey[bf][m + 2]) = u32x4{r[1], w[1], r[0], w[0]};
-                        sfp[bf][m >> 2] = f[3] | (f[2] << 8) | (f[1] << 16) | (f[0] << 24);
+                    if (g.down) {                                              /* (the slice quad's slots 3 .. 0 at i .. i + 3) */
+                        *reinterpret_cast<u32x4 *>(&skey[bf][i]) = u32x4{r[3], w[3], r[2], w[2]};
+                        *reinterpret_cast<u32x4 *>(&skey[bf][i + 2]) = u32x4{r[1], w[1], r[0], w[0]};
+                        sfp[bf][i >> 2] = f[3] | (f[2] << 8) | (f[1] << 16) | (f[0] << 24);
                     } else {
                         *reinterpret_cast<u32x4 *>(&skey[bf][i]) = u32x4{r[0], w[0], r[1], w[1]};
                         *reinterpret_cast<u32x4 *>(&skey[bf][i + 2]) = u32x4{r[2], w[2], r[3], w[3]};
                         sfp[bf][i >> 2] = f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24);
                     }
                     const u32x4 o = u32x4{ov[st].x & 0xFFFFu, ov[st].x >> 16, ov[st].y & 0xFFFFu, ov[st].y >> 16};
-                    if (g.down) *reinterpret_cast<u32x4 *>(&scnt[bf][g.seg - 4u - i]) = u32x4{o.w, o.z, o.y, o.x};
-                    else        *reinterpret_cast<u32x4 *>(&scnt[bf][i]) = o;
+                    *reinterpret_cast<u32x4 *>(&scnt[bf][i]) = g.down ? u32x4{o.w, o.z, o.y, o.x} : o;
                 } else if (i < (uint32_t)kSeg + 16u) {
-                    sfp[bf][i >> 2] = kFpPad * 0x01010101u;                /* beyond the slice (positions, not mirrored) */
+                    sfp[bf][i >> 2] = kFpPad * 0x01010101u;                /* beyond the slice */
                 }
             }
         };
@@ -760,15 +768,11 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
             uint16_t *const cp16 = tv.interior16 + (g.seg_lo - tv.span_lo);
 #pragma unroll
             for (int st = 0; st < kSteps; st++) {
-                const uint32_t i = 4u * (tid + st * kLoaderThreads);
-                if (i < g.seg) {
-                    u32x4 cv;
-                    if (g.down) {
-                        const u32x4 r = *reinterpret_cast<const u32x4 *>(&scnt[bf][g.seg - 4u - i]);
-                        cv = u32x4{r.w, r.z, r.y, r.x};
-                    } else {
-                        cv = *reinterpret_cast<const u32x4 *>(&scnt[bf][i]);
-                    }
+                const uint32_t lp = 4u * (tid + st * kLoaderThreads);         /* LDS position: the quad this thread staged */
+                if (lp < g.seg) {
+                    const uint32_t i = 4u * slice_quad(g, lp >> 2);             /* ... and where it lies in the slice */
+                    u32x4 cv = *reinterpret_cast<const u32x4 *>(&scnt[bf][lp]);
+                    if (g.down) cv = u32x4{cv.w, cv.z, cv.y, cv.x};
                     if (i - g.int_lo < g.int_len) {
                         /* private interior: the low halves go back where they came from; what has outgrown 16 bits (a
                          * k-mer seen more than 65535 times: :291 wraps there, this keeps counting) moves to the wide array */
