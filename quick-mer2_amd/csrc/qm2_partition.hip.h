@@ -801,6 +801,12 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
 #endif
         uint32_t k = 0;
         for (; b < n_buckets; b += stride, k++) {
+#ifdef QM2_TEST_LOADER_SKEW
+            /* test build only (tests/test_gpu_parity.py::test_loader_waves_out_of_step): the last loader wave runs ~27 us
+             * late, so that the others have staged the bucket after next before it flushes the one before — which must
+             * not matter (slice_quad) */
+            if (wave == kLoaderWaves - 1) for (int z = 0; z < QM2_TEST_LOADER_SKEW; z++) __builtin_amdgcn_s_sleep(127);
+#endif
             if (k) flush(b - stride, (int)((k + 1u) & 1u));       /* bucket k-1: the probers left it at barrier k */
             QM2_STAMP(0);
 #ifdef QM2_STAMPS

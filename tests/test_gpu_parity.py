@@ -5,6 +5,7 @@ import hashlib
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -1331,6 +1332,54 @@ def test_entry_points_mixed_on_one_context_replan(qm2, torch_cuda, tmp_path):
         assert prof["partitioned_batches"] == n and prof["fallback_batches"] == 0 and prof["spilled_kmers"] == 0, (order, prof)
         assert st["n_hits"] == n * exp_st["n_hits"] and st["n_probes"] == n * exp_st["n_probes"], order
         assert np.array_equal(d.astype(np.uint32), (n * exp_depth.astype(np.uint32)) & 0xFFFF), order
+
+
+def test_loader_waves_out_of_step(torch_cuda, tmp_path):
+    """bucket_count's loader waves flush bucket k - 1 and stage bucket k + 1 into the same LDS buffer with no barrier in
+    between; that is only right while a thread stages over nothing but what it has flushed itself, WHICHEVER way the two
+    buckets walk (the slice of a bucket that walks down is staged mirrored: qm2_partition.hip.h, slice_quad).  A build in
+    which the last loader wave runs late (-DQM2_TEST_LOADER_SKEW) makes the other waves stage before it flushes — at the
+    table's middle the assignment by slice position that the kernel had until round 4 then corrupted the counts of the
+    buckets in front of it (448 032 slots of this very workload with round 3's kernel built the same way,
+    tools/history/r4/skew_old_kernel.py; by chance once before, with two processes on the GPU).  The skewed build must equal the direct kernel slot for slot on a table whose
+    workgroups each cross the middle."""
+    torch = torch_cuda
+    pkg = os.path.join(ROOT, "quick-mer2_amd")
+    lib = str(tmp_path / "libqm2_skew.so")
+    src = [os.path.join(pkg, "csrc", f) for f in ("qm2_hip.hip", "qm2_tools.hip", "qm2_epilogue.hip", "qm2_io.hip")]
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function",
+                    "-DQM2_TEST_LOADER_SKEW=8", "-shared", "-o", lib] + src + ["-pthread"], check=True, cwd=pkg)
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import pyqm2 as qm2
+n, H, k = 6_000_000, 1 << 23, 30                  # 2048 finest buckets: every one of 256 workgroups takes 8, 4 either side of the middle
+genome = torch.zeros(n, dtype=torch.uint8, device="cuda")
+qm2.tools.genome_generate(genome.data_ptr(), n, seed=5, n_blocks=[], dups=[])
+keys = torch.zeros(H, dtype=torch.int64, device="cuda")
+scratch = torch.zeros(H, dtype=torch.int64, device="cuda")
+nd, nu = qm2.tools.dict_build(genome.data_ptr(), n, k, keys.data_ptr(), H, scratch.data_ptr())
+n_reads, rl = 400_000, 150
+reads = torch.zeros(n_reads * (rl + 1), dtype=torch.uint8, device="cuda")
+qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, n_reads, 0, rl, rl, 5)
+torch.cuda.synchronize()
+out = {}
+for name, flags in (("direct", qm2.FLAG_DIRECT), ("partition", qm2.FLAG_PARTITION)):
+    with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), flags=flags) as c:
+        for _ in range(3):                        # (three batches: the counter tile starts from earlier counts)
+            c.submit_device(reads.data_ptr(), reads.numel())
+        d, st = c.finish()
+        prof = c.profile()
+    out[name] = (d, st, prof)
+assert out["partition"][2]["partitioned_batches"] == 3 and out["direct"][2]["partitioned_batches"] == 0
+assert out["partition"][1] == out["direct"][1], (out["partition"][1], out["direct"][1])
+bad = np.flatnonzero(out["partition"][0] != out["direct"][0])
+assert len(bad) == 0, (len(bad), bad[:8], bad[:8] >> 12)
+assert int(out["direct"][0].astype(np.int64).sum()) %% 65536 >= 0 and nu > 1_000_000
+print("SKEW_OK", len(out["direct"][0]), int(out["direct"][1]["n_hits"]))
+""" % pkg
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, QM2_LIB=lib), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SKEW_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
 def test_bench_replicas_two_ranks_on_one_gpu(torch_cuda, tmp_path):
