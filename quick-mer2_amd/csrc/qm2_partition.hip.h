@@ -78,9 +78,27 @@ constexpr int kCountThreads  = QM2_COUNT_THREADS;
  * a cursor reservation and the previous chunk's copy-out stores in flight ACROSS their
  * barriers, so only the LDS traffic is waited for here.  (The compiler still inserts the vmcnt
  * wait in front of the first use of each loaded value.) */
+/* Test build only (-DQM2_TEST_CHAOS=n, tests/test_gpu_parity.py::test_waves_far_out_of_step): every wave idles a
+ * pseudo-random 0 .. 15 x n x 64 cycles at every workgroup barrier and between the phases in between, differently at
+ * every visit.  Nothing in these kernels may depend on waves running in step — only on the barriers. */
+#ifdef QM2_TEST_CHAOS
+__device__ __forceinline__ void chaos(uint32_t site)
+{
+    static __device__ unsigned int visit;                         /* (any changing number will do: racy on purpose) */
+    const uint32_t v = __builtin_amdgcn_readfirstlane((int)(visit++));
+    const uint32_t w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const uint32_t x = (((w + 1u) * 2654435761u) ^ ((site + 1u) * 40503u) ^ (v * 2246822519u)) >> 28;
+    for (uint32_t i = 0; i < x * (uint32_t)QM2_TEST_CHAOS; i++) __builtin_amdgcn_s_sleep(1);
+}
+#define QM2_CHAOS(S) chaos(S)
+#else
+#define QM2_CHAOS(S) do { } while (0)
+#endif
 __device__ __forceinline__ void lds_barrier()
 {
+    QM2_CHAOS(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    QM2_CHAOS(1);
 }
 
 /* Diagnostic build only (-DQM2_STAMPS, tools/stamps.sh): s_memtime brackets around the phases of
@@ -252,6 +270,7 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
     }
     lds_barrier();
     QM2_SORT_STAMP(23);
+    QM2_CHAOS(6);
 #pragma unroll
     for (int j = 0; j < kKpt; j++) {
         /* empty slots carry child id kMaxFan: they land behind the chunk's last k-mer, no branch */
@@ -266,6 +285,7 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
         QM2_STAMP(25);
     }
 #endif
+    QM2_CHAOS(7);
     uint32_t f[C];
 #pragma unroll
     for (int i = 0; i < C; i++) {
@@ -807,13 +827,16 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
              * not matter (slice_quad) */
             if (wave == kLoaderWaves - 1) for (int z = 0; z < QM2_TEST_LOADER_SKEW; z++) __builtin_amdgcn_s_sleep(127);
 #endif
+            QM2_CHAOS(2);
             if (k) flush(b - stride, (int)((k + 1u) & 1u));       /* bucket k-1: the probers left it at barrier k */
+            QM2_CHAOS(3);
             QM2_STAMP(0);
 #ifdef QM2_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             QM2_STAMP(10);
 #endif
             if (b + stride < n_buckets) stage(b + stride, (int)((k + 1u) & 1u));
+            QM2_CHAOS(4);
             QM2_STAMP(1);
             fetch(b + 2u * stride);
             QM2_STAMP(2);
@@ -1104,6 +1127,7 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
             base += kGroupKmers;
         }
         /* ---- phase B: this wave's unresolved k-mers, dense rows, once per bucket ---- */
+        QM2_CHAOS(5);
         {
             const uint32_t qn = queued < (uint32_t)kQueueCap ? queued : (uint32_t)kQueueCap;
             for (uint32_t e = lane; e < qn; e += kWave) walk(qk[pw][e], qa[pw][e]);

@@ -1382,6 +1382,57 @@ print("SKEW_OK", len(out["direct"][0]), int(out["direct"][1]["n_hits"]))
     assert r.returncode == 0 and "SKEW_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
+def test_waves_far_out_of_step(torch_cuda, tmp_path):
+    """The partitioned pipeline with every wave idling a pseudo-random time at every workgroup barrier and between the
+    phases in between (-DQM2_TEST_CHAOS): the kernels may rely on their barriers, never on waves running in step.  Both
+    table sizes of the record formats (2- and 4-byte second words need 2^30 and fewer slots), a table whose workgroups
+    cross the middle, a skewed stream that goes through the spill list: all equal to the direct kernel slot for slot."""
+    pkg = os.path.join(ROOT, "quick-mer2_amd")
+    lib = str(tmp_path / "libqm2_chaos.so")
+    src = [os.path.join(pkg, "csrc", f) for f in ("qm2_hip.hip", "qm2_tools.hip", "qm2_epilogue.hip", "qm2_io.hip")]
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function",
+                    "-DQM2_TEST_CHAOS=6", "-shared", "-o", lib] + src + ["-pthread"], check=True, cwd=pkg)
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import pyqm2 as qm2
+def case(n, lgH, n_reads, seed, poly=0):
+    H, k, rl = 1 << lgH, 30, 150
+    genome = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    qm2.tools.genome_generate(genome.data_ptr(), n, seed=seed, n_blocks=[], dups=[])
+    keys = torch.zeros(H, dtype=torch.int64, device="cuda")
+    scratch = torch.zeros(H, dtype=torch.int64, device="cuda")
+    qm2.tools.dict_build(genome.data_ptr(), n, k, keys.data_ptr(), H, scratch.data_ptr())
+    del scratch
+    reads = torch.zeros(n_reads * (rl + 1), dtype=torch.uint8, device="cuda")
+    qm2.tools.reads_generate(genome.data_ptr(), n, reads.data_ptr(), None, n_reads, 0, rl, rl, seed)
+    if poly:                                  # a flood of one k-mer: the first `poly` reads become poly-A lines
+        v = reads.view(n_reads, rl + 1)
+        v[:poly, :rl] = ord("A")
+    torch.cuda.synchronize()
+    res = {}
+    for name, flags in (("direct", qm2.FLAG_DIRECT), ("partition", qm2.FLAG_PARTITION)):
+        with qm2.Counter(None, hash_size=H, k=k, ext_keys=keys.data_ptr(), flags=flags) as c:
+            for _ in range(2):
+                c.submit_device(reads.data_ptr(), reads.numel())
+            d, st = c.finish()
+            prof = c.profile()
+        res[name] = (d, st, prof)
+    assert res["partition"][2]["partitioned_batches"] == 2 and res["partition"][2]["fallback_batches"] == 0
+    assert res["partition"][1] == res["direct"][1], (lgH, res["partition"][1], res["direct"][1])
+    bad = np.flatnonzero(res["partition"][0] != res["direct"][0])
+    assert len(bad) == 0, (lgH, len(bad), bad[:8])
+    return res["partition"][2]["spilled_kmers"]
+assert case(6_000_000, 23, 300_000, 5) == 0
+assert case(6_000_000, 23, 300_000, 6, poly=20_000) > 0
+assert case(1_500_000, 21, 100_000, 7) == 0
+assert case(6_000_000, 30, 300_000, 8) == 0          # (2-byte second words: 2^30 slots)
+print("CHAOS_OK")
+""" % pkg
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, QM2_LIB=lib), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "CHAOS_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 def test_bench_replicas_two_ranks_on_one_gpu(torch_cuda, tmp_path):
     """bench.py's N > 1 replica path with TWO ranks (both on this card, collectives over gloo: QM2_REHEARSE_ON_ONE_GPU):
     every rank must complete its counters (fold the 2-byte bucket interiors: qm2_finish) BEFORE the job's one reduce,
