@@ -157,7 +157,7 @@ static void part_init(qm2_ctx *c, int max_bits, int first_bits = 0)
     /* the finest level and the table image hold bucket records (qm2_device.hip.h): 6 bytes when the hash bits a bucket
      * does not imply fit 16 bits beside the slot and the two code bits (hg38 scale: H = 2^32), else 8 */
     const uint32_t ext = rec_ext_bits(c->k, c->lgH);
-    if ((uint32_t)kLgS + 2u + ext > 32u) return;      /* (k = 31 with fewer than 2^16 slots: the direct kernel) */
+    if ((uint32_t)kLgS + 2u + ext > 32u) return;      /* (fewer than 2^14 slots, 2^16 at k = 31: the direct kernel) */
     c->rec_bytes = (uint32_t)kLgS + 2u + ext <= 16u ? 6u : 8u;
     if (first_bits) {
         if (nb - first_bits < 1) return;                             /* nothing left to split behind the given level */
@@ -594,7 +594,7 @@ static int runs_fit(qm2_ctx *c, bool *ok)
 }
 
 /* Fill the table image (qm2_ctx.h) once the keys are there and part_reserve has made room for it: stream-ordered in front
- * of every bucket_count launch, a 56-GB pass at hg38 scale (~15 ms), once per context. */
+ * of every bucket_count launch, a 56-GB pass at hg38 scale (11 ms), once per context. */
 static int table_image(qm2_ctx *c)
 {
     std::lock_guard<std::mutex> guard(c->runs_mu);
