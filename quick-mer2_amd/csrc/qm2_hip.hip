@@ -470,25 +470,24 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
         /* (before the first snapshot has landed: the caller's hint, against the part of the bytes that can be sequence) */
         const double kpb = c->peek_bytes ? c->kmers_per_byte : c->kappa_hint * (double)src.n_upper / (double)std::max<uint64_t>(src.n_bytes, 1);
         const uint64_t per_bucket = (uint64_t)((double)src.n_bytes * (src.sv ? kpb : 1.0 / 1.3)) / n_buckets;
-        int g = 4, lw = 3;
+        int g = 4;
+        constexpr int lw = 4;
         {
-            /* loader waves (3 or 4 of the 16) and group size: the fewest rows of 2 k-mers per prober thread that
-             * take a bucket's fill; ties: 4 loader waves, the larger group */
+            /* group size: the fewest rows of 2 k-mers per prober thread that take a bucket's fill; ties: the larger group.
+             * (Loader waves: 4 of the 16.  Until round 4 a launch chose between 3 and 4 — round 2: 22.0 vs 24.4 ms at 40 M
+             * reads per launch; with the table image the three-wave loader chain is the longer one at every fill: 40 M reads
+             * 22.1 vs 21.4 ms, 20 M 18.5 vs 15.7, 60 M 25.3 vs 23.5 — profiles/r04_c3/batch_sizes.txt.) */
             const double fill = (double)per_bucket + 3.0 * std::sqrt((double)per_bucket + 1.0);
+            const int prober_threads = kCountThreads - lw * kWave;
+            const int rows = std::max(1, (int)std::ceil(fill / (2.0 * prober_threads)));
             int best_rows = 1 << 30;
-            for (int cand_lw = 3; cand_lw <= 4; cand_lw++) {
-                const int prober_threads = kCountThreads - cand_lw * kWave;
-                const int rows = std::max(1, (int)std::ceil(fill / (2.0 * prober_threads)));
-                for (int cand = 2; cand <= 6; cand++) {
-                    const int run = (rows + cand - 1) / cand * cand;           /* rows executed */
-                    if (run <= best_rows) { best_rows = run; g = cand; lw = cand_lw; }
-                }
+            for (int cand = 2; cand <= 6; cand++) {
+                const int run = (rows + cand - 1) / cand * cand;           /* rows executed */
+                if (run <= best_rows) { best_rows = run; g = cand; }
             }
         }
-        {   /* (experiments: force the loader waves / the group size) */
-            static const int env_lw = getenv("QM2_COUNT_LW") ? atoi(getenv("QM2_COUNT_LW")) : 0;
+        {   /* (experiments: force the group size) */
             static const int env_g = getenv("QM2_COUNT_G") ? atoi(getenv("QM2_COUNT_G")) : 0;
-            if (env_lw == 3 || env_lw == 4) lw = env_lw;
             if (env_g >= 2 && env_g <= 6) g = env_g;
         }
         const CountGeo cg = {c->own_lo, c->span_lo, c->span_hi, c->H >> 1};
@@ -497,8 +496,7 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
                            (const uint32_t *)fin_r, (const WT_ *)fin_w_at, p.cursors + p.cursor_off[L], p.cap[L], table_view(c), cg, n_buckets, \
                            p.shared, c->stats)
 #define QM2_LAUNCH_COUNT_LW(G_) do {                                                                            \
-            if (fin_w == 2) { if (lw == 3) QM2_LAUNCH_COUNT(G_, 3, uint16_t); else QM2_LAUNCH_COUNT(G_, 4, uint16_t); }  \
-            else            { if (lw == 3) QM2_LAUNCH_COUNT(G_, 3, uint32_t); else QM2_LAUNCH_COUNT(G_, 4, uint32_t); }  \
+            if (fin_w == 2) QM2_LAUNCH_COUNT(G_, lw, uint16_t); else QM2_LAUNCH_COUNT(G_, lw, uint32_t);        \
         } while (0)
         switch (g) {
             case 2: QM2_LAUNCH_COUNT_LW(2); break;

@@ -646,9 +646,9 @@ __global__ void table_image_kernel(const uint64_t *keys, uint64_t n_slots, uint6
     }
 }
 
-/* LW loader waves (3 or 4; the rest of the 16 probe): chosen per launch so that a bucket's fill takes the fewest
- * rows of 2 k-mers per prober thread — measured at C3: 50 M reads per launch 24.5 (3) vs 23.5 ms (4), 40 M reads
- * 22.0 vs 24.4; 2 loader waves: 51 ms (their prefetch registers spill).
+/* LW loader waves, the rest of the 16 probe: 4 (round 2 chose 3 or 4 per launch — 40 M reads per launch 22.0 vs 24.4 ms,
+ * 50 M 24.5 vs 23.5; with the table image 4 is the faster at every fill, qm2_hip.hip; 2 loader waves: 51 ms, their
+ * prefetch registers spill).
  * WT: uint16_t / uint32_t, the width of the records' second word (k-mers and table image alike). */
 template <int LG_S, int G2, int LW, typename WT>
 __global__ __launch_bounds__(kCountThreads)
