@@ -92,6 +92,10 @@ with open(os.path.join(reads_dir, "reads.fq"), "wb") as fq, open(os.path.join(re
 print("wrote %d reads (fq %.1f GB) in %.1f s" % (n_reads, os.path.getsize(os.path.join(reads_dir, "reads.fq")) / 1e9, time.time() - t), flush=True)
 del genome
 torch.cuda.empty_cache()
+# This process has just freed > 100 GB of device memory.  QM2_E2E_SETTLE=<seconds>: wait before the first CLI run, to tell the
+# driver's clearing of that memory (which the next process's hipMalloc waits for) from the CLI's own load phase.
+if os.environ.get("QM2_E2E_SETTLE"):
+    time.sleep(float(os.environ["QM2_E2E_SETTLE"]))
 cli = os.environ.get("QM2_E2E_CLI") or os.path.join(ROOT, "quick-mer2_amd", "quicKmer2")
 runs = [(f, t, e) for f in ("reads.fq", "reads.fa")
         for t, e in (("4", {}), ("8", {}), ("12", {}), ("8", {"QM2_READER_RAW": "0"}), ("4", {"QM2_READER_RAW": "0", "QM2_READER_STREAM": "1"}))]
