@@ -75,12 +75,17 @@ static int out_commit_raw(void *user, char *buf, size_t offset, size_t n, int fa
     return qm2_raw_verdict((qm2_ctx *)user) ? 2 : 0;       /* refused: no point in reading on */
 }
 
-/* the context's default device batch: 1.5 bytes per table slot, 1..6 GiB (qm2_open) */
+/* The CLI's device batch: 1.5 bytes per table slot, 1..2 GiB.  (The library's own default goes up to 6 GiB, which is what
+ * the kernels like best: 95 instead of 50-75 G bases/s at hg38 scale.  But the CLI is fed over PCIe at 23 G bases/s of FASTQ or
+ * 45 of FASTA, which 2 GiB batches still outrun, and every byte of batch costs ~11-20 bytes of partition scratch:
+ * with 6 GiB batches a run takes 170 GB of device memory and the driver stalls 3-4 s in one of the allocations in four
+ * runs out of five (load phase 2.1-4.9 s); with 2 GiB it takes 125 GB and never did (1.0-1.2 s) — whole run at hg38 scale,
+ * 100 M reads: 6.5-8.1 s -> 3.5-4.1 s.  profiles/r04_c3/cli_batch_bytes.txt) */
 static uint64_t default_batch_bytes(uint64_t hash_size)
 {
     uint64_t bb = hash_size + hash_size / 2;
     if (bb < (1ull << 30)) bb = 1ull << 30;
-    if (bb > (6ull << 30)) bb = 6ull << 30;
+    if (bb > (2ull << 30)) bb = 2ull << 30;
     return bb;
 }
 
@@ -175,6 +180,8 @@ static void *device_load_main(void *arg)
     o.flags = QM2_FLAG_KEYS_LATER | QM2_FLAG_RAW_STRICT;
     o.n_staging = (uint32_t)j->n_strip + 3;
     o.kmers_per_kib = j->kmers_per_kib;
+    o.batch_bytes = default_batch_bytes(j->d->hash_size);
+    if (getenv("QM2_BATCH_BYTES")) o.batch_bytes = strtoull(getenv("QM2_BATCH_BYTES"), NULL, 0);   /* (experiments) */
     j->rc = 1;
     if (qm2_open(&j->ctx, NULL, j->d->hash_size, j->d->k, &o)) return NULL;
     if (qm2_prepare(j->ctx, 0, j->what | QM2_PREPARE_NO_PART)) return NULL;
@@ -468,16 +475,16 @@ int qm2_main_count(int argc, char **argv)
     uint64_t in_size;
     sniff_input(reads, &regular, &fastq, &in_size);
     if (regular) o.kmers_per_kib = estimate_kmers_per_kib(reads, d.k, fastq);
+    /* The CLI's device batch (default_batch_bytes: 1.5 bytes per table slot, 1 to 2 GiB).  A regular file smaller
+     * than that gets one batch of its size: qm2_prepare then allocates (and the driver clears) a fraction of the
+     * partition scratch — 22 bytes per batch byte (11 for FASTQ text). */
+    o.batch_bytes = default_batch_bytes(d.hash_size);
     if (regular) {
-        /* A regular file smaller than the default device batch (1.5 bytes per table slot, up to 6 GiB): one
-         * batch of its size is enough, and qm2_prepare then allocates (and the driver clears) a fraction of the
-         * partition scratch — 22 bytes per batch byte (11 for FASTQ text), seconds of hipMalloc at the default
-         * against an hg38-scale table.  Pipes and larger files keep the default. */
-        const uint64_t deflt = default_batch_bytes(d.hash_size);
         uint64_t need = (in_size + (256ull << 20)) & ~((256ull << 20) - 1);
         if (need < (1ull << 30)) need = 1ull << 30;
-        if (need < deflt) o.batch_bytes = need;
+        if (need < o.batch_bytes) o.batch_bytes = need;
     }
+    if (getenv("QM2_BATCH_BYTES")) o.batch_bytes = strtoull(getenv("QM2_BATCH_BYTES"), NULL, 0);   /* (experiments) */
     clock_gettime(CLOCK_MONOTONIC, &ta);
     const char *raw_env = getenv("QM2_READER_RAW");
     const int want_raw = !(raw_env && strcmp(raw_env, "0") == 0);

@@ -127,6 +127,9 @@ for name, thr, extra in runs:
         m = re.search(r"QM2 phase count ([0-9.]+) s", out)
         sec = float(m.group(1)) if m else float("nan")
         best = sec if best is None else min(best, sec)
+        ld = re.search(r"QM2 phase load-dictionary ([0-9.]+) s", out)
+        ep = re.search(r"QM2 phase epilogue ([0-9.]+) s", out)
+        print("   rep %d: wall %.2f s = load %s + count %.3f + epilogue %s" % (rep, walls[-1], ld.group(1) if ld else "?", sec, ep.group(1) if ep else "?"), flush=True)
     nk = re.search(r"total (\d+) kmers", out)
     prog = re.findall(r"^Read (\d+)G kmers$", out, flags=re.M)
     al = re.search(r"allocations inside it: (\d+)", out)
