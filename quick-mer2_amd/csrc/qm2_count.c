@@ -79,7 +79,7 @@ static int out_commit_raw(void *user, char *buf, size_t offset, size_t n, int fa
  * the kernels like best: 95 instead of 50-75 G bases/s at hg38 scale.  But the CLI is fed over PCIe at 23 G bases/s of FASTQ or
  * 45 of FASTA, which 2 GiB batches still outrun, and every byte of batch costs ~11-20 bytes of partition scratch:
  * with 6 GiB batches a run takes 170 GB of device memory and the driver stalls 3-4 s in one of the allocations in four
- * runs out of five (load phase 2.1-4.9 s); with 2 GiB it takes 125 GB and never did (1.0-1.2 s) — whole run at hg38 scale,
+ * runs out of five (load phase 2.1-4.9 s); with 2 GiB it takes 125 GB and did not on two boxes (1.0-1.2 s; 1.1-2.5 s on a third) — whole run at hg38 scale,
  * 100 M reads: 6.5-8.1 s -> 3.5-4.1 s.  profiles/r04_c3/cli_batch_bytes.txt) */
 static uint64_t default_batch_bytes(uint64_t hash_size)
 {

@@ -12,6 +12,7 @@ n_kmers >> 30, and no allocation happens inside the count phase (qm2_prepare).""
 import os
 import re
 import subprocess
+import xxhash
 import sys
 import time
 
@@ -113,6 +114,7 @@ if os.environ.get("QM2_E2E_RUNS"):
         runs.append(("reads." + f[0], f[1], extra))
 reps = int(os.environ.get("QM2_E2E_REPS", reps))
 ok = True
+out_sums = {}
 for name, thr, extra in runs:
     best, walls = None, []
     extra = dict(extra)
@@ -130,6 +132,18 @@ for name, thr, extra in runs:
         ld = re.search(r"QM2 phase load-dictionary ([0-9.]+) s", out)
         ep = re.search(r"QM2 phase epilogue ([0-9.]+) s", out)
         print("   rep %d: wall %.2f s = load %s + count %.3f + epilogue %s" % (rep, walls[-1], ld.group(1) if ld else "?", sec, ep.group(1) if ep else "?"), flush=True)
+    # the outputs of every arrangement of the same input have to be the same bytes (.bin: the depth per dictionary k-mer, .txt: the GC curve)
+    sums = []
+    for suffix in (".bin", ".txt"):
+        h = xxhash.xxh3_128()
+        try:
+            with open(os.path.join(work, "out" + suffix), "rb") as fh:
+                for piece in iter(lambda: fh.read(1 << 26), b""):
+                    h.update(piece)
+            sums.append(h.hexdigest())
+        except OSError:
+            sums.append("missing")
+    out_sums.setdefault(name, []).append(tuple(sums))
     nk = re.search(r"total (\d+) kmers", out)
     prog = re.findall(r"^Read (\d+)G kmers$", out, flags=re.M)
     al = re.search(r"allocations inside it: (\d+)", out)
@@ -141,6 +155,10 @@ for name, thr, extra in runs:
           (name, thr, ("--devices %s " % devs) if devs else "", "host strip, read(2) stream" if "QM2_READER_STREAM" in extra else "host strip, pread blocks" if extra else "device line discipline",
            r.returncode, best, n_reads * 150 / best / 1e9, min(walls), len(prog), al.group(1) if al else "?", "" if good else "  <-- CHECK FAILED",
            load.group(0) if load else ""), flush=True)
+for name, got in out_sums.items():
+    same = len(set(got)) == 1 and "missing" not in got[0]
+    ok = ok and same
+    print("== %s: .bin and .txt of the %d arrangements above are the same bytes: %s (xxh3-128 %s / %s)" % (name, len(got), same, got[0][0], got[0][1]), flush=True)
 print(out)
 for d_ in {work, reads_dir}:
     shutil.rmtree(d_, ignore_errors=True)
