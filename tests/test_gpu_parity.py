@@ -1781,18 +1781,20 @@ def test_c3_scale_partitioned_equals_direct(qm2, torch_cuda, hg38_scale):
         _oracle_sample_equal(qm2, env, sample, flags)
 
 
-def test_c3_partitioned_equals_direct_at_the_cli_batch_geometry(qm2, torch_cuda, hg38_scale):
-    """The plan geometry the product really runs — the CLI's default device batch at hg38 scale, 6 GiB of
-    sequence lines = 42.6 M x 150 bp reads: 8192 level-1 sub-regions, 2^20 buckets, 58 + 64 + 13 GB of partition
-    buffers with more than 2^32 k-mer places — compared SLOT FOR SLOT with the direct kernel, which shares
-    nothing with the partitioned pipeline but the front end (every k-mer probed exactly once, QuicKmer.c:283-293).
-    The smaller C3 tests run plans an eighth of this size; bench.py makes the same comparison at its own batch
-    (50 M reads) through tools.checksum_u32, which is checked against torch here."""
+@pytest.mark.parametrize("batch_gib", [6, 2], ids=["library_default_6GiB", "cli_2GiB"])
+def test_c3_partitioned_equals_direct_at_the_cli_batch_geometry(qm2, torch_cuda, hg38_scale, batch_gib):
+    """The plan geometries the product really runs at hg38 scale — the library's default device batch, 6 GiB of
+    sequence lines = 42.6 M x 150 bp reads (8192 level-1 sub-regions, 2^20 buckets, 58 + 64 + 13 GB of partition
+    buffers with more than 2^32 k-mer places), and the 2 GiB batch the CLI asks for since round 4 (14.2 M reads: the
+    same buckets a third as full, another group shape in bucket_count) — compared SLOT FOR SLOT with the direct
+    kernel, which shares nothing with the partitioned pipeline but the front end (every k-mer probed exactly once,
+    QuicKmer.c:283-293).  The smaller C3 tests run plans an eighth of the large one; bench.py makes the same
+    comparison at its own batch (60 M reads) through tools.checksum_u32, which is checked against torch here."""
     torch, env = torch_cuda, hg38_scale
     H, k, keys, genome, n, rl = env["H"], env["k"], env["keys"], env["genome"], env["n"], env["rl"]
     free, _ = torch.cuda.mem_get_info()
-    batch_bytes = 6 << 30
-    if free < 190 * (1 << 30):
+    batch_bytes = batch_gib << 30
+    if free < (190 if batch_gib == 6 else 100) * (1 << 30):
         pytest.skip("needs ~190 GiB of free HBM (two counter arrays, a 6 GiB batch, 135 GB of partition buffers)")
     n_reads = batch_bytes // (rl + 1)
     reads = torch.empty(n_reads * (rl + 1), dtype=torch.uint8, device="cuda")
