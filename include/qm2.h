@@ -94,7 +94,10 @@ typedef struct {
                                  byte); input that yields more overflows into the spill list or is recounted by the
                                  direct kernel — exact either way */
     void    *ext_keys;        /* optional: device pointer to H x u64 keys that are
-                                 ALREADY resident (then `keys` may be NULL)      */
+                                 ALREADY resident (then `keys` may be NULL).  They
+                                 must not change while the context lives: the
+                                 context keeps a digest of the table (look at the
+                                 runs of occupied slots, table image) made once     */
     void    *ext_counters;    /* optional: device pointer to H x u32 counters
                                  owned by the caller (e.g. a tensor handed to
                                  RCCL for the replica reduce); zeroed by caller.
