@@ -490,11 +490,21 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
             static const int env_g = getenv("QM2_COUNT_G") ? atoi(getenv("QM2_COUNT_G")) : 0;
             if (env_g >= 2 && env_g <= 6) g = env_g;
         }
+        /* How long the loader waves hold back behind every barrier, in steps of 256 cycles (bucket_count_kernel): nothing
+         * while the loaders' chain (flush -> stage -> fetch) is the longer leg of a period — up to ~3000 k-mers per bucket —
+         * then growing with the probers' share.  C3, same box, 0 / 4 / 8 / 12 / 16 steps: 60 M reads per launch (8640 k-mers
+         * per bucket) 23.47 / 23.21 / 23.04 / 22.80 / 23.64 ms; 40 M (5760) 21.02 / 20.49 / 20.55 / 21.06 / 23.34; 20 M
+         * (2880) 15.74 / 16.20 / 17.78 / 19.32 / 21.24 (profiles/r04_c3/bucket_count_head_sleep.txt). */
+        uint32_t head_sleep = per_bucket > 3000 ? (uint32_t)std::min<uint64_t>((per_bucket - 3000) / 512, 12) : 0u;
+        {   /* (experiments: force it) */
+            static const int env_hs = getenv("QM2_COUNT_HEAD_SLEEP") ? atoi(getenv("QM2_COUNT_HEAD_SLEEP")) : -1;
+            if (env_hs >= 0) head_sleep = (uint32_t)std::min(env_hs, 64);
+        }
         const CountGeo cg = {c->own_lo, c->span_lo, c->span_hi, c->H >> 1};
 #define QM2_LAUNCH_COUNT(G_, LW_, WT_)                                                                          \
         hipLaunchKernelGGL((bucket_count_kernel<kLgS, G_, LW_, WT_>), dim3(grid), dim3(kCountThreads), 0, s,   \
                            (const uint32_t *)fin_r, (const WT_ *)fin_w_at, p.cursors + p.cursor_off[L], p.cap[L], table_view(c), cg, n_buckets, \
-                           p.shared, c->stats)
+                           p.shared, c->stats, head_sleep)
 #define QM2_LAUNCH_COUNT_LW(G_) do {                                                                            \
             if (fin_w == 2) QM2_LAUNCH_COUNT(G_, lw, uint16_t); else QM2_LAUNCH_COUNT(G_, lw, uint32_t);        \
         } while (0)

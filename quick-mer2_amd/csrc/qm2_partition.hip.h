@@ -653,7 +653,7 @@ __global__ void table_image_kernel(const uint64_t *keys, uint64_t n_slots, uint6
 template <int LG_S, int G2, int LW, typename WT>
 __global__ __launch_bounds__(kCountThreads)
 void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_t *cursors, uint32_t cap, TableView tv, CountGeo cg,
-                         uint32_t n_buckets_all, const uint32_t *shared, DevStats *stats)
+                         uint32_t n_buckets_all, const uint32_t *shared, DevStats *stats, uint32_t head_sleep)
 {
     if (stats->part_lost != 0) return;       /* this batch is recounted by the direct kernel */
     constexpr int kLoaderWaves = LW, kLoaderThreads = LW * kWave;
@@ -782,6 +782,9 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
         };
         /* counter tile of LDS buffer `bf` -> table */
         auto flush = [&](uint32_t b, int bf) {
+            /* (a memory round trip at the head of the loaders' chain of every period — and taking the fill from LDS instead,
+             * where the probers can leave it, made the kernel SLOWER, 23.6 -> 24.4 ms: the loaders are better off late, see
+             * head_sleep below) */
             if (fill_of(b) == 0) return;                 /* nothing was counted: the tile is what was loaded */
             const Geo g = geo(b);
             uint32_t *const cp = tv.counters + (g.seg_lo - tv.span_lo);
@@ -828,6 +831,10 @@ void bucket_count_kernel(const uint32_t *recs_r, const WT *recs_w, const uint32_
             if (wave == kLoaderWaves - 1) for (int z = 0; z < QM2_TEST_LOADER_SKEW; z++) __builtin_amdgcn_s_sleep(127);
 #endif
             QM2_CHAOS(2);
+            /* The loaders hold back at the head of a period (head_sleep x 256 cycles; the host picks it, launch_partitioned):
+             * their flush and stage are LDS traffic, and behind the barrier every prober wave starts its first probe set at
+             * once — while a loader chain that is shorter than the probers' period has the time to give. */
+            for (uint32_t z = 0; z < head_sleep; z++) __builtin_amdgcn_s_sleep(4);
             if (k) flush(b - stride, (int)((k + 1u) & 1u));       /* bucket k-1: the probers left it at barrier k */
             QM2_CHAOS(3);
             QM2_STAMP(0);
