@@ -819,6 +819,10 @@ def main():
                        if world > 1 else "1 GPU", "inputs": "resident in HBM (value); host-fed rates under `streamed`",
                        "setup_s": round(t_setup, 1),
                        "final_reduce_ms": round(reduce_ms, 2) if reduce_ms is not None else None,
+                       # the same steps with the job's one exchange charged to them in full (a 30x hg38 job is 10 such steps
+                       # per GPU at N = 1 and fewer at N > 1: the exchange is per job, `value` is per step)
+                       "bases_per_s_with_the_reduce_charged_to_these_steps":
+                           round(total_bases / (elapsed + reduce_ms / 1e3), 1) if reduce_ms is not None else None,
                        "fold_ms": round(fold_ms, 2),
                        "counts_conserved": counts_conserved, "spilled_kmers": prof1["spilled_kmers"] - prof0["spilled_kmers"]},
             "kernel_only_bases_per_s": roofline["kernel_only_bases_per_s"],
