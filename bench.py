@@ -412,8 +412,9 @@ def main():
     ap.add_argument("--no-streamed", action="store_true", help="skip the host-fed (PCIe-inclusive) regions")
     ap.add_argument("--no-geometry-check", action="store_true",
                     help="skip the partitioned-vs-direct comparison of all counters at the benchmarked batch geometry")
-    ap.add_argument("--streamed-steps", type=int, default=4)
-    ap.add_argument("--feed-threads", type=int, default=8, help="host threads that fill the staging buffers in the streamed regions")
+    ap.add_argument("--streamed-steps", type=int, default=4, help="steps of the ASCII host-fed regions; the packed ones take twice as many (the same seconds)")
+    ap.add_argument("--feed-threads", type=int, default=14, help="host threads that fill (and pack into) the staging buffers in the streamed regions")
+    ap.add_argument("--piece-mib", type=int, default=32, help="streamed regions: MiB of text a feeding thread packs at a time")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the -t 6 port sample")
     ap.add_argument("--ref-seconds", type=float, default=15.0, help="target counting time of the reference binary")
     ap.add_argument("--sweep-seconds", type=float, default=6.0, help="target CPU time of each other worker count")
@@ -720,7 +721,7 @@ def main():
         nb = 2
         hosts = [batches[i % n_batches][0].cpu().numpy() for i in range(nb)]
         sctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=mode_flag, ext_keys=keys.data_ptr(),
-                             n_staging=14)
+                             n_staging=max(14, args.feed_threads + 4))
         sctx.prepare(host=True, raw=True)
 
         def run(feed, steps):
@@ -753,13 +754,61 @@ def main():
             sctx.feed_host(h.ctypes.data, h.size, rl + 1, threads=args.feed_threads)
             return h.size
 
-        nbases, moved, sec, allocs, per_rank = run(feed_lines, args.streamed_steps)
+        # (1) PACKED (ABI 6, include/qm2.h "packed sequence"): the threads that fill the pinned buffers pack what they copy —
+        # the reset test and the 2-bit code of every character, QuicKmer.c:403-411, nothing more — so 0.375 bytes per base
+        # cross the link; this is what qm2_submit and the CLI's reader threads do by default
+        def feed_packed(i):
+            h = hosts[i % nb]
+            return sctx.feed_host_packed(h.ctypes.data, h.size, rl + 1, threads=args.feed_threads, piece_text=args.piece_mib << 20)
+
+        packed_steps = 2 * args.streamed_steps                 # (the drain of the last device batch is then < 10 % of the region, as in the ASCII one)
+        nbases, moved, sec, allocs, per_rank = run(feed_packed, packed_steps)
+        assert nbases == world * packed_steps * wl["reads"] * rl
         streamed = {"streamed_bases_per_s": round(nbases / sec, 1), "h2d_GBps": round(moved / sec / 1e9, 2),
                     "h2d_GBps_per_rank": per_rank, "ranks_feeding_concurrently": world,
-                    "steps": args.streamed_steps, "seconds": round(sec, 3), "allocations_inside": allocs,
-                    "feed": "%d host threads copy 64 MiB pieces into the pinned staging buffers (what the CLI's reader threads do "
-                            "with pread), one thread commits them in order; timed from the first commit to the return of qm2_finish"
-                            % args.feed_threads}
+                    "bytes_per_base_over_the_link": round(moved / max(1, nbases), 4),
+                    "steps": packed_steps, "seconds": round(sec, 3), "allocations_inside": allocs,
+                    "pack_isa": pyqm2.lib().qm2_pack_isa().decode(),
+                    "feed": "%d host threads pack 64 MiB staging buffers' worth of sequence lines from pageable memory (qm2_pack_lines: 2-bit codes + reset "
+                            "flags, what the CLI's reader threads do behind pread), one thread commits the pieces in order (qm2_staging_commit_packed); "
+                            "timed from the first commit to the return of qm2_finish" % args.feed_threads}
+        # ... and what the kernels make of packed input that is already in HBM (the ceiling of the figure above; `value` stays
+        # the ASCII-resident rate: there the device does the whole of QuicKmer.c:403-420)
+        if rank == 0:
+            blocks, pk, _ = pyqm2.pack_lines(memoryview(hosts[0]))
+            d_blocks = torch.from_numpy(blocks.view(np.int64)).to(dev)
+            del blocks
+            # (in pieces that fit the context's device batch, for which its partition buffers were made)
+            n_pieces = max(1, -(-64 * int(pk.n_blocks) // (5 << 30)))
+            per = -(-int(pk.n_blocks) // n_pieces)
+            pieces = [(a, min(per, int(pk.n_blocks) - a)) for a in range(0, int(pk.n_blocks), per)]
+            _, r0 = sctx.finish(want_depth=False)
+
+            def resident_pass():
+                for a, nblk in pieces:                    # (the line ends are taken off n_bases with the first piece: the totals are what counts)
+                    sctx.submit_packed_device(d_blocks.data_ptr() + 24 * a, pyqm2.Packed(nblk, int(pk.n_newlines) if a == 0 else 0, 0))
+
+            for _ in range(2):
+                resident_pass()
+            sctx.sync()
+            _, r0 = sctx.finish(want_depth=False)
+            pr0 = sctx.profile()
+            tA = time.perf_counter()
+            for _ in range(args.streamed_steps):
+                resident_pass()
+            sctx.sync()
+            sec_r = time.perf_counter() - tA
+            _, r1 = sctx.finish(want_depth=False)
+            pr1 = sctx.profile()
+            assert r1["n_bases"] - r0["n_bases"] == args.streamed_steps * wl["reads"] * rl
+            streamed["packed_resident_bases_per_s"] = round((r1["n_bases"] - r0["n_bases"]) / sec_r, 1)
+            streamed["packed_resident"] = {"pieces_per_step": len(pieces), "partitioned_batches": pr1["partitioned_batches"] - pr0["partitioned_batches"],
+                                           "direct_batches": pr1["direct_batches"] - pr0["direct_batches"]}
+            del d_blocks
+        # (2) the same lines as ASCII, 1 byte per base (QM2_FLAG_SUBMIT_ASCII / QM2_READER=lines; rounds 1-4's streamed figure)
+        nbases, moved, sec, allocs, per_rank = run(feed_lines, args.streamed_steps)
+        streamed.update({"streamed_ascii_bases_per_s": round(nbases / sec, 1), "ascii_h2d_GBps": round(moved / sec / 1e9, 2),
+                         "ascii_h2d_GBps_per_rank": per_rank, "ascii_allocations_inside": allocs})
         # the same reads as raw FASTQ text ("@r" / seq / "+" / qual: 2 x 151 + 5 bytes a record), line discipline on the device
         del hosts
         m = min(wl["reads"], 20_000_000)
@@ -778,7 +827,18 @@ def main():
             sctx.feed_host(fq.ctypes.data, fq.size, 2 * (rl + 1) + 5, raw=(True, 1), threads=args.feed_threads)
             return fq.size
 
+        # packed by the feeding threads, line discipline included (qm2_pack_reads: headers, '+' and quality lines never
+        # leave the host) ...
+        def feed_fastq_packed(i):
+            return sctx.feed_host_packed(fq.ctypes.data, fq.size, 2 * (rl + 1) + 5, reads=(True, 1), threads=args.feed_threads, piece_text=args.piece_mib << 20)
+
         raw_steps = max(1, args.streamed_steps * 3 // 2)      # (6 x 6.1 GB by default: the drain of the last batch is then < 10 % of the region)
+        nbases, moved, sec, allocs, per_rank = run(feed_fastq_packed, 2 * raw_steps)
+        assert nbases == world * 2 * raw_steps * m * rl
+        streamed.update({"streamed_fastq_bases_per_s": round(nbases / sec, 1), "fastq_h2d_GBps": round(moved / sec / 1e9, 2),
+                         "fastq_text_GBps": round(world * 2 * raw_steps * fq.size / sec / 1e9, 2), "fastq_h2d_GBps_per_rank": per_rank,
+                         "fastq_reads_per_step": m, "fastq_steps": 2 * raw_steps, "fastq_allocations_inside": allocs})
+        # ... and as raw text over the link, line discipline on the device (QM2_READER=raw; rounds 2-4's figure)
         nbases, moved, sec, allocs, per_rank = run(feed_fastq, raw_steps)
         streamed.update({"streamed_raw_fastq_bases_per_s": round(nbases / sec, 1), "raw_fastq_h2d_GBps": round(moved / sec / 1e9, 2),
                          "raw_fastq_h2d_GBps_per_rank": per_rank,
@@ -804,9 +864,11 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "value_is": "the count path with the read batches already resident in HBM when the timed region starts (the bench "
-                        "contract); SURVEY 8(d)'s host-fed wall-clock metric (first commit -> return of qm2_finish, PCIe "
-                        "included) is streamed_bases_per_s in this same line, raw FASTQ text: streamed.streamed_raw_fastq_bases_per_s",
+            "value_is": "the count path with the read batches (ASCII sequence lines) already resident in HBM when the timed region starts "
+                        "(the bench contract); SURVEY 8(d)'s host-fed wall-clock metric (first commit -> return of qm2_finish, PCIe "
+                        "included, the host threads packing what they feed) is streamed_bases_per_s in this same line, FASTQ text: "
+                        "streamed.streamed_fastq_bases_per_s; the same without the packing: streamed.streamed_ascii_bases_per_s / "
+                        "streamed_raw_fastq_bases_per_s",
             "config": {"workload": args.workload + ": " + wl["desc"], "k": k, "hash_size": H,
                        "dict_kmers": n_unique, "fill": round(n_unique / H, 4),
                        "partitioned_equals_direct_at_bench_batch": geometry["equal"] if geometry else None,

@@ -16,6 +16,8 @@
  *   format sniff + line discipline, :393-398, :451-455  caller (qm2_submit takes sequence lines), or
  *                                                       qm2_staging_commit_raw / qm2_submit_raw_device
  *   per-line encode + dispatch loop, :397-456           qm2_submit / qm2_staging_commit / qm2_submit_device
+ *     reset test + 2-bit code of a character, :403-411    (optionally on the host: qm2_pack_lines / qm2_pack_reads ->
+ *                                                          qm2_staging_commit_packed / qm2_submit_packed_device)
  *     rolling 2-bit encoder + canonicaliser, :399-420
  *     Kmer_count_TSK batch worker, :256-296
  *     DJBHash_encode :66-76, Find_hash :90-99
@@ -52,7 +54,7 @@
 extern "C" {
 #endif
 
-#define QM2_ABI_VERSION 5
+#define QM2_ABI_VERSION 6
 
 typedef struct qm2_ctx qm2_ctx;
 
@@ -73,6 +75,8 @@ typedef struct qm2_ctx qm2_ctx;
                                       TEXT on by one; a context that sees only some of the text's batches (one of
                                       several replicas fed in turns, `--devices`) cannot know about those in the
                                       batches it did not see, so there the caller takes the host path for such input */
+#define QM2_FLAG_SUBMIT_ASCII 0x40u /* qm2_submit copies the caller's ASCII lines to the device as they are instead of
+                                      packing them into the pinned buffers (qm2_pack_lines): 1 byte per base over the link */
 
 typedef struct {
     uint32_t struct_size;     /* = sizeof(qm2_opts); 0-filled fields = defaults  */
@@ -365,6 +369,60 @@ int qm2_submit_raw_device(qm2_ctx *c, const void *d_raw, size_t n, uint32_t fast
  * starts over (qm2_reset) on the host path.  Do not mix with qm2_submit inside one batch. */
 int qm2_staging_commit_raw(qm2_ctx *c, char *buf, size_t offset, size_t n, uint32_t fastq, uint32_t skip);
 uint32_t qm2_raw_verdict(qm2_ctx *c);
+
+/* ---- packed sequence (ABI 6): 3 bits a base over the PCIe link instead of 8 ---------------------------------- *
+ * The counting kernels turn every 16 ASCII bytes into a u32 of 2-bit codes and a 16-bit reset mask before anything
+ * else (QuicKmer.c:403-411: `c == 'N'`, the line end, `(c >> 1) & 3`).  The host may do exactly that — and no more —
+ * in the pass it makes over the text anyway (the memcpy into a pinned buffer, the reader threads' block pass), so
+ * that 0.375 bytes per base cross the link instead of 1 (FASTQ: instead of 2.05).  Rolling the k-mer, the reverse
+ * complement, the canonical choice, hashing, probing and counting stay on the device.
+ *
+ * Format: a stream of POSITIONS; every sequence character and every line end is one position, in text order (the
+ * text being what qm2_submit takes: whole '\n'-terminated sequence lines).  64 positions make one block of
+ * QM2_PACKED_BLOCK_BYTES = 24 bytes, three little-endian u64:
+ *     word 0, 1   the codes of positions 0..31 / 32..63: position q of the word has its code's HIGH bit
+ *                 ((c >> 2) & 1) in bit 2q and its LOW bit ((c >> 1) & 1) in bit 2q + 1 (one v_bfrev_b32 on the
+ *                 device puts a lane's 16 positions first-base-first)
+ *     word 2      bit p set: position p is a reset — 'N', a line end, or filler behind the last line
+ * A piece (one call) is whole blocks; its last block is filled up with resets, which behave like empty lines
+ * (zero iterations of :403).  n_newlines = line ends + filler positions: n_bases = 64 n_blocks - n_newlines.
+ * wraps: positions (from the piece's first) where the reference's uint16 run counter wraps (:402; lines of
+ * >= 65536 bases only), ascending.
+ *
+ * qm2_pack_lines   host only, no device: n bytes of sequence lines (qm2_submit's contract) -> blocks at dst
+ *                  (8-byte aligned, qm2_packed_bound(n) bytes suffice).  Thread-safe; callers pack pieces on as many
+ *                  threads as they like and commit them in order.
+ * qm2_pack_reads   the same with the reference's FASTA/FASTQ line discipline in front (:393-398, :451-455): `text`
+ *                  is whole RAW lines (a last one without '\n' gets one), *st the state at its first line —
+ *                  fastq (the first line of the file started with '@', :395; that line is NOT part of text),
+ *                  skip (lines still to drop, 0..3), desync (out: set when a FASTQ sequence-position line started
+ *                  with '>': :398 skips it without the three discards, so the state of the blocks behind it is
+ *                  no longer a function of their line count) — updated to the state behind the last line.
+ * Both return 0, 1 (bad arguments; message printed) or 2 (dst or wraps too small: nothing is printed, the caller
+ * takes the ASCII path for this piece).
+ * qm2_staging_commit_packed  commits the p->n_blocks blocks at the start of a buffer from qm2_staging_acquire
+ *                  (wraps: host array of p->n_wraps positions or NULL) under qm2_staging_commit's rules; pieces
+ *                  collect in a device batch of up to batch_bytes positions; a piece never straddles batches.
+ * qm2_submit_packed_device   the same for blocks already in device memory (16-byte aligned; d_wraps on the device).
+ * qm2_submit itself packs into the pinned buffers it copies through (QM2_FLAG_SUBMIT_ASCII turns that off). */
+#define QM2_PACKED_BLOCK_BYTES 24
+typedef struct {
+    uint64_t n_blocks;
+    uint64_t n_newlines;
+    uint64_t n_wraps;
+} qm2_packed;
+typedef struct {
+    uint32_t fastq, skip, desync;
+} qm2_line_state;
+size_t qm2_packed_bound(size_t n_text);
+int qm2_pack_lines(const char *lines, size_t n, void *dst, size_t dst_bytes, uint64_t *wraps, size_t wraps_cap,
+                   qm2_packed *out);
+int qm2_pack_reads(const char *text, size_t n, qm2_line_state *st, void *dst, size_t dst_bytes, uint64_t *wraps,
+                   size_t wraps_cap, qm2_packed *out);
+const char *qm2_pack_isa(void);      /* "avx512" / "avx2" / "portable": the build of the packers this CPU runs */
+const char *qm2_pack_isa_select(const char *name);   /* force a build (tests run all three; NULL = the widest again); returns what runs */
+int qm2_staging_commit_packed(qm2_ctx *c, char *buf, const qm2_packed *p, const uint64_t *wraps);
+int qm2_submit_packed_device(qm2_ctx *c, const void *d_blocks, const qm2_packed *p, const uint64_t *d_wraps);
 
 /* Straight from the .qm file to the device (QuicKmer.c:353-359 and :483 without the 32 GiB
  * host array the reference mallocs at :353): the key table / the chain are read from `fd` at

@@ -68,6 +68,11 @@ static int out_submit(void *user, const char *lines, size_t n)
     progress_peek((qm2_ctx *)user);
     return qm2_submit((qm2_ctx *)user, lines, n);
 }
+static int out_commit_packed(void *user, char *buf, const qm2_packed *p, const uint64_t *wraps)
+{
+    progress_peek((qm2_ctx *)user);
+    return qm2_staging_commit_packed((qm2_ctx *)user, buf, p, wraps);
+}
 static int out_commit_raw(void *user, char *buf, size_t offset, size_t n, int fastq, unsigned skip)
 {
     progress_peek((qm2_ctx *)user);
@@ -87,6 +92,23 @@ static uint64_t default_batch_bytes(uint64_t hash_size)
     if (bb < (1ull << 30)) bb = 1ull << 30;
     if (bb > (2ull << 30)) bb = 2ull << 30;
     return bb;
+}
+
+/* How the input reaches the device (QM2_READER = packed | raw | lines; the older QM2_READER_RAW = 1 / 0 = raw / lines):
+ *   packed (default)  the reader threads run the line discipline and pack what it keeps — 2-bit codes and reset flags,
+ *                     0.375 bytes per base over the link (include/qm2.h, "packed sequence"); files and pipes alike
+ *   raw               regular files: the threads only pread, the device does the line discipline (2.05 bytes per base
+ *                     of FASTQ, 1.0x of FASTA); pipes: lines
+ *   lines             the threads strip to ASCII sequence lines (1 byte per base) */
+enum { READER_PACKED = 0, READER_RAW = 1, READER_LINES = 2 };
+static int reader_mode(void)
+{
+    const char *m = getenv("QM2_READER"), *raw = getenv("QM2_READER_RAW");
+    if (m && !strcmp(m, "raw")) return READER_RAW;
+    if (m && !strcmp(m, "lines")) return READER_LINES;
+    if (m && !strcmp(m, "packed")) return READER_PACKED;
+    if (raw) return strcmp(raw, "0") == 0 ? READER_LINES : READER_RAW;
+    return READER_PACKED;
 }
 
 /* What the reader will do with `reads`: a regular file goes to the device as raw text (unless QM2_READER_RAW=0) and
@@ -209,8 +231,8 @@ static int count_on_devices(qm2_dict_file *d, const char *reads, int n_strip, co
     int regular, fastq;
     uint64_t in_size;
     sniff_input(reads, &regular, &fastq, &in_size);
-    const char *raw_env = getenv("QM2_READER_RAW");
-    int want_raw = regular && n_strip > 0 && !(raw_env && strcmp(raw_env, "0") == 0);
+    int want_raw = regular && n_strip > 0 && reader_mode() == READER_RAW;
+    const int want_packed = n_strip > 0 && reader_mode() == READER_PACKED;
     const uint32_t what = QM2_PREPARE_HOST | (want_raw ? QM2_PREPARE_RAW : 0u) | (want_raw && fastq ? QM2_PREPARE_FASTQ : 0u);
     /* one loader thread per replica: each reads the .qm through the page cache and feeds its own GPU over its own
      * PCIe link, so N replicas load in about the time of one (the contexts share nothing but the file descriptor,
@@ -242,7 +264,7 @@ static int count_on_devices(qm2_dict_file *d, const char *reads, int n_strip, co
     if (load_rc) return 1;
     for (int i = 0; i < n_dev; i++) {
         sinks[i].acquire = out_acquire; sinks[i].commit = out_commit; sinks[i].submit = out_submit;
-        sinks[i].flush = out_flush; sinks[i].user = ctxs[i]; sinks[i].commit_raw = out_commit_raw;
+        sinks[i].flush = out_flush; sinks[i].user = ctxs[i]; sinks[i].commit_raw = out_commit_raw; sinks[i].commit_packed = out_commit_packed;
         progress_ctx[i] = ctxs[i];
     }
     progress_n = n_dev;
@@ -265,7 +287,8 @@ static int count_on_devices(qm2_dict_file *d, const char *reads, int n_strip, co
             size_t blocks = tb_env ? (size_t)strtoull(tb_env, NULL, 10) : (size_t)(bb / per_block);
             qm2_dispatch_raw_turn(disp, blocks ? blocks : 1);
         }
-        qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, disp, want_raw ? qm2_dispatch_commit_raw : NULL};
+        qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, disp, want_raw ? qm2_dispatch_commit_raw : NULL,
+                             want_packed && !want_raw ? qm2_dispatch_commit_packed : NULL};
         rc = qm2_stream_reads(reads, &out, n_strip);
         qm2_dispatch_free(disp);
         memset(st, 0, sizeof *st);
@@ -289,7 +312,7 @@ static int count_on_devices(qm2_dict_file *d, const char *reads, int n_strip, co
     if (timing && !rc) {
         const double sec = (tc.tv_sec - tb.tv_sec) + 1e-9 * (tc.tv_nsec - tb.tv_nsec);
         printf("QM2 phase count %.3f s (%.2f G bases/s) on %d contexts, %s\n", sec, st->n_bases / sec / 1e9, n_dev,
-               want_raw ? "raw blocks in turns" : "host line discipline");
+               want_raw ? "raw blocks in turns" : want_packed ? "packed on the host" : "host line discipline");
     }
     for (int i = 1; i < n_dev && !rc; i++) rc = qm2_merge_counters(ctxs[0], ctxs[i]);
     if (timing && !rc) {
@@ -352,7 +375,7 @@ static int count_on_shards(qm2_dict_file *d, const char *reads, int n_strip, con
     qm2_stats st;
     memset(&st, 0, sizeof st);
     if (!rc) {
-        qm2_lines_out out = {sh_acquire, sh_commit, sh_submit, S, NULL};       /* sequence lines: the host line discipline */
+        qm2_lines_out out = {sh_acquire, sh_commit, sh_submit, S, NULL, NULL};       /* sequence lines: the host line discipline */
         rc = qm2_stream_reads(reads, &out, n_strip);
         if (!rc) rc = g_shards.finish(S, &st);
     }
@@ -486,8 +509,8 @@ int qm2_main_count(int argc, char **argv)
     }
     if (getenv("QM2_BATCH_BYTES")) o.batch_bytes = strtoull(getenv("QM2_BATCH_BYTES"), NULL, 0);   /* (experiments) */
     clock_gettime(CLOCK_MONOTONIC, &ta);
-    const char *raw_env = getenv("QM2_READER_RAW");
-    const int want_raw = !(raw_env && strcmp(raw_env, "0") == 0);
+    const int want_raw = reader_mode() == READER_RAW;
+    const int want_packed = reader_mode() == READER_PACKED && n_strip > 0;
     struct timespec t_open, t_prep;
     if (qm2_open(&ctx, NULL, d.hash_size, d.k, &o)) { qm2_dict_close(&d); return 1; }
     clock_gettime(CLOCK_MONOTONIC, &t_open);
@@ -522,7 +545,7 @@ int qm2_main_count(int argc, char **argv)
     progress_printed_g = 0;
     progress_ctx[0] = ctx;
     progress_n = 1;
-    qm2_lines_out out = {out_acquire, out_commit, out_submit, ctx, want_raw ? out_commit_raw : NULL};
+    qm2_lines_out out = {out_acquire, out_commit, out_submit, ctx, want_raw ? out_commit_raw : NULL, want_packed ? out_commit_packed : NULL};
     int rc = qm2_stream_reads(reads, &out, n_strip);
     qm2_stats st;
     memset(&st, 0, sizeof st);
@@ -546,10 +569,11 @@ int qm2_main_count(int argc, char **argv)
         qm2_profile pr;
         memset(&pr, 0, sizeof pr);
         (void)qm2_get_profile(ctx, &pr);
-        printf("QM2 phase count %.3f s (%.2f G bases/s); allocations inside it: %llu\n",
+        printf("QM2 phase count %.3f s (%.2f G bases/s); allocations inside it: %llu; input %s\n",
                (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec),
                st.n_bases / ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / 1e9,
-               (unsigned long long)(pr.allocations - allocs_before));
+               (unsigned long long)(pr.allocations - allocs_before),
+               out.commit_raw ? "raw text, line discipline on the device" : out.commit_packed ? "packed on the host" : "ASCII lines from the host");
     }
     clock_gettime(CLOCK_MONOTONIC, &ta);
     rc = qm2_write_outputs(&d, ctx, ref_prefix, out_prefix);

@@ -35,6 +35,8 @@ struct Batch {                              /* one device batch being filled by 
     hipEvent_t  done = nullptr;             /* its kernels have finished */
     hipEvent_t  copied = nullptr;           /* its staged copies have landed (the kernels wait for it) */
     bool        busy = false;
+    bool        packed = false;             /* holds PACKED sequence (qm2_staging_commit_packed): fill = bytes of blocks ... */
+    uint64_t    packed_nl = 0;              /* ... of whose positions this many are line ends or filler */
     bool        raw = false;                /* holds raw FASTA/FASTQ text (qm2_staging_commit_raw) ... */
     uint32_t    raw_fastq = 0, raw_skip = 0;/* ... in this line state at dev[0] */
 };

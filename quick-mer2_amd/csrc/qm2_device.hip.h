@@ -53,6 +53,8 @@ struct SeqView {
                                   0 = base + lead) whose windows the uint16 run
                                   counter drops (:402)                           */
     uint64_t        n_suppress;
+    uint32_t        packed = 0;/* the input is PACKED (include/qm2.h, "packed sequence"): base = its blocks (16-byte aligned),
+                                  lead = emit_from = 0, n_total = 64 x blocks positions; the kernels' PK instantiations read it */
 };
 
 /* stats block in device memory */
@@ -276,6 +278,36 @@ __host__ __device__ __forceinline__ uint4 load16(const SeqView &sv, int64_t g)
     return fix16(sv, g, load16_raw(sv, g));
 }
 
+/* ---- packed input (include/qm2.h, "packed sequence"; the host side is qm2_pack.c) --------------------------------
+ * A lane's 16 positions are unit u = g / 16 of the stream: 4 bytes of codes and 2 bytes of reset flags inside block
+ * u / 4 (24 bytes: codes of positions 0..31, of 32..63, flags).  The host has done pack16's work — (c >> 1) & 3 and
+ * the reset test, QuicKmer.c:403-411 — so what is left is the bit order: the stream is first-position-lowest, the
+ * window code wants base 0 on top: one v_bfrev_b32 each.  load16_packed_raw is load16_raw's counterpart (a clamped
+ * address, so that it can be issued a chunk early), unpack16 that of pack16(fix16()). */
+__host__ __device__ __forceinline__ uint4 load16_packed_raw(const SeqView &sv, int64_t g)
+{
+    const int64_t last = (int64_t)(sv.n_total >> 4) - 1;
+    int64_t u = g >> 4;                                   /* (g is a multiple of 16, possibly negative) */
+    u = u < 0 ? 0 : (u > last ? last : u);
+    const uint8_t *blk = sv.base + (uint64_t)(u >> 2) * 24u;
+    const uint32_t sub = (uint32_t)u & 3u;
+    const uint32_t codes = *reinterpret_cast<const uint32_t *>(blk + 4u * sub);
+    const uint32_t flags = *reinterpret_cast<const uint16_t *>(blk + 16u + 2u * sub);
+    return make_uint4(codes, flags, 0u, 0u);
+}
+
+__host__ __device__ __forceinline__ Packed unpack16(const SeqView &sv, int64_t g, uint4 v)
+{
+    Packed p;
+    /* (whole blocks: a lane's 16 positions are all inside the stream or all outside, where everything is a line end) */
+    const bool in = g >= 0 && g < (int64_t)sv.n_total;
+    p.fwd = __builtin_bitreverse32(v.x);                  /* code high bit in bit 2q, low bit in 2q + 1 -> base 0 in bits 31:30 */
+    p.bad = in ? __builtin_bitreverse32(v.y) >> 16 : 0xFFFFu;
+    p.nl = 0;                                             /* (line ends are not told from 'N' here: the host counts them, and
+                                                              the launch takes them off n_bases — stats_sub_bases_kernel) */
+    return p;
+}
+
 /* The 48-base window of one lane: its own 16 bases and the 32 before them. */
 struct Window {
     uint32_t w0, w1, w2;     /* forward: own, lane-1, lane-2 (w2 oldest)         */
@@ -382,24 +414,24 @@ __host__ __device__ __forceinline__ int64_t lane_offset(uint64_t tile0, int lane
 }
 
 /* Build the window for `lane` of a wave whose tile starts at byte tile0.
- * All 64 lanes must call (wave shuffles inside). */
-template <bool K30>
+ * All 64 lanes must call (wave shuffles inside).  PK: packed input. */
+template <bool K30, bool PK = false>
 __device__ __forceinline__ Window make_window(const SeqView &sv, uint64_t tile0, int lane, uint32_t k)
 {
     const int64_t g = lane_offset(tile0, lane);
-    const Packed p = pack16(load16(sv, g));
+    const Packed p = PK ? unpack16(sv, g, load16_packed_raw(sv, g)) : pack16(load16(sv, g));
     Packed p1, p2;
     p1.fwd = __shfl_up(p.fwd, 1); p1.bad = __shfl_up(p.bad, 1); p1.nl = 0;
     p2.fwd = __shfl_up(p.fwd, 2); p2.bad = __shfl_up(p.bad, 2); p2.nl = 0;
     return assemble_window<K30>(sv, g, lane < kHaloLanes, p, p1, p2, k);
 }
 
-/* Same, with the lane's 16 bytes already fetched by load16_raw (software prefetch). */
-template <bool K30>
+/* Same, with the lane's 16 bytes already fetched by load16_raw / load16_packed_raw (software prefetch). */
+template <bool K30, bool PK = false>
 __device__ __forceinline__ Window make_window_from(const SeqView &sv, uint64_t tile0, int lane, uint32_t k, uint4 bytes)
 {
     const int64_t g = lane_offset(tile0, lane);
-    const Packed p = pack16(fix16(sv, g, bytes));
+    const Packed p = PK ? unpack16(sv, g, bytes) : pack16(fix16(sv, g, bytes));
     Packed p1, p2;
     p1.fwd = __shfl_up(p.fwd, 1); p1.bad = __shfl_up(p.bad, 1); p1.nl = 0;
     p2.fwd = __shfl_up(p.fwd, 2); p2.bad = __shfl_up(p.bad, 2); p2.nl = 0;

@@ -93,6 +93,23 @@ int qm2_dispatch_commit(void *user, char *buf, size_t n)
     return 1;
 }
 
+int qm2_dispatch_commit_packed(void *user, char *buf, const qm2_packed *p, const uint64_t *wraps)
+{
+    qm2_dispatch *d = user;
+    for (int i = 0; i < QM2_MAX_LENT; i++) {
+        if (d->lent[i].buf != buf) continue;
+        const int sink = d->lent[i].sink;
+        qm2_sink *s = &d->sinks[sink];
+        const int was_current = sink == d->cur;
+        d->lent[i].buf = NULL;
+        if (!s->commit_packed) { puts("qm2: packed commit to a sink that takes none"); return 1; }
+        if (s->commit_packed(s->user, buf, p, wraps)) return 1;
+        return was_current ? turn_over(d, (size_t)p->n_blocks * 64) : 0;
+    }
+    puts("qm2: commit of a buffer that was not acquired");
+    return 1;
+}
+
 int qm2_dispatch_commit_raw(void *user, char *buf, size_t offset, size_t n, int fastq, unsigned skip)
 {
     qm2_dispatch *d = user;

@@ -20,6 +20,9 @@
 #ifndef QM2_DISPATCH_H
 #define QM2_DISPATCH_H
 #include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/qm2.h"
 
 typedef struct {
     int (*acquire)(void *user, char **buf, size_t *capacity);
@@ -29,6 +32,9 @@ typedef struct {
     void *user;
     /* optional: raw text with the line state at its first byte (qm2_lines_out.commit_raw); 0, 1 or 2 */
     int (*commit_raw)(void *user, char *buf, size_t offset, size_t n, int fastq, unsigned skip);
+    /* optional: a packed piece of sequence lines (qm2_lines_out.commit_packed); dealt like stripped lines, a turn
+     * being counted in positions */
+    int (*commit_packed)(void *user, char *buf, const qm2_packed *p, const uint64_t *wraps);
 } qm2_sink;
 
 typedef struct qm2_dispatch qm2_dispatch;
@@ -46,4 +52,5 @@ int qm2_dispatch_acquire(void *d, char **buf, size_t *capacity);
 int qm2_dispatch_commit(void *d, char *buf, size_t n);
 int qm2_dispatch_submit(void *d, const char *lines, size_t n);
 int qm2_dispatch_commit_raw(void *d, char *buf, size_t offset, size_t n, int fastq, unsigned skip);
+int qm2_dispatch_commit_packed(void *d, char *buf, const qm2_packed *p, const uint64_t *wraps);
 #endif

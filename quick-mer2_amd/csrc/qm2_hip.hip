@@ -327,6 +327,21 @@ static SeqView seq_view(const uint8_t *data, size_t n, size_t carry, const uint6
     sv.n_total = sv.lead + n;
     sv.suppress = d_sup;
     sv.n_suppress = n_sup;
+    sv.packed = 0;
+    return sv;
+}
+
+/* n positions of packed input (include/qm2.h, "packed sequence"): whole blocks at a 16-byte aligned address */
+static SeqView seq_view_packed(const uint8_t *blocks, size_t n_positions, const uint64_t *d_sup, uint64_t n_sup)
+{
+    SeqView sv;
+    sv.base = blocks;
+    sv.lead = 0;
+    sv.emit_from = 0;
+    sv.n_total = n_positions;
+    sv.suppress = d_sup;
+    sv.n_suppress = n_sup;
+    sv.packed = 1;
     return sv;
 }
 
@@ -337,12 +352,11 @@ static int launch_direct(qm2_ctx *c, const SeqView &sv, const unsigned long long
     const int grid = grid_for(c, n_tiles);
     TimedLaunch t;
     if (time_begin(c, &t, QM2_K_COUNT_DIRECT)) return 1;
-    if (c->k == 30)
-        hipLaunchKernelGGL(count_kernel<true>, dim3(grid), dim3(kBlock), 0, c->stream, sv, table_view(c), c->k,
-                           n_tiles, c->stats, only_if, seq_stats);
-    else
-        hipLaunchKernelGGL(count_kernel<false>, dim3(grid), dim3(kBlock), 0, c->stream, sv, table_view(c), c->k,
-                           n_tiles, c->stats, only_if, seq_stats);
+#define QM2_DIRECT(K30_, PK_) hipLaunchKernelGGL((count_kernel<K30_, PK_>), dim3(grid), dim3(kBlock), 0, c->stream, sv, table_view(c), c->k, \
+                                                n_tiles, c->stats, only_if, seq_stats)
+    if (sv.packed) { if (c->k == 30) QM2_DIRECT(true, true); else QM2_DIRECT(false, true); }
+    else           { if (c->k == 30) QM2_DIRECT(true, false); else QM2_DIRECT(false, false); }
+#undef QM2_DIRECT
     HIP_OK(hipGetLastError());
     return time_end(c, &t, batch_end);
 }
@@ -363,13 +377,23 @@ struct PartSource {
 
 /* The split kernels by what their destination is: a level of k-mers (fin = 0; segmented or region-major), or the finest
  * level, written as bucket records with a second word of `fin` = 2 or 4 bytes (always region-major). */
-template <bool K30, bool SEG, uint32_t FX, typename... A>
+template <bool K30, bool SEG, uint32_t FX, bool PK, typename... A>
 static void launch_text_split(int fin, int grid, hipStream_t s, A... a)
 {
-    if constexpr (FX != 0) split_text_kernel<K30, SEG, FX, 0><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);   /* (a level above the finest) */
-    else if (fin == 2)     split_text_kernel<K30, false, 0, 2><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
-    else if (fin == 4)     split_text_kernel<K30, false, 0, 4><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
-    else                   split_text_kernel<K30, SEG, 0, 0><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
+    if constexpr (FX != 0) split_text_kernel<K30, SEG, FX, 0, PK><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);   /* (a level above the finest) */
+    else if (fin == 2)     split_text_kernel<K30, false, 0, 2, PK><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
+    else if (fin == 4)     split_text_kernel<K30, false, 0, 4, PK><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
+    else                   split_text_kernel<K30, SEG, 0, 0, PK><<<dim3(grid), dim3(kSplitThreads), 0, s>>>(a...);
+}
+/* ... and by what the text is: ASCII, or packed (PK) */
+template <bool PK, typename... A>
+static void launch_text_split_for(const qm2_ctx *c, const PartPlan &p, int fin, int grid, hipStream_t s, A... a)
+{
+    /* (the hg38-scale split with its shift and width as constants: split_text 21.57 -> 21.37, split_kmer 24.47 -> 24.17 ms) */
+    constexpr uint32_t kFx1 = (22u << 8) | 10u;       /* H = 2^32: level 1 takes bits 22..31 of the home slot */
+    if (c->k == 30 && !fin && p.seg0 && p.shift[0] == 22 && p.bits[0] == 10) launch_text_split<true, true, kFx1, PK>(0, grid, s, a...);
+    else if (c->k == 30) { if (p.seg0) launch_text_split<true, true, 0, PK>(fin, grid, s, a...); else launch_text_split<true, false, 0, PK>(fin, grid, s, a...); }
+    else                 { if (p.seg0) launch_text_split<false, true, 0, PK>(fin, grid, s, a...); else launch_text_split<false, false, 0, PK>(fin, grid, s, a...); }
 }
 template <bool FLAT, bool SRC_SEG, bool DST_SEG, uint32_t FX, typename... A>
 static void launch_kmer_split(int fin, uint32_t grid, hipStream_t s, A... a)
@@ -405,12 +429,9 @@ static int launch_partitioned(qm2_ctx *c, const PartSource &src)
             const uint64_t n_chunks = (sv.n_total + kSplitTextBytes - 1) / kSplitTextBytes;
             const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * kSplitWgPerCu);
             if (time_begin(c, &t, QM2_K_SPLIT_TEXT)) return 1;
-            /* (the hg38-scale split with its shift and width as constants: split_text 21.57 -> 21.37, split_kmer 24.47 -> 24.17 ms) */
-            constexpr uint32_t kFx1 = (22u << 8) | 10u;       /* H = 2^32: level 1 takes bits 22..31 of the home slot */
 #define QM2_TEXT_ARGS sv, c->k, p.shift[0], p.bits[0], n_chunks, d, c->stats, (unsigned long long *)nullptr
-            if (c->k == 30 && !fin && p.seg0 && p.shift[0] == 22 && p.bits[0] == 10) launch_text_split<true, true, kFx1>(0, grid, s, QM2_TEXT_ARGS);
-            else if (c->k == 30) { if (p.seg0) launch_text_split<true, true, 0>(fin, grid, s, QM2_TEXT_ARGS); else launch_text_split<true, false, 0>(fin, grid, s, QM2_TEXT_ARGS); }
-            else                 { if (p.seg0) launch_text_split<false, true, 0>(fin, grid, s, QM2_TEXT_ARGS); else launch_text_split<false, false, 0>(fin, grid, s, QM2_TEXT_ARGS); }
+            if (sv.packed) launch_text_split_for<true>(c, p, fin, grid, s, QM2_TEXT_ARGS);
+            else           launch_text_split_for<false>(c, p, fin, grid, s, QM2_TEXT_ARGS);
 #undef QM2_TEXT_ARGS
         } else {
             const uint32_t chunks = (uint32_t)std::max<uint64_t>(1, ((src.slab_cap + kSplitSlots - 1) / kSplitSlots + 3) / 4);
@@ -643,15 +664,20 @@ static void stats_peek_harvest(qm2_ctx *c)
     }
 }
 
-/* seq_bound: an upper bound on the batch's sequence bytes when it is smaller than n (raw FASTQ text: half), else 0 */
+/* seq_bound: an upper bound on the batch's sequence bytes when it is smaller than n (raw FASTQ text: half), else 0.
+ * packed: `data` is n POSITIONS of packed sequence (whole blocks), packed_nl of them line ends or filler. */
 static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry, const uint64_t *d_sup,
-                        uint64_t n_sup, uint64_t seq_bound = 0)
+                        uint64_t n_sup, uint64_t seq_bound = 0, bool packed = false, uint64_t packed_nl = 0)
 {
     if (n == 0) return 0;
     if (c->keys_consumed)
         return fail("qm2: the key table was overwritten by qm2_chain_gather; this context cannot count any more");
     if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
-    const SeqView sv = seq_view(data, n, carry, d_sup, n_sup);
+    const SeqView sv = packed ? seq_view_packed(data, n, d_sup, n_sup) : seq_view(data, n, carry, d_sup, n_sup);
+    if (packed) {                                                    /* (in front of the count: stream-ordered either way) */
+        hipLaunchKernelGGL(stats_sub_bases_kernel, dim3(1), dim3(64), 0, c->stream, c->stats, (unsigned long long)packed_nl);
+        HIP_OK(hipGetLastError());
+    }
     c->bytes_launched += n;
     if (part_plan_kind(c, 0)) return 1;                               /* (after qm2_probe_subslabs_device: the plan of our own level 0 again) */
     bool part = (c->flags & QM2_FLAG_PARTITION) != 0 || ((uint64_t)n >= c->H / 8 && n >= (1u << 20));
@@ -895,6 +921,9 @@ static int batch_flush(qm2_ctx *c)
     }
     uint64_t *d_sup = nullptr;
     const uint64_t n_sup = b.wraps.size();
+    const bool packed = b.packed;
+    const uint64_t packed_nl = b.packed_nl;
+    b.packed = false; b.packed_nl = 0;
     if (n_sup) {                              /* long lines are rare: a small blocking copy is fine */
         if (b.wraps_cap < n_sup) {
             if (b.dev_wraps) HIP_OK(hipFree(b.dev_wraps));
@@ -905,7 +934,8 @@ static int batch_flush(qm2_ctx *c)
         HIP_OK(hipMemcpy(b.dev_wraps, b.wraps.data(), n_sup * sizeof(uint64_t), hipMemcpyHostToDevice));
         d_sup = b.dev_wraps;
     }
-    if (launch_batch(c, b.dev, b.fill, b.carry, d_sup, n_sup)) return 1;
+    if (packed ? launch_batch(c, b.dev, b.fill / QM2_PACKED_BLOCK_BYTES * 64, 0, d_sup, n_sup, 0, true, packed_nl)
+               : launch_batch(c, b.dev, b.fill, b.carry, d_sup, n_sup)) return 1;
     HIP_OK(hipEventRecord(b.done, c->stream));
     b.busy = true;
     b.fill = b.carry = 0;
@@ -962,6 +992,7 @@ static int stage_bytes(qm2_ctx *c, Batch &b, const char *src, size_t n, Slot *ow
 }
 
 static int submit_lines(qm2_ctx *c, const char *buf, size_t n, Slot *owner);
+static int submit_packing(qm2_ctx *c, const char *buf, size_t n);
 
 extern "C" int qm2_submit(qm2_ctx *c, const char *buf, size_t n)
 {
@@ -972,12 +1003,77 @@ extern "C" int qm2_submit(qm2_ctx *c, const char *buf, size_t n)
     if (buf[n - 1] != '\n')
         return fail("qm2_submit: buffer must end with a newline (whole sequence lines only)");
     if (use_device(c)) return 1;
+    if (!(c->flags & QM2_FLAG_SUBMIT_ASCII)) return submit_packing(c, buf, n);
     return submit_lines(c, buf, n, nullptr);
+}
+
+/* One packed piece, already in pinned slot `s` (blocks from its first byte), behind the current batch's fill. */
+static int stage_packed(qm2_ctx *c, Slot &s, const qm2_packed &p, const uint64_t *wraps)
+{
+    const uint64_t positions = p.n_blocks * 64;
+    if (positions > c->batch_bytes) return fail("qm2: a packed piece of %llu positions is larger than a device batch", (unsigned long long)positions);
+    {
+        Batch &b0 = c->batch[c->cur];
+        if (b0.fill && (!b0.packed || b0.fill / QM2_PACKED_BLOCK_BYTES * 64 + positions > c->batch_bytes) && batch_flush(c)) return 1;
+    }
+    Batch &b = c->batch[c->cur];
+    if (batch_ready(c, b)) return 1;
+    if (b.fill == 0) { b.packed = true; b.packed_nl = 0; b.carry = 0; b.raw = false; b.wraps.clear(); }
+    const uint64_t pos0 = b.fill / QM2_PACKED_BLOCK_BYTES * 64;
+    HIP_OK(hipMemcpyAsync(b.dev + b.fill, s.host, p.n_blocks * QM2_PACKED_BLOCK_BYTES, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_OK(hipEventRecord(s.done, c->copy_stream));
+    s.busy = true;
+    b.fill += p.n_blocks * QM2_PACKED_BLOCK_BYTES;
+    b.packed_nl += p.n_newlines;
+    for (uint64_t i = 0; i < p.n_wraps; i++) b.wraps.push_back(wraps[i] + pos0);
+    if (b.fill / QM2_PACKED_BLOCK_BYTES * 64 >= c->batch_bytes) return batch_flush(c);
+    return 0;
+}
+
+/* qm2_submit's default: the pass it makes over the caller's lines anyway (into a pinned buffer) packs them, so that
+ * 0.375 bytes per base cross the link (qm2_pack.c).  Pieces are whole lines; a line that no piece holds (longer than a
+ * staging buffer's worth of positions), or one with more run-counter wraps than the list takes, goes the ASCII way. */
+static int submit_packing(qm2_ctx *c, const char *buf, size_t n)
+{
+    /* (whole blocks: what a piece's text rounds up to must still fit a batch) */
+    const size_t piece_max = std::min<size_t>((c->staging_bytes / QM2_PACKED_BLOCK_BYTES) * 64, c->batch_bytes) & ~(size_t)63;
+    if (piece_max == 0) return submit_lines(c, buf, n, nullptr);
+    uint64_t wraps[256];
+    size_t off = 0;
+    while (off < n) {
+        size_t take = std::min(piece_max, n - off);
+        if (take < n - off) {
+            const void *nl = take ? memrchr(buf + off, '\n', take) : nullptr;
+            if (!nl) {                                         /* one line longer than a piece: as ASCII, up to its end */
+                const char *e = (const char *)memchr(buf + off, '\n', n - off);
+                const size_t len = (size_t)(e - (buf + off)) + 1;
+                if (submit_lines(c, buf + off, len, nullptr)) return 1;
+                off += len;
+                continue;
+            }
+            take = (size_t)((const char *)nl - (buf + off)) + 1;
+        }
+        Slot *s = nullptr;
+        for (size_t tries = 0; tries < c->slots.size() && !s; tries++) {
+            Slot &cand = c->slots[c->next_slot];
+            c->next_slot = (c->next_slot + 1) % (uint32_t)c->slots.size();
+            if (!cand.lent) s = &cand;
+        }
+        if (!s) return fail("qm2_submit: every staging buffer is held by qm2_staging_acquire");
+        if (qm2_slot_ready(c, *s)) return 1;
+        qm2_packed p;
+        const int rc = qm2_pack_lines(buf + off, take, s->host, c->staging_bytes, wraps, sizeof wraps / sizeof wraps[0], &p);
+        if (rc == 1) return fail("qm2_submit: packing failed");
+        if (rc == 2) { if (submit_lines(c, buf + off, take, nullptr)) return 1; }
+        else if (stage_packed(c, *s, p, wraps)) return 1;
+        off += take;
+    }
+    return 0;
 }
 
 static int submit_lines(qm2_ctx *c, const char *buf, size_t n, Slot *owner)
 {
-    if (c->batch[c->cur].raw && batch_flush(c)) return 1;       /* a raw batch is pending: it goes first */
+    if ((c->batch[c->cur].raw || c->batch[c->cur].packed) && batch_flush(c)) return 1;   /* a raw / packed batch is pending: it goes first */
     std::vector<Part> parts;
     {
         const Batch &b0 = c->batch[c->cur];
@@ -1037,6 +1133,34 @@ extern "C" int qm2_staging_commit(qm2_ctx *c, char *buf, size_t n)
         return fail("qm2_staging_commit: buffer must end with a newline (whole sequence lines only)");
     if (use_device(c)) return 1;
     return submit_lines(c, buf, n, owner);
+}
+
+extern "C" int qm2_staging_commit_packed(qm2_ctx *c, char *buf, const qm2_packed *p, const uint64_t *wraps)
+{
+    if (!c || !buf || !p) return fail("qm2_staging_commit_packed: null argument");
+    Slot *owner = nullptr;
+    for (auto &s : c->slots) if (s.lent && s.host == buf) owner = &s;
+    if (!owner) return fail("qm2_staging_commit_packed: not a buffer from qm2_staging_acquire");
+    owner->lent = false;
+    if (p->n_blocks == 0) return 0;
+    if (p->n_blocks > c->staging_bytes / QM2_PACKED_BLOCK_BYTES) return fail("qm2_staging_commit_packed: more blocks than the buffer holds");
+    if (p->n_newlines > p->n_blocks * 64) return fail("qm2_staging_commit_packed: more line ends than positions");
+    if (p->n_wraps && !wraps) return fail("qm2_staging_commit_packed: null wrap list");
+    if (use_device(c)) return 1;
+    return stage_packed(c, *owner, *p, wraps);
+}
+
+extern "C" int qm2_submit_packed_device(qm2_ctx *c, const void *d_blocks, const qm2_packed *p, const uint64_t *d_wraps)
+{
+    if (!c || !p) return fail("qm2_submit_packed_device: null argument");
+    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
+    if (p->n_blocks == 0) return 0;
+    if (!d_blocks) return fail("qm2_submit_packed_device: null buffer");
+    if ((uintptr_t)d_blocks & 15u) return fail("qm2_submit_packed_device: the blocks must be 16-byte aligned");
+    if (p->n_newlines > p->n_blocks * 64) return fail("qm2_submit_packed_device: more line ends than positions");
+    if (p->n_wraps && !d_wraps) return fail("qm2_submit_packed_device: null wrap list");
+    if (use_device(c)) return 1;
+    return launch_batch(c, (const uint8_t *)d_blocks, p->n_blocks * 64, 0, d_wraps, p->n_wraps, 0, true, p->n_newlines);
 }
 
 extern "C" int qm2_submit_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup,

@@ -51,6 +51,12 @@ typedef struct {
      * returns the buffer.  Returns 0, 1 (error, message printed) or 2 (give up on raw hand-over:
      * qm2_stream_reads returns 2). */
     int (*commit_raw)(void *user, char *buf, size_t offset, size_t n, int fastq, unsigned skip);
+    /* optional (ABI 6, include/qm2.h "packed sequence"): when set (and commit_raw is not), the workers run the line
+     * discipline AND pack what it keeps — qm2_pack_reads, straight into the acquired buffer: 2-bit codes and reset flags,
+     * 0.375 bytes per base — and hand over the piece here, in input order.  What does not pack (a piece with more
+     * run-counter wraps than the list holds) and what the serial parts of the reader produce still comes through
+     * commit / submit as ASCII lines. */
+    int (*commit_packed)(void *user, char *buf, const qm2_packed *p, const uint64_t *wraps);
 } qm2_lines_out;
 
 /* Streams `path` (file, pipe or /dev/fd/N) with a read-ahead thread, strips it to sequence

@@ -40,7 +40,7 @@ constexpr int kNJ    = 16;             /* k-mers per lane per tile              
         }                                                                          \
     }
 
-template <bool K30>
+template <bool K30, bool PK = false>
 __global__ __launch_bounds__(kBlock) void count_kernel(SeqView sv, TableView tv, uint32_t k,
                                                        uint64_t n_tiles, DevStats *stats,
                                                        const unsigned long long *only_if, bool seq_stats)
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(SeqView sv, TableView tv,
     unsigned long long n_bases = 0, n_kmers = 0, n_probes = 0, n_hits = 0;
 
     for (uint64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
-        const Window W = make_window<K30>(sv, tile * kTileBytes, lane, k);
+        const Window W = make_window<K30, PK>(sv, tile * kTileBytes, lane, k);
         n_bases += W.n_bases;
         n_kmers += __popc(W.emit);
 
@@ -284,6 +284,13 @@ __global__ __launch_bounds__(kBlock) void probe_regions_kernel(const uint64_t *k
         atomicAdd(&stats->n_probes, n_probes);
         atomicAdd(&stats->n_hits, n_hits);
     }
+}
+
+/* Packed input does not tell a line end from an 'N' (both are resets), so its kernels count every position as a base;
+ * the host knows how many of a batch's positions are line ends or filler (qm2_packed.n_newlines) and takes them off. */
+__global__ void stats_sub_bases_kernel(DevStats *stats, unsigned long long n)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->n_bases, 0ull - n);
 }
 
 /* u32 accumulators -> the reference's uint16 counters (mod 65536, :23/:291). */

@@ -1,0 +1,142 @@
+/*
+ * qm2_pack_body.h — the packers of qm2_pack.c, compiled once per instruction set: the including file defines
+ *   QM2_ISA            suffix of the functions made here (avx512 / avx2 / portable)
+ *   QM2_TARGET         the function attribute that selects the instruction set ("" for the portable build)
+ *   QM2_MASKS64(p, hi, lo, nl, nn)   the four 64-bit byte masks of the 64 text bytes at p (bit i = byte i):
+ *                      hi = bit 2 of the byte, lo = bit 1 (code = (c >> 1) & 3 = hi:lo, QuicKmer.c:411), nl = c == '\n', nn = c == 'N'
+ *   QM2_NLMASK(p)      the nl mask alone (a group inside a dropped line needs nothing else)
+ *   QM2_SPREAD(x)      bit q of the 32-bit x -> bit 2q of a 64-bit word
+ */
+#define QM2_CAT2(a, b) a##_##b
+#define QM2_CAT(a, b) QM2_CAT2(a, b)
+#define QM2_FN(name) QM2_CAT(name, QM2_ISA)
+
+/* one block = 64 positions: codes of positions 0..31, of 32..63, reset flags (include/qm2.h, "packed sequence") */
+QM2_TARGET static inline void QM2_FN(put_block)(uint64_t *dst, uint64_t hi, uint64_t lo, uint64_t bad)
+{
+    dst[0] = QM2_SPREAD((uint32_t)hi) | (QM2_SPREAD((uint32_t)lo) << 1);
+    dst[1] = QM2_SPREAD((uint32_t)(hi >> 32)) | (QM2_SPREAD((uint32_t)(lo >> 32)) << 1);
+    dst[2] = bad;
+}
+
+/* positions appended to the sink a run at a time: cnt in 1..64, the bits above cnt zero */
+QM2_TARGET static inline int QM2_FN(sink_append)(pack_sink *s, uint64_t hi, uint64_t lo, uint64_t bad, unsigned cnt)
+{
+    const unsigned f = s->fill;
+    s->hi |= hi << f; s->lo |= lo << f; s->bad |= bad << f;
+    s->n_pos += cnt;
+    if (f + cnt < 64) { s->fill = f + cnt; return 0; }
+    if (s->n_blocks >= s->cap_blocks) return 1;
+    QM2_FN(put_block)(s->out + 3 * s->n_blocks++, s->hi, s->lo, s->bad);
+    s->fill = f + cnt - 64;
+    if (f) { s->hi = hi >> (64 - f); s->lo = lo >> (64 - f); s->bad = bad >> (64 - f); }
+    else s->hi = s->lo = s->bad = 0;
+    return 0;
+}
+
+/* the masks of the n < 64 bytes at p (the rest read as '\n') */
+QM2_TARGET static inline void QM2_FN(masks_tail)(const uint8_t *p, size_t n, uint64_t *hi, uint64_t *lo, uint64_t *nl, uint64_t *nn)
+{
+    uint8_t tmp[64];
+    memset(tmp, '\n', sizeof tmp);
+    memcpy(tmp, p, n);
+    QM2_MASKS64(tmp, hi, lo, nl, nn);
+}
+
+/* n bytes of sequence lines -> blocks; every byte is a position.  Returns the blocks written. */
+QM2_TARGET static size_t QM2_FN(pack_lines)(const uint8_t *text, size_t n, uint64_t *dst, uint64_t *n_newlines)
+{
+    size_t b = 0, i = 0;
+    uint64_t newlines = 0;
+    for (; i + 64 <= n; i += 64, b++) {
+        uint64_t hi, lo, nl, nn;
+        QM2_MASKS64(text + i, &hi, &lo, &nl, &nn);
+        newlines += (uint64_t)__builtin_popcountll(nl);
+        QM2_FN(put_block)(dst + 3 * b, hi, lo, nl | nn);
+    }
+    if (i < n) {                                   /* the last block is filled up with line ends */
+        uint64_t hi, lo, nl, nn;
+        QM2_FN(masks_tail)(text + i, n - i, &hi, &lo, &nl, &nn);
+        const uint64_t m = (1ull << (n - i)) - 1;                                        /* (the filler reads as line ends, code 0) */
+        newlines += (uint64_t)__builtin_popcountll(nl & m);
+        QM2_FN(put_block)(dst + 3 * b, hi & m, lo & m, nl | nn);
+        b++;
+    }
+    *n_newlines = newlines;
+    return b;
+}
+
+/* The FASTA / FASTQ line discipline (QuicKmer.c:393-398, :451-455) and the packing in one pass: `text` is whole lines
+ * (a last one without its '\n' gets one); the bits of the sequence lines are appended to the sink a piece of a 64-byte
+ * group at a time.  Returns 0, or 2 when the output or the wrap list does not hold it. */
+QM2_TARGET static int QM2_FN(pack_reads)(const uint8_t *text, size_t n, qm2_line_state *st, pack_sink *s)
+{
+    uint32_t skip = st->skip, desync = st->desync;
+    const uint32_t fastq = st->fastq;
+    int at_line_start = 1, take = 0;
+    size_t line_start = 0;                          /* of the line being taken: where it starts in the text ... */
+    uint64_t line_pos0 = 0;                         /* ... and in the packed positions */
+    for (size_t g = 0; g < n; g += 64) {
+        uint64_t hi = 0, lo = 0, nl, nn = 0;
+        size_t cnt = 64;
+        int have = 0;                               /* hi / lo / nn of this group are worked out: only for a group that holds kept text */
+        if (n - g >= 64) {
+            nl = QM2_NLMASK(text + g);
+            if (!nl && !take && !at_line_start) continue;                             /* inside a dropped line */
+        } else {
+            cnt = n - g;
+            QM2_FN(masks_tail)(text + g, cnt, &hi, &lo, &nl, &nn);
+            nl &= (1ull << cnt) - 1;                /* (the filler is not text) */
+            have = 1;
+        }
+        size_t pos = 0;
+        while (pos < cnt) {
+            if (at_line_start) {
+                at_line_start = 0;
+                const uint8_t first = text[g + pos];
+                if (skip) { skip--; take = 0; }                                       /* :452-454 */
+                else if (first == '>') { if (fastq) desync = 1; take = 0; }           /* :398 (before :451: no discards) */
+                else {
+                    take = 1;
+                    if (fastq) skip = 3;
+                    line_start = g + pos;
+                    line_pos0 = s->n_pos;
+                }
+            }
+            const uint64_t rest = pos < 64 ? nl >> pos : 0;
+            size_t len;                             /* positions of this line inside the group, its '\n' included */
+            int ends;
+            if (rest) { len = (size_t)__builtin_ctzll(rest) + 1; ends = 1; }
+            else { len = cnt - pos; ends = 0; }
+            if (take) {
+                if (!have) { uint64_t nl2; QM2_MASKS64(text + g, &hi, &lo, &nl2, &nn); have = 1; }
+                const uint64_t m = len >= 64 ? ~0ull : (1ull << len) - 1;
+                if (QM2_FN(sink_append)(s, (hi >> pos) & m, (lo >> pos) & m, ((nl | nn) >> pos) & m, (unsigned)len)) return 2;
+                if (ends) {
+                    s->n_newlines++;
+                    const size_t line_len = g + pos + len - 1 - line_start;           /* without the '\n' */
+                    if (line_len >= 65536 && sink_wraps(s, text + line_start, line_len, line_pos0)) return 2;
+                }
+            }
+            pos += len;
+            if (ends) at_line_start = 1;
+        }
+    }
+    if (!at_line_start && take) {                   /* the text's last line had no '\n': supplied (a divergence where the reference is undefined) */
+        if (QM2_FN(sink_append)(s, 0, 0, 1, 1)) return 2;
+        s->n_newlines++;
+        if (n - line_start >= 65536 && sink_wraps(s, text + line_start, n - line_start, line_pos0)) return 2;
+    }
+    if (s->fill) {                                  /* fill the last block up with line ends */
+        const unsigned pad = 64 - s->fill;
+        if (QM2_FN(sink_append)(s, 0, 0, pad >= 64 ? ~0ull : (1ull << pad) - 1, pad)) return 2;
+        s->n_newlines += pad;
+    }
+    st->skip = skip;
+    st->desync = desync;
+    return 0;
+}
+
+#undef QM2_FN
+#undef QM2_CAT
+#undef QM2_CAT2

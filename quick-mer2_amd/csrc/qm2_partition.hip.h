@@ -400,7 +400,8 @@ __device__ __forceinline__ void copy_all(const SplitLds &L, const SplitDst &d, u
 /* FX: 0, or (shift << 8 | bits) as compile-time constants — the split of an hg38-scale table (H = 2^32: 10 + 10 bucket
  * bits above 12 slot bits).  v_bfe_u32 takes one scalar operand; with both in SGPRs hipcc moves one into a VGPR in
  * front of EVERY hash (it has no register to keep it in): two instructions per k-mer. */
-template <bool K30, bool SEG, uint32_t FX = 0, int FIN = 0>
+/* PK: the text arrives PACKED (qm2_device.hip.h, unpack16): 6 bytes per 16 positions instead of 16, nothing to classify. */
+template <bool K30, bool SEG, uint32_t FX = 0, int FIN = 0, bool PK = false>
 __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_kernel(SeqView sv, uint32_t k, uint32_t shift, uint32_t bits,
                                                                    uint64_t n_chunks, SplitDst d, DevStats *stats,
                                                                    unsigned long long *call)
@@ -414,15 +415,19 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
                                  *  split_text 21.4 -> 23.0 ms, split_kmer 24.6 -> 27.3: hipcc schedules the longer blocks worse) */
     const uint64_t child0 = sub_region0(d, fan);
     /* the 16 bytes of this lane for the NEXT chunk are fetched while the current one is processed */
-    uint4 bytes = load16_raw(sv, lane_offset(((uint64_t)blockIdx.x * kSplitWaves + wave) * kTileBytes, lane));
+    auto load_text = [&](uint64_t chunk_) {
+        const int64_t g_ = lane_offset((chunk_ * kSplitWaves + wave) * kTileBytes, lane);
+        return PK ? load16_packed_raw(sv, g_) : load16_raw(sv, g_);
+    };
+    uint4 bytes = load_text(blockIdx.x);
 #ifdef QM2_STAMPS
     unsigned long long st_acc[28] = {0}, st_last = stamp_now();
 #endif
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint64_t tile = chunk * kSplitWaves + wave;
         const uint4 cur = bytes;
-        bytes = load16_raw(sv, lane_offset(((chunk + gridDim.x) * kSplitWaves + wave) * kTileBytes, lane));
-        const Window W = make_window_from<K30>(sv, tile * kTileBytes, lane, k, cur);
+        bytes = load_text(chunk + gridDim.x);
+        const Window W = make_window_from<K30, PK>(sv, tile * kTileBytes, lane, k, cur);
         n_bases += W.n_bases;
         n_kmers += __builtin_popcount(W.emit);
         QM2_STAMP(16);

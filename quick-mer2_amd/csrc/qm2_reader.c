@@ -43,6 +43,7 @@
                                               of the block before it                          */
 #define QM2_MAX_WORKERS 32
 #define QM2_RING_MAX (QM2_MAX_WORKERS + 3)
+#define QM2_WRAPS_CAP 512                   /* run-counter wraps a packed piece may carry (lines of >= 65536 bases only) */
 
 /* ---- the I/O thread -------------------------------------------------------- */
 
@@ -159,6 +160,10 @@ typedef struct {
     char       *obuf;                      /* pinned output from out->acquire */
     size_t      ocap, olen;
     int         rc;
+    int         pack_mode;                 /* pack what the line discipline keeps (qm2_lines_out.commit_packed) */
+    int         is_packed;                 /* obuf holds `packed` (else olen bytes of ASCII lines) */
+    qm2_packed  packed;
+    uint64_t    wraps[QM2_WRAPS_CAP];
     sem_t       start, done;
     int         quit;
 } strip_job;
@@ -167,10 +172,28 @@ static int buf_acquire(void *u, char **b, size_t *c) { (void)u; (void)b; (void)c
 static int buf_commit(void *u, char *b, size_t n) { (void)u; (void)b; (void)n; return 0; }
 static int buf_submit(void *u, const char *p, size_t n) { (void)u; (void)p; (void)n; return 1; }
 
+/* the line discipline and the packing in one pass over whole lines (qm2_pack.c); 0 = packed, 1 = error, 2 = take the ASCII way */
+static int pack_whole_lines(const char *p, size_t n, line_state *st, char *obuf, size_t ocap, qm2_packed *packed, uint64_t *wraps)
+{
+    qm2_line_state ps = {(uint32_t)st->fastq, (uint32_t)st->skip, 0};
+    const int rc = qm2_pack_reads(p, n, &ps, obuf, ocap, wraps, QM2_WRAPS_CAP, packed);
+    if (rc) return rc;
+    st->skip = (int)ps.skip;
+    if (ps.desync) st->desync = 1;
+    return 0;
+}
+
 static void strip_block(strip_job *j)
 {
+    j->is_packed = 0;
+    if (j->pack_mode) {
+        line_state st = j->st;
+        const int prc = pack_whole_lines(j->data, j->n, &st, j->obuf, j->ocap, &j->packed, j->wraps);
+        if (prc == 0) { j->st = st; j->is_packed = 1; j->rc = 0; j->olen = 0; return; }
+        if (prc == 1) { j->rc = 1; j->olen = 0; return; }
+    }
     /* an out_state pinned to the job's buffer: the output never exceeds the input, so it fits */
-    static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL, NULL};
+    static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL, NULL, NULL};
     out_state os = {&none, j->obuf, j->ocap, 0};
     size_t at = 0;
     j->rc = 0;
@@ -278,6 +301,10 @@ typedef struct {
     line_state  st_end;
     int         too_big, rc;
     int         raw_mode;                  /* read straight into obuf, do not strip */
+    int         pack_mode;                 /* strip and pack (qm2_lines_out.commit_packed) */
+    int         is_packed;                 /* obuf holds `packed` */
+    qm2_packed  packed;
+    uint64_t    wraps[QM2_WRAPS_CAP];
     sem_t       start, done;
     int         quit;
 } pf_worker;
@@ -378,10 +405,17 @@ static void *pf_main(void *arg)
         sh->lines_before[b + 1] = w->before + lines;
         atomic_store_explicit(&sh->known[b + 1], 1, memory_order_release);
         line_state st = pf_state(sh, w->before);
-        if (!atomic_load(&sh->stop) && !w->rc && !w->raw_mode) {
+        w->is_packed = 0;
+        if (!atomic_load(&sh->stop) && !w->rc && w->pack_mode && w->hi > w->lo) {
+            const int prc = pack_whole_lines(w->raw + w->lo, w->hi - w->lo, &st, w->obuf, w->ocap, &w->packed, w->wraps);
+            if (prc == 0) w->is_packed = 1;
+            else if (prc == 1) w->rc = 1;
+            else st = pf_state(sh, w->before);                         /* (does not pack: as ASCII lines, below) */
+        }
+        if (!atomic_load(&sh->stop) && !w->rc && !w->raw_mode && !w->is_packed) {
             if (w->hi - w->lo + 1 > w->ocap) w->too_big = 1;          /* more than a staging buffer holds */
             else {
-                static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL, NULL};
+                static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL, NULL, NULL};
                 out_state os = {&none, w->obuf, w->ocap, 0};
                 if (strip_range(w->raw + w->lo, w->hi - w->lo, &st, &os)) w->rc = 1;
                 w->olen = os.len;
@@ -465,6 +499,7 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
         for (int w = 0; w < n_threads && (size_t)w < sh.n_blocks; w++) {
             ws[w].sh = &sh;
             ws[w].raw_mode = raw_mode;
+            ws[w].pack_mode = !raw_mode && out->commit_packed != NULL;
             if (!raw_mode) {
                 ws[w].raw_cap = QM2_BLOCK + (1u << 17);
                 ws[w].raw = malloc(ws[w].raw_cap);
@@ -514,7 +549,7 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
                 serial_lo = w->file_hi;
                 tail = st;
             }
-        } else if (out->commit(out->user, w->obuf, w->olen)) rc = 1;
+        } else if (w->is_packed ? out->commit_packed(out->user, w->obuf, &w->packed, w->wraps) : out->commit(out->user, w->obuf, w->olen)) rc = 1;
     }
     while (collected < issued) {                                     /* drain what is still in flight */
         pf_worker *w = &ws[collected % (size_t)n_workers];
@@ -558,7 +593,7 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads)
         struct stat sb;
         char first = 0;
         if (fstat(ring.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && pread(ring.fd, &first, 1, 0) == 1 &&
-            (first == '@' || getenv("QM2_READER_BLOCKS") || out->commit_raw)) {
+            (first == '@' || getenv("QM2_READER_BLOCKS") || out->commit_raw || out->commit_packed)) {
             const int brc = stream_blocks(ring.fd, (size_t)sb.st_size, out, n_threads);
             close(ring.fd);
             return brc;
@@ -583,6 +618,7 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads)
     int n_workers = 0;
     for (int w = 0; w < n_threads; w++) {
         memset(&jobs[w], 0, sizeof jobs[w]);
+        jobs[w].pack_mode = out->commit_packed != NULL;
         sem_init(&jobs[w].start, 0, 0);
         sem_init(&jobs[w].done, 0, 0);
         if (pthread_create(&workers[w], NULL, strip_main, &jobs[w])) break;
@@ -601,7 +637,8 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads)
         sem_wait(&j->done);                                                                        \
         collected++;                                                                               \
         if (j->rc) rc = 1;                                                                         \
-        if (out->commit(out->user, j->obuf, rc ? 0 : j->olen)) rc = 1;                             \
+        if (!rc && j->is_packed ? out->commit_packed(out->user, j->obuf, &j->packed, j->wraps)     \
+                                : out->commit(out->user, j->obuf, rc ? 0 : j->olen)) rc = 1;       \
         if (!rc && j->st.desync && parallel) {                                                     \
             parallel = 0;                                                                          \
             ls = j->st;                           /* exact state after this block */               \

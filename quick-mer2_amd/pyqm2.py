@@ -19,6 +19,8 @@ FLAG_DIRECT = 0x4
 FLAG_PARTITION = 0x8
 FLAG_KEYS_LATER = 0x10
 FLAG_RAW_STRICT = 0x20
+FLAG_SUBMIT_ASCII = 0x40
+PACKED_BLOCK_BYTES = 24
 KERNEL_CLASSES = ["count_direct", "split_text", "split_kmer", "bucket_count", "probe", "encode", "lines", "-"]
 
 
@@ -45,6 +47,15 @@ class Profile(C.Structure):
                 ("allocations", C.c_uint64), ("spilled_kmers", C.c_uint64)]
 
 
+class Packed(C.Structure):
+    """qm2_packed: a piece of packed sequence (include/qm2.h, "packed sequence")"""
+    _fields_ = [("n_blocks", C.c_uint64), ("n_newlines", C.c_uint64), ("n_wraps", C.c_uint64)]
+
+
+class LineState(C.Structure):
+    _fields_ = [("fastq", C.c_uint32), ("skip", C.c_uint32), ("desync", C.c_uint32)]
+
+
 class Range(C.Structure):
     _fields_ = [("start", C.c_uint64), ("len", C.c_uint64)]
 
@@ -57,6 +68,7 @@ class Dup(C.Structure):
 ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_route_device_carry", "qm2_probe_slabs_device", "qm2_probe_subslabs_device", "qm2_route_xcd_device", "qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
                "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_chain_gc_sums_fd", "qm2_submit_raw_device", "qm2_staging_commit_raw", "qm2_raw_verdict",
+               "qm2_packed_bound", "qm2_pack_lines", "qm2_pack_reads", "qm2_pack_isa", "qm2_pack_isa_select", "qm2_staging_commit_packed", "qm2_submit_packed_device",
                "qm2_shard_span", "qm2_last_error",
                "qm2_abi_version"]
 TOOL_SYMBOLS = ["qm2t_genome_generate", "qm2t_dict_build", "qm2t_reads_generate",
@@ -138,6 +150,19 @@ def lib():
     L.qm2_staging_commit_raw.argtypes = [vp, vp, C.c_size_t, C.c_size_t, u32, u32]
     L.qm2_raw_verdict.restype = u32
     L.qm2_raw_verdict.argtypes = [vp]
+    L.qm2_packed_bound.restype = C.c_size_t
+    L.qm2_packed_bound.argtypes = [C.c_size_t]
+    L.qm2_pack_lines.restype = C.c_int
+    L.qm2_pack_lines.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(Packed)]
+    L.qm2_pack_reads.restype = C.c_int
+    L.qm2_pack_reads.argtypes = [vp, C.c_size_t, C.POINTER(LineState), vp, C.c_size_t, vp, C.c_size_t, C.POINTER(Packed)]
+    L.qm2_pack_isa.restype = C.c_char_p
+    L.qm2_pack_isa_select.restype = C.c_char_p
+    L.qm2_pack_isa_select.argtypes = [C.c_char_p]
+    L.qm2_staging_commit_packed.restype = C.c_int
+    L.qm2_staging_commit_packed.argtypes = [vp, vp, C.POINTER(Packed), vp]
+    L.qm2_submit_packed_device.restype = C.c_int
+    L.qm2_submit_packed_device.argtypes = [vp, vp, C.POINTER(Packed), vp]
     L.qm2_keys_from_fd.restype = C.c_int
     L.qm2_keys_from_fd.argtypes = [vp, C.c_int, u64]
     L.qm2_chain_gather_fd.restype = C.c_int
@@ -268,6 +293,78 @@ class Counter:
                     self.staging_commit(buf, take)
                 else:
                     self.staging_commit_raw(buf, 0, take, raw[0], raw[1])
+
+    def staging_commit_packed(self, addr, packed, wraps=None):
+        _check(lib().qm2_staging_commit_packed(self._h, addr, C.byref(packed), wraps.ctypes.data if wraps is not None and len(wraps) else None),
+               "qm2_staging_commit_packed")
+
+    def submit_packed(self, lines: bytes, piece=None):
+        """qm2_staging_acquire / qm2_pack_lines into the buffer / qm2_staging_commit_packed, a staging buffer at a time
+        (piece: at most that many text bytes per buffer)."""
+        L = lib()
+        off = 0
+        while off < len(lines):
+            buf, cap = self.staging_acquire()
+            take = min((cap // PACKED_BLOCK_BYTES) * 64, len(lines) - off, piece or (1 << 62))
+            if off + take < len(lines):
+                take = lines.rfind(b"\n", off, off + take) + 1 - off
+                if take <= 0:                         # a line longer than a piece: the ASCII way (qm2_submit cuts it)
+                    self.staging_commit(buf, 0)
+                    end = lines.find(b"\n", off) + 1
+                    _check(L.qm2_submit(self._h, lines[off:end], end - off), "qm2_submit")
+                    off = end
+                    continue
+            p, wraps = Packed(), np.zeros(4096, np.uint64)
+            view = np.frombuffer(lines, np.uint8, take, off)
+            rc = L.qm2_pack_lines(view.ctypes.data, take, buf, cap, wraps.ctypes.data, len(wraps), C.byref(p))
+            if rc:
+                self.staging_commit(buf, 0)
+                raise Qm2Error("qm2_pack_lines: %d" % rc)
+            self.staging_commit_packed(buf, p, wraps[:p.n_wraps])
+            off += take
+
+    def submit_packed_device(self, ptr, packed, wraps_ptr=None):
+        _check(lib().qm2_submit_packed_device(self._h, ptr, C.byref(packed), wraps_ptr), "qm2_submit_packed_device")
+
+    def feed_host_packed(self, addr, n, unit, reads=None, threads=8, depth=None, piece_text=16 << 20):
+        """feed_host with the packing on the threads (qm2_pack.c; the calls release the GIL): every piece of whole
+        `unit`-byte records is packed into an acquired pinned buffer — reads = None: the text is sequence lines
+        (qm2_pack_lines); reads = (fastq, skip): raw FASTA/FASTQ with that line state at the start of every piece
+        (qm2_pack_reads) — and committed in order (qm2_staging_commit_packed).  Pieces of piece_text bytes of text (the
+        CLI's reader: 32 MiB blocks), threads + 2 of them in flight (the context must have that many staging buffers + 1).
+        Returns the bytes that crossed the link."""
+        from concurrent.futures import ThreadPoolExecutor
+        L = lib()
+        pend, off, sent = [], 0, 0
+        depth = depth or threads + 2
+
+        def pack(buf, cap, src, take):
+            p, wraps = Packed(), np.zeros(64, np.uint64)
+            if reads is None:
+                rc = L.qm2_pack_lines(src, take, buf, cap, wraps.ctypes.data, len(wraps), C.byref(p))
+            else:
+                st = LineState(1 if reads[0] else 0, reads[1], 0)
+                rc = L.qm2_pack_reads(src, take, C.byref(st), buf, cap, wraps.ctypes.data, len(wraps), C.byref(p))
+                if st.desync:
+                    rc = 3
+            return rc, p, wraps
+
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            while off < n or pend:
+                while off < n and len(pend) < depth:
+                    buf, cap = self.staging_acquire()
+                    per = min((cap // PACKED_BLOCK_BYTES) * 64 - 64 if reads is None else cap, piece_text)
+                    take = min(max(1, per // unit) * unit, n - off)
+                    pend.append((buf, pool.submit(pack, buf, cap, addr + off, take)))
+                    off += take
+                buf, fut = pend.pop(0)
+                rc, p, wraps = fut.result()
+                if rc:
+                    self.staging_commit(buf, 0)
+                    raise Qm2Error("packing a piece failed (%d)" % rc)
+                self.staging_commit_packed(buf, p, wraps[:p.n_wraps])
+                sent += int(p.n_blocks) * PACKED_BLOCK_BYTES
+        return sent
 
     def submit_device(self, ptr, n, suppress_ptr=None, n_suppress=0):
         _check(lib().qm2_submit_device(self._h, ptr, n, suppress_ptr, n_suppress), "qm2_submit_device")
@@ -402,6 +499,28 @@ class Counter:
             self.close()
         except Exception:
             pass
+
+
+def pack_lines(lines: bytes, wraps_cap=4096):
+    """qm2_pack_lines on the host -> (blocks as uint64[3 n_blocks], Packed, wraps)"""
+    out = np.empty(lib().qm2_packed_bound(len(lines)) // 8, np.uint64)
+    p, wraps = Packed(), np.zeros(wraps_cap, np.uint64)
+    src = np.frombuffer(lines, np.uint8)                  # (bytes, or anything with the buffer protocol)
+    rc = lib().qm2_pack_lines(src.ctypes.data if len(src) else None, len(src), out.ctypes.data, out.nbytes, wraps.ctypes.data, wraps_cap, C.byref(p))
+    if rc:
+        raise Qm2Error("qm2_pack_lines: %d" % rc)
+    return out[:3 * p.n_blocks], p, wraps[:p.n_wraps]
+
+
+def pack_reads(text: bytes, fastq, skip=0, wraps_cap=4096, room=None):
+    """qm2_pack_reads on the host -> (blocks, Packed, wraps, LineState after the last line)"""
+    out = np.zeros((lib().qm2_packed_bound(len(text)) if room is None else room) // 8, np.uint64)
+    p, wraps, st = Packed(), np.zeros(wraps_cap, np.uint64), LineState(1 if fastq else 0, skip, 0)
+    src = np.frombuffer(text, np.uint8)
+    rc = lib().qm2_pack_reads(src.ctypes.data if len(text) else None, len(text), C.byref(st), out.ctypes.data, out.nbytes, wraps.ctypes.data, wraps_cap, C.byref(p))
+    if rc:
+        raise Qm2Error("qm2_pack_reads: %d" % rc)
+    return out[:3 * p.n_blocks], p, wraps[:p.n_wraps], st
 
 
 def shard_span(keys, n_shards, g):

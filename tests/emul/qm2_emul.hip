@@ -18,13 +18,16 @@
 
 using namespace qm2;
 
-template <bool K30>
+template <bool K30, bool PK = false>
 static void emul_part(const SeqView &sv, uint32_t k, std::vector<uint64_t> &out, uint64_t *n_bases)
 {
     const uint64_t n_tiles = (sv.n_total + kTileBytes - 1) / kTileBytes;
     for (uint64_t tile = 0; tile < n_tiles; tile++) {
         Packed p[kWave];
-        for (int lane = 0; lane < kWave; lane++) p[lane] = pack16(load16(sv, lane_offset(tile * kTileBytes, lane)));
+        for (int lane = 0; lane < kWave; lane++) {
+            const int64_t g = lane_offset(tile * kTileBytes, lane);
+            p[lane] = PK ? unpack16(sv, g, load16_packed_raw(sv, g)) : pack16(load16(sv, g));
+        }
         for (int lane = 0; lane < kWave; lane++) {
             /* __shfl_up(x, d): lanes < d keep their own value */
             const Packed p1 = p[lane >= 1 ? lane - 1 : lane], p2 = p[lane >= 2 ? lane - 2 : lane];
@@ -131,6 +134,34 @@ uint64_t qm2e_extract_dealt(const char *buf, size_t n, uint32_t k, size_t piece_
     for (uint64_t i = 0; i < km.size() && i < cap; i++) out[i] = km[i];
     if (n_bases) *n_bases = bases;
     if (n_rounds) *n_rounds = rounds;
+    return km.size();
+}
+
+/* The device's reading of PACKED input (qm2_device.hip.h: load16_packed_raw, unpack16) on n_blocks blocks as the host
+ * packers write them (quick-mer2_amd/csrc/qm2_pack.c); `wraps` as positions.  *n_positions = what the kernels add to
+ * n_bases before the host's line ends are taken off. */
+uint64_t qm2e_extract_packed(const void *blocks, uint64_t n_blocks, uint32_t k, const uint64_t *wraps, uint64_t n_wraps,
+                             uint64_t *out, uint64_t cap, uint64_t *n_positions)
+{
+    std::vector<uint8_t> dev(n_blocks * 24 + 64, 0xFF);       /* (a poisoned tail behind the last block) */
+    uint8_t *data = (uint8_t *)(((uintptr_t)dev.data() + 15) & ~(uintptr_t)15);
+    memcpy(data, blocks, n_blocks * 24);
+    SeqView sv;
+    sv.base = data;
+    sv.lead = 0;
+    sv.emit_from = 0;
+    sv.n_total = n_blocks * 64;
+    sv.suppress = n_wraps ? wraps : nullptr;
+    sv.n_suppress = n_wraps;
+    sv.packed = 1;
+    std::vector<uint64_t> km;
+    uint64_t bases = 0;
+    if (n_blocks) {
+        if (k == 30) emul_part<true, true>(sv, k, km, &bases);
+        else emul_part<false, true>(sv, k, km, &bases);
+    }
+    for (uint64_t i = 0; i < km.size() && i < cap; i++) out[i] = km[i];
+    if (n_positions) *n_positions = bases;
     return km.size();
 }
 

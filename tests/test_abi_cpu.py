@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(pkg):
         assert hasattr(L, n), n
     assert sorted(pkg.pyqm2.ABI_SYMBOLS) == declared("qm2.h")
     assert sorted(pkg.pyqm2.TOOL_SYMBOLS) == declared("qm2_tools.h")
-    assert L.qm2_abi_version() == 5
+    assert L.qm2_abi_version() == 6
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "quick-mer2_amd", "libqm2_hip.so")],
                          stdout=subprocess.PIPE, check=True).stdout.decode()
     exported = set(re.findall(r" T (qm2t?_[a-z_0-9]+)", out))
@@ -118,13 +118,47 @@ static int sub(void *u, const char *p, size_t n) { (void)u; fwrite(p, 1, n, O); 
 static int raw(void *u, char *b, size_t off, size_t n, int fastq, unsigned skip) { (void)u;
   if (n) { unsigned hdr[3] = {(unsigned)n, (unsigned)fastq, skip}; fwrite(hdr, 4, 3, O); fwrite(b + off, 1, n, O); }
   free(b); return 0; }
+static int pk(void *u, char *b, const qm2_packed *p, const uint64_t *w) { (void)u;
+  unsigned long long hdr[3] = {~0ull - p->n_blocks, p->n_newlines, p->n_wraps}; fwrite(hdr, 8, 3, O); fwrite(b, 24, p->n_blocks, O); fwrite(w, 8, p->n_wraps, O);
+  free(b); return 0; }
+/* packed mode: ASCII pieces (the serial parts of the reader) are framed too, so that the order is kept */
+static int com_f(void *u, char *b, size_t n) { (void)u; if (n) { unsigned long long hdr[3] = {n, 0, 0}; fwrite(hdr, 8, 3, O); fwrite(b, 1, n, O); } free(b); return 0; }
+static int sub_f(void *u, const char *p, size_t n) { (void)u; unsigned long long hdr[3] = {n, 0, 0}; fwrite(hdr, 8, 3, O); fwrite(p, 1, n, O); return 0; }
 int main(int argc, char **argv) { O = fopen(argv[2], "wb"); CAP = (size_t)atol(argv[3]);
-  qm2_lines_out out = {acq, com, sub, NULL, argc > 5 ? raw : NULL};
+  const int packed = argc > 5 && argv[5][0] == 'p';
+  qm2_lines_out out = {acq, packed ? com_f : com, packed ? sub_f : sub, NULL, argc > 5 && !packed ? raw : NULL, packed ? pk : NULL};
   int rc = qm2_stream_reads(argv[1], &out, atoi(argv[4])); fclose(O); return rc; }
 ''')
     exe = str(tmp_path / "h")
     subprocess.run(["gcc", "-O1", "-pthread", "-I", src, "-o", exe, str(harness),
-                    os.path.join(src, "qm2_reader.c")], check=True)
+                    os.path.join(src, "qm2_reader.c"), os.path.join(src, "qm2_pack.c")], check=True)
+
+    def content(codes, bad):
+        """what of a position stream the k-mers depend on: the codes of the non-reset positions, and between which
+        of them a reset lies (a packed piece does not tell a line end from an 'N', and ends in filler)"""
+        good = np.flatnonzero(~bad)
+        return codes[good], np.diff(good) > 1, len(good)
+
+    def packed_content(blob):
+        import test_pack_cpu as tp
+        codes, bad, at, n_newlines = [], [], 0, 0
+        while at < len(blob):
+            a, nl, nw = np.frombuffer(blob, dtype=np.uint64, count=3, offset=at)
+            at += 24
+            if int(a) > (1 << 62):                      # a packed piece
+                nb = (1 << 64) - 1 - int(a)
+                c, b = tp.unpack(np.frombuffer(blob, dtype=np.uint64, count=3 * nb, offset=at))
+                at += 24 * nb + 8 * int(nw)
+                n_newlines += int(nl)
+            else:                                       # ASCII lines
+                c, b = tp.expect(blob[at:at + int(a)])
+                at += int(a)
+                n_newlines += int(np.count_nonzero(np.frombuffer(blob[at - int(a):at], np.uint8) == 10))
+            codes.append(c)
+            bad.append(b)
+        codes = np.concatenate(codes) if codes else np.zeros(0, np.uint8)
+        bad = np.concatenate(bad) if bad else np.zeros(0, bool)
+        return content(codes, bad), len(codes) - n_newlines
     import oracle_lib as ol
     import synth
     cases = synth.kat_cases(synth.kat_reference())
@@ -156,7 +190,19 @@ int main(int argc, char **argv) { O = fopen(argv[2], "wb"); CAP = (size_t)atol(a
             for env in ({},) if thr == 0 else ({}, {"QM2_READER_BLOCKS": "1"}, {"QM2_READER_STREAM": "1"}):
                 subprocess.run([exe, str(p), outp, str(batch), str(thr)], check=True, env=dict(os.environ, **env))
                 assert open(outp, "rb").read() == exp, (name, batch, thr, env)
-        # raw hand-over (what the CLI does by default): blocks of untouched text + the line state at their
+        # packed hand-over (the CLI's default since ABI 6): the workers strip AND pack; what arrives must hold the
+        # oracle's stripped stream, position for position (modulo filler), and its base count
+        import test_pack_cpu as tp
+        ec, eb = tp.expect(exp)
+        want, want_bases = content(ec, eb), len(exp) - exp.count(b"\n")
+        for batch, thr in ((64 << 20, 1), (64 << 20, 3), (64 << 20, 8), (40 << 20, 2)):
+            for env in ({}, {"QM2_READER_STREAM": "1"}):
+                outp = str(tmp_path / "packed.bin")
+                subprocess.run([exe, str(p), outp, str(batch), str(thr), "packed"], check=True, env=dict(os.environ, **env))
+                got, got_bases = packed_content(open(outp, "rb").read())
+                assert got_bases == want_bases, (name, thr, env)
+                assert got[2] == want[2] and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (name, thr, env)
+        # raw hand-over (QM2_READER=raw): blocks of untouched text + the line state at their
         # first byte; applying the device's rule (tests restate it here) to each block must give `exp`
         if name not in ("fq_desync", "gt_in_fastq_seq_pos"):
             for batch, thr in ((64 << 20, 1), (64 << 20, 3), (64 << 20, 8)):
@@ -215,9 +261,9 @@ int main(int argc, char **argv) {
   int n = atoi(argv[2]); size_t turn = (size_t)atol(argv[3]); Sink S[8]; qm2_sink sinks[8]; char name[512];
   LOG = fopen(argv[4], "w");
   for (int i = 0; i < n; i++) { snprintf(name, sizeof name, "%s.%d", argv[4], i); S[i].id = i; S[i].f = fopen(name, "wb"); S[i].lent = S[i].flushes = S[i].bytes = 0;
-    sinks[i].acquire = acq; sinks[i].commit = com; sinks[i].submit = sub; sinks[i].flush = flu; sinks[i].user = &S[i]; sinks[i].commit_raw = NULL; }
+    sinks[i].acquire = acq; sinks[i].commit = com; sinks[i].submit = sub; sinks[i].flush = flu; sinks[i].user = &S[i]; sinks[i].commit_raw = NULL; sinks[i].commit_packed = NULL; }
   qm2_dispatch *d = qm2_dispatch_new(sinks, n, turn);
-  qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, d, NULL};
+  qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, d, NULL, NULL};
   int rc = qm2_stream_reads(argv[1], &out, atoi(argv[5]));
   qm2_dispatch_free(d);
   for (int i = 0; i < n; i++) { if (S[i].lent) rc = 3; fclose(S[i].f); }
@@ -225,7 +271,7 @@ int main(int argc, char **argv) {
 ''')
     exe = str(tmp_path / "d")
     subprocess.run(["gcc", "-O1", "-pthread", "-I", src, "-o", exe, str(harness), os.path.join(src, "qm2_reader.c"),
-                    os.path.join(src, "qm2_dispatch.c")], check=True)
+                    os.path.join(src, "qm2_dispatch.c"), os.path.join(src, "qm2_pack.c")], check=True)
     import oracle_lib as ol
     import synth
     fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
@@ -279,10 +325,10 @@ int main(int argc, char **argv) {
   int n = atoi(argv[2]); Sink S[8]; qm2_sink sinks[8]; char name[512];
   LOG = fopen(argv[4], "w"); snprintf(name, sizeof name, "%s.data", argv[4]); DATA = fopen(name, "wb");
   for (int i = 0; i < n; i++) { S[i].id = i; S[i].lent = 0;
-    sinks[i].acquire = acq; sinks[i].commit = com; sinks[i].submit = sub; sinks[i].flush = flu; sinks[i].user = &S[i]; sinks[i].commit_raw = raw; }
+    sinks[i].acquire = acq; sinks[i].commit = com; sinks[i].submit = sub; sinks[i].flush = flu; sinks[i].user = &S[i]; sinks[i].commit_raw = raw; sinks[i].commit_packed = NULL; }
   qm2_dispatch *d = qm2_dispatch_new(sinks, n, 1);
   qm2_dispatch_raw_turn(d, (size_t)atol(argv[3]));
-  qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, d, qm2_dispatch_commit_raw};
+  qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, d, qm2_dispatch_commit_raw, NULL};
   int rc = qm2_stream_reads(argv[1], &out, atoi(argv[5]));
   qm2_dispatch_free(d);
   for (int i = 0; i < n; i++) if (S[i].lent) rc = 3;
@@ -290,7 +336,7 @@ int main(int argc, char **argv) {
 ''')
     exe = str(tmp_path / "r")
     subprocess.run(["gcc", "-O1", "-pthread", "-I", src, "-o", exe, str(harness), os.path.join(src, "qm2_reader.c"),
-                    os.path.join(src, "qm2_dispatch.c")], check=True)
+                    os.path.join(src, "qm2_dispatch.c"), os.path.join(src, "qm2_pack.c")], check=True)
     import oracle_lib as ol
     import synth
     fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))

@@ -33,6 +33,8 @@ def emul():
     L.qm2e_extract.restype = C.c_uint64
     L.qm2e_extract.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint, C.c_void_p,
                                C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.qm2e_extract_packed.restype = C.c_uint64
+    L.qm2e_extract_packed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.qm2e_djb32.restype = C.c_uint32
     L.qm2e_djb32.argtypes = [C.c_uint64]
     _L = L
@@ -46,6 +48,32 @@ def emul_extract(blob, k, staging=1 << 20, misalign=0):
     out = np.empty(cap, dtype=np.uint64)
     n = L.qm2e_extract(blob, len(blob), k, staging, misalign, out.ctypes.data, cap, C.byref(nb), C.byref(npart))
     return out[:n], int(nb.value), int(npart.value)
+
+
+def product():
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ol.ROOT, "quick-mer2_amd", "libqm2_hip.so")):
+        ge.build()
+    return ge.load_package()
+
+
+def emul_extract_packed(blob, k, reads=None):
+    """The product's host packer (qm2_pack_lines, or qm2_pack_reads on raw text with reads = (fastq, skip)), then the
+    product's device-side reading of the blocks, lane by lane on the CPU -> (k-mers, n_bases as the library reports it)."""
+    P = product().pyqm2
+    if reads is None:
+        blocks, p, wraps = P.pack_lines(blob, wraps_cap=1 << 12)
+    else:
+        blocks, p, wraps, _ = P.pack_reads(blob, reads[0], reads[1], wraps_cap=1 << 12)
+    L = emul()
+    cap = 64 * int(p.n_blocks) + 16
+    out = np.empty(cap, dtype=np.uint64)
+    npos = C.c_uint64(0)
+    blocks = np.ascontiguousarray(blocks)
+    wraps = np.ascontiguousarray(wraps, dtype=np.uint64)
+    n = L.qm2e_extract_packed(blocks.ctypes.data if len(blocks) else None, int(p.n_blocks), k, wraps.ctypes.data if len(wraps) else None, len(wraps),
+                              out.ctypes.data, cap, C.byref(npos))
+    return out[:n], int(npos.value) - int(p.n_newlines)
 
 
 def fuzz_blob(seed, n_lines=300, maxlen=400):
@@ -110,6 +138,57 @@ def test_long_lines_uint16_wrap(k):
     for staging in (1 << 22, 40000):
         got, nb, _ = emul_extract(blob, k, staging, 0)
         assert nb == exp_nb and np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("k", [30, 1, 12, 25, 29, 31])
+def test_packed_stream_equals_oracle(k):
+    """host packer -> the device's reading of packed input == the oracle's k-mer stream and base count"""
+    for seed in range(3):
+        blob = fuzz_blob(100 * k + seed)
+        exp, exp_nb = ol.extract(blob, k)
+        got, nb = emul_extract_packed(blob, k)
+        assert nb == exp_nb and np.array_equal(got, exp), (k, seed)
+    for blob in (b"", b"\n", b"\n\n\n", b"A\n", b"ACGT\n" * 3, b"N" * 100 + b"\n", synth.kat_reference().tobytes()[:30] + b"\n",
+                 synth.kat_reference().tobytes()[:29] + b"\n" + synth.kat_reference().tobytes()[:31] + b"\n",
+                 synth.kat_reference().tobytes()[:63] + b"\n", synth.kat_reference().tobytes()[:64] + b"\n"):
+        exp, exp_nb = ol.extract(blob, k)
+        got, nb = emul_extract_packed(blob, k)
+        assert nb == exp_nb and np.array_equal(got, exp), (k, blob[:20])
+
+
+@pytest.mark.parametrize("k", [30, 25, 31])
+def test_packed_long_lines_uint16_wrap(k):
+    tile = synth.kat_reference().tobytes()
+    for L in (65535, 65536, 65537, 65566, 70000, 131100):
+        s = (tile * (L // len(tile) + 1))[:L]
+        blob = b"ACGT\n" + s + b"\n" + tile[:100] + b"\n"
+        exp, exp_nb = ol.extract(blob, k)
+        got, nb = emul_extract_packed(blob, k)
+        assert nb == exp_nb and np.array_equal(got, exp), (k, L)
+        got, nb = emul_extract_packed(b">h\n" + blob + b">t\n", k, reads=(False, 0))       # the same through the line discipline
+        assert nb == exp_nb and np.array_equal(got, exp), (k, L)
+    s = bytearray((tile * 60)[:250000])
+    for p in (1234, 70000, 70001, 135535, 200000):
+        s[p] = ord("N")
+    blob = bytes(s) + b"\n" + bytes(s[:66000]) + b"\n"
+    exp, exp_nb = ol.extract(blob, k)
+    got, nb = emul_extract_packed(blob, k)
+    assert nb == exp_nb and np.array_equal(got, exp)
+
+
+def test_packed_reads_of_the_kat_files():
+    """raw FASTA / FASTQ vectors -> qm2_pack_reads -> the device's reading == the oracle on the oracle's own strip"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fa, ctrl, rfa, rfq = synth.mini_inputs(td)
+        for path in (rfa, rfq):
+            text = open(path, "rb").read()
+            fastq = text[:1] == b"@"
+            body = text[text.index(b"\n") + 1:] if fastq else text
+            for k in (30, 25):
+                exp, exp_nb = ol.extract(ol.strip_reads(path), k)
+                got, nb = emul_extract_packed(body, k, reads=(fastq, 0))
+                assert nb == exp_nb and np.array_equal(got, exp), (path, k)
 
 
 def test_edges():

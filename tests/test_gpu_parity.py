@@ -47,21 +47,24 @@ def kat_qm(setname="kat"):
 
 
 def check_against_oracle(qm2, keys, k, lines, partition_available=True, **kw):
-    """Both pipelines (direct kernel; partitioned: radix split + LDS probe/count) vs the oracle."""
+    """Both pipelines (direct kernel; partitioned: radix split + LDS probe/count) vs the oracle, and both forms the text
+    crosses the link in: packed by qm2_submit on the way into the pinned buffers (its default since ABI 6: the kernels'
+    PK instantiations read 2-bit codes + reset flags) and as the caller's ASCII (QM2_FLAG_SUBMIT_ASCII)."""
     exp_depth, exp_st = ol.count_lines(keys, k, lines)
     for flags in (qm2.FLAG_DIRECT, qm2.FLAG_PARTITION):
-        with qm2.Counter(keys, k=k, flags=flags | qm2.FLAG_TIMING, **kw) as c:
-            c.submit(lines)
-            depth, st = c.finish()
-            prof = c.profile()
-        assert st == exp_st, flags
-        assert np.array_equal(depth, exp_depth), flags
-        if len(lines) > 64:
-            if flags == qm2.FLAG_PARTITION and partition_available:
-                assert prof["partitioned_batches"] > 0 and prof["direct_batches"] == 0
-                assert prof["class_launches"]["bucket_count"] > 0
-            elif flags == qm2.FLAG_DIRECT or not partition_available:
-                assert prof["partitioned_batches"] == 0 and prof["class_launches"]["count_direct"] > 0
+        for form in (0, qm2.FLAG_SUBMIT_ASCII):
+            with qm2.Counter(keys, k=k, flags=flags | form | qm2.FLAG_TIMING, **kw) as c:
+                c.submit(lines)
+                depth, st = c.finish()
+                prof = c.profile()
+            assert st == exp_st, (flags, form)
+            assert np.array_equal(depth, exp_depth), (flags, form)
+            if len(lines) > 64:
+                if flags == qm2.FLAG_PARTITION and partition_available:
+                    assert prof["partitioned_batches"] > 0 and prof["direct_batches"] == 0
+                    assert prof["class_launches"]["bucket_count"] > 0
+                elif flags == qm2.FLAG_DIRECT or not partition_available:
+                    assert prof["partitioned_batches"] == 0 and prof["class_launches"]["count_direct"] > 0
     return st
 
 
@@ -104,14 +107,16 @@ def test_cli_matches_reference_vectors(setname, name, tmp_path):
     assert txt.rstrip().endswith("Exit quicK-mer2 count")
 
 
-@pytest.mark.parametrize("raw", ["1", "0"])
-def test_cli_raw_and_host_line_discipline(raw, tmp_path):
-    """The CLI's default for regular files: the host only preads, the device does the line discipline
-    (SURVEY 8(f) f3); QM2_READER_RAW=0: stripped on the host.  Every k = 30 reference vector must come
-    out byte-identical both ways; an input the device path refuses must silently go round again through
+@pytest.mark.parametrize("mode", ["packed", "raw", "lines"])
+def test_cli_raw_and_host_line_discipline(mode, tmp_path):
+    """The three ways the CLI's input reaches the device (QM2_READER): packed (the default: the reader threads strip and
+    pack, 0.375 bytes per base over the link), raw (regular files: the host only preads, the device does the line
+    discipline), lines (stripped to ASCII on the host).  Every k = 30 reference vector must come
+    out byte-identical all three ways; an input the device line discipline refuses must silently go round again through
     the host path."""
     refused = []
-    env = dict(os.environ, QM2_READER_RAW=raw, QM2_TIMING="1")
+    raw = "1" if mode == "raw" else "0"
+    env = dict(os.environ, QM2_READER=mode, QM2_TIMING="1")
     for name, c in MAN["sets"]["kat"]["cases"].items():
         rp = _reads_path("kat", name, str(tmp_path))
         out = str(tmp_path / ("raw_" + name))
@@ -122,6 +127,7 @@ def test_cli_raw_and_host_line_discipline(raw, tmp_path):
         assert "total %d kmers" % c["n_kmers"] in txt, name
         assert open(out + ".bin", "rb").read() == open(os.path.join(GOLD, "kat", name + ".bin"), "rb").read(), name
         assert md5_file(out + ".txt") == c["txt_md5"], name
+        assert {"packed": "input packed on the host", "raw": "input raw text", "lines": "input ASCII lines"}[mode] in txt, txt
         if "raw input refused" in txt:
             refused.append(name)
     assert not refused, refused             # long lines included: the device keeps its own wrap list
@@ -166,25 +172,41 @@ def test_cli_mini_fasta_fastq_and_pipe(tmp_path):
         assert md5_file(out + ".bin") == m["bin_md5"] and md5_file(out + ".txt") == m["txt_md5"]
         assert ("total %d kmers" % m["n_kmers"]).encode() in r.stdout
     # stdin pipe, the README's usage (samtools ... | quicKmer2 count ref /dev/fd/0 out)
-    out = str(tmp_path / "pipe")
-    with open(rfq, "rb") as f:
-        r = subprocess.run([CLI, "count", "-t", "4", ref_prefix, "/dev/fd/0", out], stdin=f,
-                           stdout=subprocess.PIPE, timeout=300)
-    assert r.returncode == 0 and md5_file(out + ".bin") == m["bin_md5"]
+    # ... through a REAL pipe (a regular file on stdin is seekable: that is the path above), FASTQ and FASTA (whose
+    # first line the reference loses on a pipe, QuicKmer.c:396: the rewind fails), packed by the reader threads and as lines
+    for tag, reads in (("fq", rfq), ("fa", rfa)):
+        qm = ol.load_qm(ref_prefix + ".qm")
+        exp_depth, exp_st = ol.count_lines(qm["keys"], 30, ol.strip_reads(reads, seekable=False))
+        exp_bin = exp_depth[ol.chain_order(qm)].astype("<u2").tobytes()
+        for mode in ("packed", "lines"):
+            out = str(tmp_path / ("pipe_%s_%s" % (tag, mode)))
+            cat = subprocess.Popen(["cat", reads], stdout=subprocess.PIPE)
+            r = subprocess.run([CLI, "count", "-t", "4", ref_prefix, "/dev/fd/0", out], stdin=cat.stdout, env=dict(os.environ, QM2_READER=mode, QM2_TIMING="1"),
+                               stdout=subprocess.PIPE, timeout=300)
+            cat.stdout.close()
+            assert cat.wait() == 0 and r.returncode == 0, r.stdout.decode(errors="replace")
+            assert ("total %d kmers" % exp_st["n_kmers"]).encode() in r.stdout
+            assert open(out + ".bin", "rb").read() == exp_bin, (tag, mode)
+            if tag == "fq":
+                assert md5_file(out + ".bin") == m["bin_md5"]
+            assert (b"input packed on the host" in r.stdout) == (mode == "packed")
 
 
 def test_cli_devices_two_contexts_sum_to_the_reference(tmp_path):
     """`quicKmer2 count --devices 0,0`: two replicas of the dictionary (here on the one GPU of the box), one
     reader, the input dealt to the contexts in turns (small ones, so that all of them really count), the
     counters summed into the first before the epilogue: .bin / .txt are the reference's own, stdout too.
-    Regular files go to the contexts as RAW blocks (line discipline on the devices, turns of consecutive blocks);
-    `-t 0` and QM2_READER_RAW=0 strip on the host and deal bytes."""
+    By default the reader threads pack what they strip and the pieces are dealt in turns of positions; QM2_READER=raw
+    sends regular files to the contexts as RAW blocks (line discipline on the devices, turns of consecutive blocks);
+    `-t 0` and QM2_READER=lines strip on the host and deal bytes."""
     m = MAN["sets"]["mini"]
     fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
     ref_prefix = os.path.join(GOLD, "mini", "ref.fa")
     small = dict(os.environ, QM2_TURN_BYTES="100000", QM2_BLOCK_BYTES="16384", QM2_TURN_BLOCKS="3", QM2_TIMING="1")
     for tag, reads, devs, thr, env in (("fa", rfa, "0,0", "2", small), ("fq", rfq, "0,0,0", "0", small), ("one", rfq, "0", "4", small),
-                                       ("fq_raw", rfq, "0,0,0", "3", small), ("fq_host", rfq, "0,0", "3", dict(small, QM2_READER_RAW="0")),
+                                       ("fq_packed", rfq, "0,0,0", "3", small), ("fa_packed", rfa, "0,0", "4", dict(small, QM2_READER="packed")),
+                                       ("fq_raw", rfq, "0,0,0", "3", dict(small, QM2_READER="raw")), ("fa_raw", rfa, "0,0", "2", dict(small, QM2_READER="raw")),
+                                       ("fq_host", rfq, "0,0", "3", dict(small, QM2_READER_RAW="0")),
                                        ("fq_default_turns", rfq, "0,0", "2", dict(os.environ, QM2_TIMING="1")),
                                        # (the replicas of distinct GPUs are loaded by one thread each: forced here on the one GPU)
                                        ("fq_threaded_loaders", rfq, "0,0,0", "3", dict(small, QM2_LOAD_THREADS="1")),
@@ -206,13 +228,14 @@ def test_cli_devices_two_contexts_sum_to_the_reference(tmp_path):
     p = tmp_path / "desync.fq"
     p.write_bytes(b"".join(recs))
     out = str(tmp_path / "desync")
-    r = subprocess.run([CLI, "count", "-t", "3", "--devices", "0,0", os.path.join(GOLD, "kat", "ref.fa"), str(p), out], env=small,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-    assert r.returncode == 0, r.stdout
-    assert b"raw input refused" in r.stdout
     exp_depth, exp_st = ol.count_lines(kat_qm()["keys"], 30, ol.strip_reads(str(p)))
-    assert ("total %d kmers" % exp_st["n_kmers"]).encode() in r.stdout
-    assert open(out + ".bin", "rb").read() == exp_depth[ol.chain_order(kat_qm())].astype("<u2").tobytes()
+    for mode in ("raw", "packed"):      # (packed: the reader sees the line itself and finishes the file serially)
+        r = subprocess.run([CLI, "count", "-t", "3", "--devices", "0,0", os.path.join(GOLD, "kat", "ref.fa"), str(p), out], env=dict(small, QM2_READER=mode),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0, r.stdout
+        assert (b"raw input refused" in r.stdout) == (mode == "raw")
+        assert ("total %d kmers" % exp_st["n_kmers"]).encode() in r.stdout
+        assert open(out + ".bin", "rb").read() == exp_depth[ol.chain_order(kat_qm())].astype("<u2").tobytes()
     # bad ordinals are refused, not read as device 0
     for devs in ("0,x", "-1", "0,,1x"):
         r = subprocess.run([CLI, "count", "--devices", devs, ref_prefix, rfq, str(tmp_path / "bad")], stdout=subprocess.PIPE, timeout=60)
@@ -426,7 +449,8 @@ def test_batch_boundaries_do_not_matter(qm2, staging, tmp_path):
         p.write_bytes(cases[name][1])
         blob += ol.strip_reads(str(p))
     exp_depth, exp_st = ol.count_lines(qm["keys"], 30, blob)
-    for flags in (qm2.FLAG_DIRECT, qm2.FLAG_PARTITION):
+    for flags in (qm2.FLAG_DIRECT, qm2.FLAG_PARTITION, qm2.FLAG_DIRECT | qm2.FLAG_SUBMIT_ASCII, qm2.FLAG_PARTITION | qm2.FLAG_SUBMIT_ASCII):
+        # (packed, the default: the lines longer than a staging buffer's worth of positions go the ASCII way in between)
         for batch in (staging, 3 * staging + 17, 1 << 22):
             with qm2.Counter(qm["keys"], k=30, staging_bytes=staging, n_staging=2, batch_bytes=batch,
                              flags=flags) as c:
@@ -509,6 +533,68 @@ def test_fuzz_arbitrary_bytes(qm2):
     blob = b"".join(parts)
     for k, setname in ((30, "kat"), (25, "kat_k25")):
         check_against_oracle(qm2, kat_qm(setname)["keys"], k, blob, staging_bytes=8192)
+
+
+def test_packed_entry_points(qm2, torch_cuda, tmp_path):
+    """ABI 6, include/qm2.h "packed sequence": pieces packed by the caller (qm2_pack_lines) and committed through the pinned
+    buffers (qm2_staging_commit_packed: any piece size, pieces collect in device batches, run-counter wraps of long lines as
+    positions), the same blocks handed over in device memory (qm2_submit_packed_device), mixed with ASCII and raw entry
+    points on one context — every time the oracle's counters and statistics."""
+    torch = torch_cuda
+    qm = kat_qm()
+    cases = synth.kat_cases(synth.kat_reference())
+    blob = b""
+    for name in ("reads_fa", "long70000", "long_with_N", "polyA", "junk_bytes", "short_reads", "crlf"):
+        p = tmp_path / (name + ".fa")
+        p.write_bytes(cases[name][1])
+        blob += ol.strip_reads(str(p))
+    for k, setname in ((30, "kat"), (25, "kat_k25")):
+        keys = kat_qm(setname)["keys"]
+        exp_depth, exp_st = ol.count_lines(keys, k, blob)
+        for flags in (qm2.FLAG_DIRECT, qm2.FLAG_PARTITION):
+            # through the pinned buffers, pieces of every size; batches smaller and larger than a piece
+            for piece, batch in ((None, 1 << 22), (100_000, 1 << 18), (80_000, 3 << 20), (300_000, 1 << 19)):
+                with qm2.Counter(keys, k=k, flags=flags, staging_bytes=1 << 20, n_staging=3, batch_bytes=batch) as c:
+                    c.submit_packed(blob, piece=piece)
+                    depth, st = c.finish()
+                assert st == exp_st and np.array_equal(depth, exp_depth), (k, flags, piece, batch)
+            # already on the device
+            blocks, p, wraps = qm2.pack_lines(blob)
+            assert p.n_wraps > 0
+            d_blocks = torch.from_numpy(blocks.view(np.int64).copy()).cuda()
+            d_wraps = torch.from_numpy(wraps.view(np.int64).copy()).cuda()
+            with qm2.Counter(keys, k=k, flags=flags) as c:
+                c.submit_packed_device(d_blocks.data_ptr(), p, d_wraps.data_ptr())
+                depth, st = c.finish()
+            assert st == exp_st and np.array_equal(depth, exp_depth), (k, flags)
+            # the entry points mix on one context: packed pieces, ASCII lines, packed again, device text
+            cut = blob.find(b"\n", len(blob) // 3) + 1
+            cut2 = blob.find(b"\n", 2 * len(blob) // 3) + 1
+            d_text = torch.frombuffer(bytearray(blob[cut2:]), dtype=torch.uint8).cuda()
+            with qm2.Counter(keys, k=k, flags=flags | qm2.FLAG_SUBMIT_ASCII, staging_bytes=1 << 20, n_staging=3) as c:
+                c.submit_packed(blob[:cut], piece=50_000)
+                c.submit(blob[cut:cut2])
+                c.submit_packed(blob[:cut], piece=70_000)
+                c.sync()
+                wr = ol_wraps(blob[cut2:])
+                d_wr = torch.tensor(wr, dtype=torch.int64).cuda() if wr else None
+                c.submit_device(d_text.data_ptr(), len(blob) - cut2, d_wr.data_ptr() if wr else None, len(wr))
+                depth, st = c.finish()
+            e2, s2 = ol.count_lines(keys, k, blob + blob[:cut])
+            assert st == s2 and np.array_equal(depth, e2), (k, flags)
+    # bad arguments fail loudly
+    with qm2.Counter(qm["keys"], k=30) as c:
+        pk = qm2.Packed(1, 65, 0)
+        with pytest.raises(qm2.Qm2Error):
+            c.submit_packed_device(d_blocks.data_ptr(), pk)
+        with pytest.raises(qm2.Qm2Error):
+            c.submit_packed_device(d_blocks.data_ptr() + 8, qm2.Packed(1, 0, 0))
+
+
+def ol_wraps(lines: bytes):
+    """the positions where the reference's uint16 run counter wraps (qm2_plan.h find_wraps), for qm2_submit_device"""
+    import test_pack_cpu as tp
+    return tp.model_wraps(lines)
 
 
 def test_zero_copy_staging_and_cli_threads(qm2, tmp_path):

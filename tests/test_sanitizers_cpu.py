@@ -27,7 +27,7 @@ HARNESS = r'''
 #include <string.h>
 #include "qm2_dispatch.h"
 #include "qm2_host.h"
-/* argv: reads, n_sinks, strip threads, out prefix, "raw" | "host", blocks per raw turn / bytes per host turn */
+/* argv: reads, n_sinks, strip threads, out prefix, "raw" | "host" | "packed", blocks per raw turn / bytes (positions) per host (packed) turn */
 typedef struct { int id; long lent; FILE *f; } Sink;
 static size_t CAP = 1 << 18;
 static int acq(void *u, char **b, size_t *c) { Sink *s = u; *c = CAP; *b = malloc(*c + 8); if (!*b) return 1; memcpy(*b, &s->id, sizeof s->id); *b += 8; s->lent++; return 0; }
@@ -37,14 +37,21 @@ static int raw(void *u, char *b, size_t off, size_t n, int fastq, unsigned skip)
   unsigned hdr[3] = {(unsigned)n, (unsigned)fastq, skip}; if (n) { fwrite(hdr, 4, 3, s->f); fwrite(b + off, 1, n, s->f); } s->lent--; free(b - 8); return 0; }
 static int sub(void *u, const char *p, size_t n) { Sink *s = u; fwrite(p, 1, n, s->f); return 0; }
 static int flu(void *u) { Sink *s = u; const unsigned mark[3] = {0xFFFFFFFFu, 0, 0}; fwrite(mark, 4, 3, s->f); return 0; }
+/* packed mode: every piece framed — {0xFFFFFFFE, blocks, line ends + filler} + blocks, or {0xFFFFFFFD, bytes, 0} + ASCII lines */
+static int pk(void *u, char *b, const qm2_packed *p, const uint64_t *w) { Sink *s = u; (void)w; if (own(s, b)) return 1;
+  unsigned hdr[3] = {0xFFFFFFFEu, (unsigned)p->n_blocks, (unsigned)p->n_newlines}; fwrite(hdr, 4, 3, s->f); fwrite(b, 24, p->n_blocks, s->f); s->lent--; free(b - 8); return 0; }
+static int com_f(void *u, char *b, size_t n) { Sink *s = u; if (own(s, b)) return 1; unsigned hdr[3] = {0xFFFFFFFDu, (unsigned)n, 0};
+  if (n) { fwrite(hdr, 4, 3, s->f); fwrite(b, 1, n, s->f); } s->lent--; free(b - 8); return 0; }
+static int sub_f(void *u, const char *p, size_t n) { Sink *s = u; unsigned hdr[3] = {0xFFFFFFFDu, (unsigned)n, 0}; fwrite(hdr, 4, 3, s->f); fwrite(p, 1, n, s->f); return 0; }
 int main(int argc, char **argv) {
   if (argc < 7) return 9;
-  const int n = atoi(argv[2]), is_raw = strcmp(argv[5], "raw") == 0; Sink S[8]; qm2_sink sinks[8]; char name[600];
+  const int n = atoi(argv[2]), is_raw = strcmp(argv[5], "raw") == 0, is_packed = strcmp(argv[5], "packed") == 0; Sink S[8]; qm2_sink sinks[8]; char name[600];
   for (int i = 0; i < n; i++) { snprintf(name, sizeof name, "%s.%d", argv[4], i); S[i].id = i; S[i].lent = 0; S[i].f = fopen(name, "wb");
-    sinks[i].acquire = acq; sinks[i].commit = com; sinks[i].submit = sub; sinks[i].flush = flu; sinks[i].user = &S[i]; sinks[i].commit_raw = is_raw ? raw : NULL; }
+    sinks[i].acquire = acq; sinks[i].commit = is_packed ? com_f : com; sinks[i].submit = is_packed ? sub_f : sub; sinks[i].flush = flu; sinks[i].user = &S[i];
+    sinks[i].commit_raw = is_raw ? raw : NULL; sinks[i].commit_packed = is_packed ? pk : NULL; }
   qm2_dispatch *d = qm2_dispatch_new(sinks, n, is_raw ? 1 : (size_t)atol(argv[6]));
   if (is_raw) qm2_dispatch_raw_turn(d, (size_t)atol(argv[6]));
-  qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, d, is_raw ? qm2_dispatch_commit_raw : NULL};
+  qm2_lines_out out = {qm2_dispatch_acquire, qm2_dispatch_commit, qm2_dispatch_submit, d, is_raw ? qm2_dispatch_commit_raw : NULL, is_packed ? qm2_dispatch_commit_packed : NULL};
   int rc = qm2_stream_reads(argv[1], &out, atoi(argv[3]));
   qm2_dispatch_free(d);
   for (int i = 0; i < n; i++) { if (S[i].lent) rc = 3; fclose(S[i].f); }
@@ -109,7 +116,7 @@ def test_reader_and_dispatcher_under_sanitizers(san, tmp_path):
     harness.write_text(HARNESS)
     exe = str(tmp_path / "h")
     subprocess.run(["gcc", "-O1", "-g", "-pthread"] + flags + ["-I", SRC, "-o", exe, str(harness), os.path.join(SRC, "qm2_reader.c"),
-                    os.path.join(SRC, "qm2_dispatch.c")], check=True)
+                    os.path.join(SRC, "qm2_dispatch.c"), os.path.join(SRC, "qm2_pack.c")], check=True)
     fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
     # ragged FASTQ: line lengths from 0 to 400 (empty sequence lines too), N's, no final newline
     rng = np.random.default_rng(5)
@@ -124,14 +131,44 @@ def test_reader_and_dispatcher_under_sanitizers(san, tmp_path):
         exp = ol.strip_reads(path)
         exp_lines = sorted(exp.split(b"\n"))
         for n_sinks, thr, mode, turn, block in ((2, 4, "raw", 3, 8192), (3, 8, "raw", 1, 4096), (1, 3, "raw", 4, 65536),
-                                                (2, 4, "host", 20000, 16384), (3, 0, "host", 5000, 8192), (1, 6, "host", 1 << 30, 4096)):
+                                                (2, 4, "host", 20000, 16384), (3, 0, "host", 5000, 8192), (1, 6, "host", 1 << 30, 4096),
+                                                (1, 5, "packed", 1 << 30, 8192), (3, 4, "packed", 30000, 4096), (2, 8, "packed", 5000, 16384)):
             out = str(tmp_path / "o")
             r = subprocess.run([exe, path, str(n_sinks), str(thr), out, mode, str(turn)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                env=dict(os.environ, QM2_BLOCK_BYTES=str(block), **env), timeout=600)
             assert r.returncode == 0, (san, path, mode, r.stderr.decode()[-3000:])
             assert b"Sanitizer" not in r.stderr and b"runtime error" not in r.stderr, r.stderr.decode()[-3000:]
             parts = [open("%s.%d" % (out, i), "rb").read() for i in range(n_sinks)]
-            if mode == "raw" and thr > 0:
+            if mode == "packed":
+                # pieces of 2-bit codes + reset flags (qm2_pack.c on the worker threads): every sink's positions together
+                # hold the stripped stream's bases; with one sink, in order: the same codes between the same resets
+                import test_pack_cpu as tp
+                bases, codes, bad = 0, [], []
+                for blob in parts:
+                    at = 0
+                    while at < len(blob):
+                        tag, a, b = (int(x) for x in np.frombuffer(blob, dtype=np.uint32, count=3, offset=at))
+                        at += 12
+                        if tag == 0xFFFFFFFF:
+                            continue
+                        if tag == 0xFFFFFFFE:
+                            c, r = tp.unpack(np.frombuffer(blob, dtype=np.uint64, count=3 * a, offset=at))
+                            at += 24 * a
+                            bases += 64 * a - b
+                        else:
+                            assert tag == 0xFFFFFFFD
+                            c, r = tp.expect(blob[at:at + a])
+                            bases += a - blob[at:at + a].count(b"\n")
+                            at += a
+                        codes.append(c)
+                        bad.append(r)
+                assert bases == len(exp) - exp.count(b"\n"), (san, path, n_sinks, thr)
+                if n_sinks == 1:
+                    ec, eb = tp.expect(exp)
+                    c, r = np.concatenate(codes), np.concatenate(bad)
+                    good, egood = np.flatnonzero(~r), np.flatnonzero(~eb)
+                    assert np.array_equal(c[good], ec[egood]) and np.array_equal(np.diff(good) > 1, np.diff(egood) > 1)
+            elif mode == "raw" and thr > 0:
                 got = [l for p in parts for l in device_rule(p)]
                 assert sorted(got + [b""]) == exp_lines, (san, path, n_sinks, thr)
             else:

@@ -4,7 +4,7 @@
 # Everything is written under gpurun_out/<tag>/ (tag = $QM2_TAG, default r04); what is to be kept goes to profiles/ by hand.
 # Every GPU step runs under its own `timeout -k 10`; a step that times out stops the recipe (no further GPU step).
 set -u
-TAG=${QM2_TAG:-r04}
+TAG=${QM2_TAG:-r05}
 O=gpurun_out/$TAG
 mkdir -p "$O"
 export TMPDIR=/tmp
