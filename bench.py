@@ -41,6 +41,54 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "quick-mer2_amd"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# VALU issue: a wave64 instruction occupies a SIMD's 16 lanes for 4 cycles; 4 SIMDs per CU (MI355X_MICROARCH.md)
+VALU_WAVE_INSTS_PER_CU_CYCLE = 1.0
+
+
+def kernel_source_sha16():
+    """Identifies the kernels a PMC file was measured on: sha256 over the device sources of libqm2_hip.so (16 hex digits).
+    tools/summarize_profile.py stamps profiles/traffic_<workload>.json with it; a bench line only quotes the file's
+    counters (roofline.traffic, roofline.valu) when the stamp is that of the tree it runs from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "quick-mer2_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.hip.h")) + [os.path.join(src, "qm2_plan.h")]):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(gpus, json_out):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start N ranks of this very script under
+    torch.distributed.run as a CHILD process (nothing here has touched the GPU yet, and nothing will), relay the one JSON
+    line rank 0 prints and the exit code.  (The reference's own N-way split is its worker pool, QuicKmer.c:368-384.)"""
+    import shlex
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    launcher = shlex.split(os.environ["QM2_BENCH_LAUNCHER"]) if os.environ.get("QM2_BENCH_LAUNCHER") else [sys.executable, "-m", "torch.distributed.run"]
+    cmd = launcher + ["--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                      os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without a rank environment: starting %s\n" % (gpus, " ".join(cmd)))
+    pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    line = None
+    for raw in pr.stdout:
+        txt = raw.decode(errors="replace")
+        if txt.startswith("{"):
+            line = txt
+        else:
+            sys.stderr.write(txt)
+    rc = pr.wait()
+    if line is not None:
+        json_out.write(line if line.endswith("\n") else line + "\n")
+        json_out.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks printed no JSON line\n")
+        rc = 1
+    return rc
 
 WORKLOADS = {
     "c2": dict(genome=50_818_468, lgH=28, reads=10_000_000, len_lo=150, len_hi=150, sub=0.005,
@@ -410,6 +458,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-binary", action="store_true", help="CPU leg: the oracle port only")
     ap.add_argument("--no-streamed", action="store_true", help="skip the host-fed (PCIe-inclusive) regions")
+    ap.add_argument("--no-random-access", action="store_true", help="skip the random-access microbenchmark (roofline.random_access)")
     ap.add_argument("--no-geometry-check", action="store_true",
                     help="skip the partitioned-vs-direct comparison of all counters at the benchmarked batch geometry")
     ap.add_argument("--streamed-steps", type=int, default=4, help="steps of the ASCII host-fed regions; the packed ones take twice as many (the same seconds)")
@@ -432,6 +481,16 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "partition"],
                     help="count pipeline: auto = chosen per batch from its size vs. H")
     args = ap.parse_args()
+
+    # --gpus N is the number of ranks.  Under torch.distributed.run (the driver's form for N > 1) the environment says the
+    # same; without it, N > 1 starts the ranks itself; anything else is a mistake that must not print a 1-GPU line.
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, json_out))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: the launcher's rank count and --gpus disagree"
+                         % (args.gpus, os.environ.get("WORLD_SIZE")))
 
     import numpy as np
     import torch
@@ -655,7 +714,8 @@ def main():
     levels_kmer = (cls_n["split_kmer"] // max(1, part_batches)) if part_batches else 0
     # bytes each kernel class must move over the timed region by ITS OWN model
     # (the finest level and the table pass hold bucket records, DESIGN.md section 3: 6 bytes from 2^30 slots on, else 8)
-    rec = 6 if H >= (1 << 30) else 8
+    # (qm2_device.hip.h rec_ext_bits: slot bits 12 + 2 code bits + the hash bits above log2 H (+ 2 per base beyond 30) fit 16)
+    rec = 6 if 12 + 2 + (32 - wl["lgH"]) + (2 * (k - 30) if k > 30 else 0) <= 16 else 8
     alg = {
         "count_direct": b_survey if part_batches == 0 else 0,
         # text in, k-mers out (records, when the text level is the finest one)
@@ -668,14 +728,22 @@ def main():
     }
     # HBM bytes per launch measured by PMC counters: written by tools/summarize_profile.py from the rocprofv3
     # passes named in the file (profiles/<round>_<workload>/); absent = null
-    traffic_step, traffic_src, traffic_k = None, None, {}
+    traffic_step, traffic_src, traffic_k, valu_k, lds_k, traffic_stale = None, None, {}, {}, {}, None
     tr_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tr_file):
         try:
             tj = json.load(open(tr_file))
-            traffic_k = {c: v.get("hbm_bytes_per_launch") for c, v in tj.get("per_kernel", {}).items()}
-            traffic_step = tj.get("hbm_bytes_per_step")
-            traffic_src = tj.get("source")
+            if tj.get("kernel_source_sha16") != kernel_source_sha16():
+                # measured on other kernels than the ones that just ran: not quoted
+                traffic_stale = "profiles/traffic_%s.json was measured on kernel sources %s, this tree is %s: not quoted" % (
+                    args.workload, tj.get("kernel_source_sha16"), kernel_source_sha16())
+            else:
+                traffic_k = {c: v.get("hbm_bytes_per_launch") for c, v in tj.get("per_kernel", {}).items()}
+                valu_k = {c: v.get("valu_wave_insts_per_launch") for c, v in tj.get("per_kernel", {}).items()}
+                lds_k = {c: {q: v.get(q) for q in ("lds_insts_per_launch", "lds_bank_conflict_cycles_per_launch", "lds_active_cycles_per_launch")}
+                         for c, v in tj.get("per_kernel", {}).items()}
+                traffic_step = tj.get("hbm_bytes_per_step")
+                traffic_src = tj.get("source")
         except Exception:
             pass
     dom = max(cls_ms, key=lambda c: cls_ms[c])
@@ -692,7 +760,7 @@ def main():
     dom_ms = cls_ms[dom] / max(1, cls_n[dom])
     dom_survey = b_survey / args.steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(pipe_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(pipe_gbs / HBM_PEAK_GBS, 5), "traffic": traffic_step, "traffic_source": traffic_src,
+                "frac": round(pipe_gbs / HBM_PEAK_GBS, 5), "traffic": traffic_step, "traffic_source": traffic_src or traffic_stale,
                 "what": "whole path: SURVEY 8(d) bytes (1 B/base + 8 B/slot inspected + 4 B/hit) of a step / summed kernel time of a step",
                 "algorithmic_bytes_per_step": b_survey // args.steps,
                 "bytes_per_base": round(b_survey / max(1, d["n_bases"]), 3),
@@ -709,6 +777,56 @@ def main():
     ctx = None
     del counters
     torch.cuda.empty_cache()
+
+    # ---- the instruction side (what the byte fraction above is bound BY: the three kernels' time x CUs is constant):
+    #      VALU wave-instructions per launch (SQ_INSTS_VALU, a PMC pass of tools/profile.sh on these very kernel sources)
+    #      against what the chip can issue in the launch's measured time ---------------------------------------------
+    if any(valu_k.get(c) for c in per_kernel):
+        clk_hz = 2.4e9                                                      # MI355X max clock (MI355X_MICROARCH.md); under load the chip holds less, so the fraction reads low
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        issue = n_cu * VALU_WAVE_INSTS_PER_CU_CYCLE * clk_hz               # wave64 VALU instructions per second, whole chip
+        vk, tot_i, tot_s = {}, 0.0, 0.0
+        for c, e in per_kernel.items():
+            if not valu_k.get(c):
+                continue
+            sec = e["avg_launch_ms"] * 1e-3
+            kmers_launch = d["n_kmers"] / max(1, cls_n[c])
+            vk[c] = {"valu_wave_insts_per_launch": valu_k[c], "lane_ops_per_kmer": round(64.0 * valu_k[c] / max(1.0, kmers_launch), 1),
+                     "issue_frac": round(valu_k[c] / (sec * issue), 4), **{q: v for q, v in (lds_k.get(c) or {}).items() if v is not None}}
+            if vk[c].get("lds_active_cycles_per_launch"):
+                vk[c]["lds_conflict_share_of_active_cycles"] = round(vk[c]["lds_bank_conflict_cycles_per_launch"] / vk[c]["lds_active_cycles_per_launch"], 3)
+            tot_i += valu_k[c] * cls_n[c] / args.steps
+            tot_s += sec * cls_n[c] / args.steps
+        roofline["valu"] = {"bound": "valu issue", "unit": "wave64 VALU instructions/s", "peak": issue, "peak_is": "%d CUs x 4 SIMDs x 1 wave64 instruction per 4 cycles x %.1f GHz (the max clock)" % (n_cu, clk_hz / 1e9),
+                            "achieved": round(tot_i / tot_s, 1) if tot_s else None, "frac": round(tot_i / tot_s / issue, 4) if tot_s else None,
+                            "lane_ops_per_kmer_whole_path": round(64.0 * tot_i / max(1.0, d["n_kmers"] / args.steps), 1),
+                            "kernels": vk, "source": traffic_src}
+    else:
+        roofline["valu"] = None
+
+    # ---- north_star's other denominator: the HBM RANDOM-ACCESS roofline = what this device does with uniformly
+    #      random 8-byte loads + 4-byte atomic adds over arrays of this table's size (the direct kernel's access pattern,
+    #      one of each per k-mer at least), measured here and now; and B_sector, the bytes that pattern moves in 64-byte sectors ----
+    if rank == 0 and not args.no_random_access:
+        try:
+            n_ops = 1 << 29
+            ms = {m: pyqm2.tools.microbench(H, n_ops, m, repeats=2) for m in (0, 1, 2)}
+            ceiling = n_ops / (ms[2] * 1e-3)
+            kmers_per_s = d["n_kmers"] / elapsed / max(1, world)
+            crossings = (d["n_probes"] - d["n_kmers"]) / 8.0            # a walk's next slot lies in the next 64-byte line one time in eight
+            b_sector = 64.0 * (d["n_kmers"] + crossings) + 128.0 * d["n_hits"]
+            roofline["random_access"] = {
+                "what": "uniformly random 8-byte load + 4-byte atomic add per operation over arrays of the table's size (qm2t_microbench, 2^29 operations, 16 in flight per lane): "
+                        "the ceiling of one sector gather + one memory-side atomic per k-mer, which the partitioned pipeline replaces by streams",
+                "slots": H, "load8_Gops_per_s": round(n_ops / ms[0] / 1e6, 2), "atomic4_Gops_per_s": round(n_ops / ms[1] / 1e6, 2),
+                "load8_atomic4_Gops_per_s": round(ceiling / 1e9, 2),
+                "kmers_per_s": round(kmers_per_s, 1), "kmers_per_s_over_the_ceiling": round(kmers_per_s / ceiling, 2),
+                "B_sector_bytes_per_step": int(b_sector / args.steps),
+                "B_sector_GBs": round(b_sector / max(1, world) / elapsed / 1e9, 1),
+                "B_sector_frac_of_peak": round(b_sector / max(1, world) / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
+        except Exception as e:                                          # (no room for the microbenchmark's own 48 GiB: say so)
+            roofline["random_access"] = {"error": str(e)}
+        torch.cuda.empty_cache()
 
     # ---- SURVEY 8(d)'s wall-clock metric: the batches fed from HOST memory through the pinned staging
     #      buffers, first commit -> return of qm2_finish, allocations made beforehand ---------------------
@@ -881,10 +999,10 @@ def main():
                        if world > 1 else "1 GPU", "inputs": "resident in HBM (value); host-fed rates under `streamed`",
                        "setup_s": round(t_setup, 1),
                        "final_reduce_ms": round(reduce_ms, 2) if reduce_ms is not None else None,
-                       # the same steps with the job's one exchange charged to them in full (a 30x hg38 job is 10 such steps
+                       # the same steps with the job's per-job costs (the fold of the 2-byte interiors + the one exchange) charged to them in full (a 30x hg38 job is 10 such steps
                        # per GPU at N = 1 and fewer at N > 1: the exchange is per job, `value` is per step)
-                       "bases_per_s_with_the_reduce_charged_to_these_steps":
-                           round(total_bases / (elapsed + reduce_ms / 1e3), 1) if reduce_ms is not None else None,
+                       "bases_per_s_with_the_fold_and_the_reduce_charged_to_these_steps":
+                           round(total_bases / (elapsed + (reduce_ms + fold_ms) / 1e3), 1) if reduce_ms is not None else None,
                        "fold_ms": round(fold_ms, 2),
                        "counts_conserved": counts_conserved, "spilled_kmers": prof1["spilled_kmers"] - prof0["spilled_kmers"]},
             "kernel_only_bases_per_s": roofline["kernel_only_bases_per_s"],

@@ -381,3 +381,38 @@ int main(int argc, char **argv) {
             assert sorted(lines) == sorted(exp.split(b"\n")[:-1])
             if n_sinks > 1:
                 assert len({(k // per_turn) % n_sinks for k in range(j)}) == min(n_sinks, (j + per_turn - 1) // per_turn)
+
+
+def test_bench_gpus_means_ranks(tmp_path):
+    """`python bench.py --gpus N` (the driver's own form): N > 1 without a rank environment starts N ranks of the script under
+    torch.distributed.run as a child process — checked with a stand-in launcher — and relays rank 0's one JSON line and the
+    exit code; a rank environment that disagrees with --gpus fails loudly instead of printing a line for another N."""
+    import json
+    import sys
+    stub = tmp_path / "launcher.py"
+    stub.write_text('''
+import json, os, sys
+a = sys.argv[1:]
+sys.stderr.write("STUB " + " ".join(a) + "\\n")
+print("some native library banner")
+n = int(a[a.index("--nproc-per-node") + 1])
+print(json.dumps({"n_gpus": n, "script": a[a.index("--master-port") + 2], "rest": a[a.index("--master-port") + 3:], "addr": os.environ.get("MASTER_ADDR")}))
+sys.exit(int(os.environ.get("STUB_RC", "0")))
+''')
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["QM2_BENCH_LAUNCHER"] = "%s %s" % (sys.executable, stub)
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "3", "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                    # ONE line on stdout; the banner went to stderr
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and os.path.samefile(d["script"], bench) and d["rest"] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and d["addr"] == "127.0.0.1"
+    assert b"--nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, STUB_RC="7"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 7
+    # the launcher's rank count and --gpus disagree (e.g. torchrun --nproc-per-node 2 bench.py --gpus 8): no line, an error
+    r = subprocess.run([sys.executable, bench, "--gpus", "8"], env=dict(env, WORLD_SIZE="2", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == b"" and b"disagree" in r.stderr
+    r = subprocess.run([sys.executable, bench], env=dict(env, WORLD_SIZE="2", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"disagree" in r.stderr              # (--gpus defaults to 1)

@@ -1432,9 +1432,7 @@ def test_loader_waves_out_of_step(torch_cuda, tmp_path):
     torch = torch_cuda
     pkg = os.path.join(ROOT, "quick-mer2_amd")
     lib = str(tmp_path / "libqm2_skew.so")
-    src = [os.path.join(pkg, "csrc", f) for f in ("qm2_hip.hip", "qm2_tools.hip", "qm2_epilogue.hip", "qm2_io.hip")]
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function",
-                    "-DQM2_TEST_LOADER_SKEW=8", "-shared", "-o", lib] + src + ["-pthread"], check=True, cwd=pkg)
+    subprocess.run(["make", "-C", pkg, "variant", "TUNE=-DQM2_TEST_LOADER_SKEW=8", "OUT=" + lib], check=True, stdout=subprocess.DEVNULL)   # (the Makefile's compiler, arch and flags)
     code = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, %r)
@@ -1475,9 +1473,7 @@ def test_waves_far_out_of_step(torch_cuda, tmp_path):
     cross the middle, a skewed stream that goes through the spill list: all equal to the direct kernel slot for slot."""
     pkg = os.path.join(ROOT, "quick-mer2_amd")
     lib = str(tmp_path / "libqm2_chaos.so")
-    src = [os.path.join(pkg, "csrc", f) for f in ("qm2_hip.hip", "qm2_tools.hip", "qm2_epilogue.hip", "qm2_io.hip")]
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function",
-                    "-DQM2_TEST_CHAOS=6", "-shared", "-o", lib] + src + ["-pthread"], check=True, cwd=pkg)
+    subprocess.run(["make", "-C", pkg, "variant", "TUNE=-DQM2_TEST_CHAOS=6", "OUT=" + lib], check=True, stdout=subprocess.DEVNULL)
     code = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, %r)
@@ -1524,8 +1520,9 @@ def test_bench_replicas_two_ranks_on_one_gpu(torch_cuda, tmp_path):
     every rank must complete its counters (fold the 2-byte bucket interiors: qm2_finish) BEFORE the job's one reduce,
     or the merged table lacks the other ranks' interior counts — `counts_conserved` is the check, on the merged result."""
     env = dict(os.environ, QM2_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run(["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    # (`bench.py --gpus 2` with no rank environment: it starts its two ranks itself, on a free port)
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(["python3", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--workload", "c2", "--reads-per-step", "4000000", "--mode", "partition", "--no-streamed",
                         "--no-cpu-baseline", "--no-geometry-check"],
                        env=env, capture_output=True, text=True, timeout=900)

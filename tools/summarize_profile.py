@@ -68,6 +68,22 @@ if len(sys.argv) > 2:
             e.setdefault(cn + "_n", 0)
             e[cn + "_KiB"] += sum(vals)
             e[cn + "_n"] += len(vals)
+    # the instruction side (tools/profile.sh, pass pmc_sq): wave-instructions and LDS cycles per dispatch
+    for cn, key in (("SQ_INSTS_VALU", "valu_wave_insts_per_launch"), ("SQ_INSTS_LDS", "lds_insts_per_launch"),
+                    ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_cycles_per_launch"), ("SQ_LDS_IDX_ACTIVE", "lds_active_cycles_per_launch")):
+        agg = defaultdict(list)
+        for f, r in rows("pmc_sq/**/*counter_collection.csv"):
+            if r["Counter_Name"] == cn:
+                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        for kname, vals in agg.items():
+            m = re.search(r"qm2::(\w+)_kernel", kname)
+            if not m or m.group(1) not in ("split_text", "split_kmer", "bucket_count", "count", "probe"):
+                continue
+            cls = {"count": "count_direct"}.get(m.group(1), m.group(1))
+            pk[cls].setdefault("_sq", {})
+            e = pk[cls]["_sq"].setdefault(key, [0.0, 0])
+            e[0] += sum(vals)
+            e[1] += len(vals)
     steps = None
     try:
         bj = json.load(open(os.path.join(out, "bench_pmc_rd.json")))
@@ -82,12 +98,18 @@ if len(sys.argv) > 2:
         hbm = int(2 * rd * 1024 + wr * 1024)
         per_kernel[cls] = {"FETCH_SIZE_KiB": round(rd), "WRITE_SIZE_KiB": round(wr), "hbm_bytes_per_launch": hbm,
                            "launches_profiled": n}
+        for key, (tot, cnt) in e.get("_sq", {}).items():
+            per_kernel[cls][key] = round(tot / max(1, cnt))
         if steps:
             step_total += hbm * n / steps
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench as _bench
     tj = {"workload": workload,
+          "kernel_source_sha16": _bench.kernel_source_sha16(),      # bench.py quotes these counters only for the kernels they were measured on
           "source": "%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py` (tools/profile.sh), "
                     "condensed by tools/summarize_profile.py; KiB per dispatch; the read side is doubled (gfx950 tallies wide "
-                    "coalesced reads at half their bytes: MI355X_MICROARCH.md, HBM)" % os.path.relpath(dest, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")),
+                    "coalesced reads at half their bytes: MI355X_MICROARCH.md, HBM); SQ_INSTS_VALU / SQ_INSTS_LDS / SQ_LDS_* from a "
+                    "third pass, per dispatch" % os.path.relpath(dest, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")),
           "per_kernel": per_kernel,
           "hbm_bytes_per_step": int(step_total) if steps else None}
     json.dump(tj, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "traffic_%s.json" % workload), "w"), indent=1)
