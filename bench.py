@@ -838,11 +838,11 @@ def main():
         rl = wl["len_lo"]
         nb = 2
         hosts = [batches[i % n_batches][0].cpu().numpy() for i in range(nb)]
-        sctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=mode_flag, ext_keys=keys.data_ptr(),
-                             n_staging=max(14, args.feed_threads + 4))
-        sctx.prepare(host=True, raw=True)
+        step_bytes = max(b[1] for b in batches)
+        batches = batches[:1]                                         # (batch 0 stays for the FASTQ text and the CPU legs)
+        torch.cuda.empty_cache()
 
-        def run(feed, steps):
+        def run(sctx, feed, steps):
             feed(0)                                                   # warm-up: page in, first-touch
             sctx.finish(want_depth=False)
             a0 = sctx.profile()["allocations"]
@@ -867,64 +867,72 @@ def main():
                 per_rank = [round(float(r.item()), 2) for r in rates]
             return nbases, moved, sec, allocs, per_rank
 
-        def feed_lines(i):
-            h = hosts[i % nb]
-            sctx.feed_host(h.ctypes.data, h.size, rl + 1, threads=args.feed_threads)
-            return h.size
-
         # (1) PACKED (ABI 6, include/qm2.h "packed sequence"): the threads that fill the pinned buffers pack what they copy —
         # the reset test and the 2-bit code of every character, QuicKmer.c:403-411, nothing more — so 0.375 bytes per base
-        # cross the link; this is what qm2_submit and the CLI's reader threads do by default
+        # cross the link; this is what qm2_submit and the CLI's reader threads do by default.  A context of its own: its
+        # device batches hold blocks only (QM2_PREPARE_PACKED: 3/8 of the bytes), which leaves room for batches as large as
+        # the resident steps' (the table stream is a fixed cost per batch).
+        pctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=mode_flag, ext_keys=keys.data_ptr(), kmers_per_kib=kib_hint,
+                             n_staging=max(14, args.feed_threads + 4), batch_bytes=(step_bytes + 63) & ~63)
+        pctx.prepare(host=True, packed=True)
+
         def feed_packed(i):
             h = hosts[i % nb]
-            return sctx.feed_host_packed(h.ctypes.data, h.size, rl + 1, threads=args.feed_threads, piece_text=args.piece_mib << 20)
+            pctx.submit_threads(None, args.feed_threads, addr=h.ctypes.data, n=h.size)     # ONE call of the C-ABI per step (qm2_submit_threads)
+            return h.size * 24 // 64                                                        # (the blocks' bytes, to a piece's rounding; checked against the profile below)
 
-        packed_steps = 2 * args.streamed_steps                 # (the drain of the last device batch is then < 10 % of the region, as in the ASCII one)
-        nbases, moved, sec, allocs, per_rank = run(feed_packed, packed_steps)
+        packed_steps = 2 * args.streamed_steps                 # (the drain of the last device batch is then ~10 % of the region, as in the ASCII one)
+        nbases, moved, sec, allocs, per_rank = run(pctx, feed_packed, packed_steps)
         assert nbases == world * packed_steps * wl["reads"] * rl
+        staged_total = pctx.profile()["staged_bytes"]          # (warm-up step included: packed_steps + 1 steps of the same size)
+        assert abs(staged_total / (packed_steps + 1) * packed_steps - moved / world) < 1e-3 * moved, (staged_total, moved)
         streamed = {"streamed_bases_per_s": round(nbases / sec, 1), "h2d_GBps": round(moved / sec / 1e9, 2),
                     "h2d_GBps_per_rank": per_rank, "ranks_feeding_concurrently": world,
                     "bytes_per_base_over_the_link": round(moved / max(1, nbases), 4),
                     "steps": packed_steps, "seconds": round(sec, 3), "allocations_inside": allocs,
+                    "device_batch_positions": (step_bytes + 63) & ~63,
                     "pack_isa": pyqm2.lib().qm2_pack_isa().decode(),
-                    "feed": "%d host threads pack 64 MiB staging buffers' worth of sequence lines from pageable memory (qm2_pack_lines: 2-bit codes + reset "
-                            "flags, what the CLI's reader threads do behind pread), one thread commits the pieces in order (qm2_staging_commit_packed); "
-                            "timed from the first commit to the return of qm2_finish" % args.feed_threads}
+                    "feed": "qm2_submit_threads(ctx, lines, n, %d): one call per step on a 9 GB buffer of sequence lines in pageable memory; the library's threads pack "
+                            "32 MiB pieces into the pinned staging buffers (qm2_pack_lines: 2-bit codes + reset flags, what the CLI's reader threads do behind pread), "
+                            "the calling thread commits them in order; timed from the first call to the return of qm2_finish" % args.feed_threads}
         # ... and what the kernels make of packed input that is already in HBM (the ceiling of the figure above; `value` stays
         # the ASCII-resident rate: there the device does the whole of QuicKmer.c:403-420)
         if rank == 0:
             blocks, pk, _ = pyqm2.pack_lines(memoryview(hosts[0]))
             d_blocks = torch.from_numpy(blocks.view(np.int64)).to(dev)
             del blocks
-            # (in pieces that fit the context's device batch, for which its partition buffers were made)
-            n_pieces = max(1, -(-64 * int(pk.n_blocks) // (5 << 30)))
-            per = -(-int(pk.n_blocks) // n_pieces)
-            pieces = [(a, min(per, int(pk.n_blocks) - a)) for a in range(0, int(pk.n_blocks), per)]
-            _, r0 = sctx.finish(want_depth=False)
-
-            def resident_pass():
-                for a, nblk in pieces:                    # (the line ends are taken off n_bases with the first piece: the totals are what counts)
-                    sctx.submit_packed_device(d_blocks.data_ptr() + 24 * a, pyqm2.Packed(nblk, int(pk.n_newlines) if a == 0 else 0, 0))
-
             for _ in range(2):
-                resident_pass()
-            sctx.sync()
-            _, r0 = sctx.finish(want_depth=False)
-            pr0 = sctx.profile()
+                pctx.submit_packed_device(d_blocks.data_ptr(), pk)
+            pctx.sync()
+            _, r0 = pctx.finish(want_depth=False)
+            pr0 = pctx.profile()
             tA = time.perf_counter()
             for _ in range(args.streamed_steps):
-                resident_pass()
-            sctx.sync()
+                pctx.submit_packed_device(d_blocks.data_ptr(), pk)
+            pctx.sync()
             sec_r = time.perf_counter() - tA
-            _, r1 = sctx.finish(want_depth=False)
-            pr1 = sctx.profile()
+            _, r1 = pctx.finish(want_depth=False)
+            pr1 = pctx.profile()
             assert r1["n_bases"] - r0["n_bases"] == args.streamed_steps * wl["reads"] * rl
             streamed["packed_resident_bases_per_s"] = round((r1["n_bases"] - r0["n_bases"]) / sec_r, 1)
-            streamed["packed_resident"] = {"pieces_per_step": len(pieces), "partitioned_batches": pr1["partitioned_batches"] - pr0["partitioned_batches"],
+            streamed["packed_resident"] = {"partitioned_batches": pr1["partitioned_batches"] - pr0["partitioned_batches"],
                                            "direct_batches": pr1["direct_batches"] - pr0["direct_batches"]}
             del d_blocks
-        # (2) the same lines as ASCII, 1 byte per base (QM2_FLAG_SUBMIT_ASCII / QM2_READER=lines; rounds 1-4's streamed figure)
-        nbases, moved, sec, allocs, per_rank = run(feed_lines, args.streamed_steps)
+        pctx.close()
+        torch.cuda.empty_cache()
+
+        # (2) the same lines as ASCII, 1 byte per base (QM2_FLAG_SUBMIT_ASCII / QM2_READER=lines; rounds 1-4's streamed figure),
+        # and (3) FASTQ text, packed by the feeding threads and as raw text: one context with the library's default batches
+        sctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=mode_flag, ext_keys=keys.data_ptr(),
+                             n_staging=max(14, args.feed_threads + 4))
+        sctx.prepare(host=True, raw=True)
+
+        def feed_lines(i):
+            h = hosts[i % nb]
+            sctx.feed_host(h.ctypes.data, h.size, rl + 1, threads=args.feed_threads)
+            return h.size
+
+        nbases, moved, sec, allocs, per_rank = run(sctx, feed_lines, args.streamed_steps)
         streamed.update({"streamed_ascii_bases_per_s": round(nbases / sec, 1), "ascii_h2d_GBps": round(moved / sec / 1e9, 2),
                          "ascii_h2d_GBps_per_rank": per_rank, "ascii_allocations_inside": allocs})
         # the same reads as raw FASTQ text ("@r" / seq / "+" / qual: 2 x 151 + 5 bytes a record), line discipline on the device
@@ -951,13 +959,13 @@ def main():
             return sctx.feed_host_packed(fq.ctypes.data, fq.size, 2 * (rl + 1) + 5, reads=(True, 1), threads=args.feed_threads, piece_text=args.piece_mib << 20)
 
         raw_steps = max(1, args.streamed_steps * 3 // 2)      # (6 x 6.1 GB by default: the drain of the last batch is then < 10 % of the region)
-        nbases, moved, sec, allocs, per_rank = run(feed_fastq_packed, 2 * raw_steps)
+        nbases, moved, sec, allocs, per_rank = run(sctx, feed_fastq_packed, 2 * raw_steps)
         assert nbases == world * 2 * raw_steps * m * rl
         streamed.update({"streamed_fastq_bases_per_s": round(nbases / sec, 1), "fastq_h2d_GBps": round(moved / sec / 1e9, 2),
                          "fastq_text_GBps": round(world * 2 * raw_steps * fq.size / sec / 1e9, 2), "fastq_h2d_GBps_per_rank": per_rank,
                          "fastq_reads_per_step": m, "fastq_steps": 2 * raw_steps, "fastq_allocations_inside": allocs})
         # ... and as raw text over the link, line discipline on the device (QM2_READER=raw; rounds 2-4's figure)
-        nbases, moved, sec, allocs, per_rank = run(feed_fastq, raw_steps)
+        nbases, moved, sec, allocs, per_rank = run(sctx, feed_fastq, raw_steps)
         streamed.update({"streamed_raw_fastq_bases_per_s": round(nbases / sec, 1), "raw_fastq_h2d_GBps": round(moved / sec / 1e9, 2),
                          "raw_fastq_h2d_GBps_per_rank": per_rank,
                          "raw_fastq_reads_per_step": m, "raw_fastq_steps": raw_steps, "raw_fastq_allocations_inside": allocs,

@@ -161,6 +161,11 @@ typedef struct {
                                   qm2_finish once qm2_prepare has run)                          */
     uint64_t spilled_kmers;    /* partitioned batches: k-mers that did not fit their bucket and were probed from the
                                   spill list by the direct path (skewed input; 0 on uniform reads)            */
+    uint64_t staged_bytes;     /* bytes the host pipeline has copied to the device (qm2_submit*, qm2_staging_commit*): what
+                                  crossed the link — packed pieces count their blocks (ABI 6)                  */
+    uint64_t replans;          /* times the partition plan was torn down and rebuilt because the caller alternated between
+                                  qm2_probe_subslabs_device and the other entry points (each costs a stream sync + the
+                                  re-allocation of the partition buffers)                                      */
 } qm2_profile;
 
 /* Create a counting context for a dictionary of `hash_size` slots (power of
@@ -237,6 +242,10 @@ int qm2_stats_peek(qm2_ctx *c, qm2_stats *st);
 /* everything BUT the partition buffers; a second call without this flag makes them — e.g. from another thread while
  * qm2_keys_from_fd streams the dictionary in (the two may run concurrently; nothing else of a context may) */
 #define QM2_PREPARE_NO_PART 8u
+/* with QM2_PREPARE_HOST: the device batches will only ever hold PACKED pieces (qm2_staging_commit_packed, qm2_submit's
+ * default): they are made 3/8 the size (24 bytes per 64 positions).  Text that arrives all the same (a line too long
+ * for a piece, a caller's ASCII) makes its batch grow then — an allocation inside the counting phase, nothing else. */
+#define QM2_PREPARE_PACKED 16u
 int qm2_prepare(qm2_ctx *c, uint64_t batch_bytes, uint32_t what);
 
 /* Zero counters and statistics (a fresh calloc, :360). */
@@ -422,6 +431,9 @@ int qm2_pack_reads(const char *text, size_t n, qm2_line_state *st, void *dst, si
 const char *qm2_pack_isa(void);      /* "avx512" / "avx2" / "portable": the build of the packers this CPU runs */
 const char *qm2_pack_isa_select(const char *name);   /* force a build (tests run all three; NULL = the widest again); returns what runs */
 int qm2_staging_commit_packed(qm2_ctx *c, char *buf, const qm2_packed *p, const uint64_t *wraps);
+/* qm2_submit with the packing spread over n_threads host threads (0 = qm2_submit): pieces of whole lines, packed into
+ * the pinned staging buffers by the threads, committed in order by the calling thread.  Same contract, same result. */
+int qm2_submit_threads(qm2_ctx *c, const char *seq_bytes, size_t n, uint32_t n_threads);
 int qm2_submit_packed_device(qm2_ctx *c, const void *d_blocks, const qm2_packed *p, const uint64_t *d_wraps);
 
 /* Straight from the .qm file to the device (QuicKmer.c:353-359 and :483 without the 32 GiB

@@ -27,6 +27,7 @@ struct Slot {                               /* one pinned staging buffer */
 
 struct Batch {                              /* one device batch being filled by qm2_submit */
     uint8_t    *dev = nullptr;
+    size_t      cap = 0;                    /* bytes at dev: a batch of ASCII / raw text, or (QM2_PREPARE_PACKED) only of packed blocks */
     size_t      fill = 0;
     size_t      carry = 0;                  /* leading bytes that only serve as look-back */
     std::vector<uint64_t> wraps;            /* uint16-wrap positions, relative to dev[0]  */

@@ -14,7 +14,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -197,6 +200,7 @@ static int part_plan_kind(qm2_ctx *c, int first_bits)
     const bool want_ext = first_bits > 0;
     if (p.ext0 == want_ext && (!want_ext || (p.levels != 0 && p.bits[0] == (uint32_t)first_bits))) return 0;
     HIP_OK(hipStreamSynchronize(c->stream));                          /* buffers may be in use */
+    if (p.reserved) c->prof.replans++;                                /* (a plan with buffers is thrown away: qm2_profile) */
     qm2_part_free(p);
     if (p.shared) { (void)hipFree(p.shared); p.shared = nullptr; }
     p.runs = 0;
@@ -880,18 +884,28 @@ extern "C" void *qm2_keys_device(qm2_ctx *c) { return c ? c->keys : nullptr; }
 
 /* ---- host-buffer pipeline: pinned staging -> device batch -> kernels --------- */
 
-static int batch_ready(qm2_ctx *c, Batch &b)
+/* bytes a device batch needs for text (ASCII or raw), and for packed blocks of batch_bytes positions */
+static size_t batch_text_bytes(const qm2_ctx *c) { return c->batch_bytes + kCarry + kDevPad; }
+static size_t batch_packed_bytes(const qm2_ctx *c) { return (c->batch_bytes / 64 + 1) * QM2_PACKED_BLOCK_BYTES + kDevPad; }
+
+static int batch_ready(qm2_ctx *c, Batch &b, size_t need)
 {
     /* (events first: b.dev marks the batch as complete, so a failure in between is retried whole) */
     if (!b.done) HIP_OK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
     if (!b.copied) HIP_OK(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
-    if (!b.dev) {
-        HIP_OK(hipMalloc((void **)&b.dev, c->batch_bytes + kCarry + kDevPad));
-        c->n_allocations++;
-    }
     if (b.busy) {
         HIP_OK(hipEventSynchronize(b.done));
         b.busy = false;
+    }
+    if (b.dev && b.cap < need) {              /* prepared for packed input only (QM2_PREPARE_PACKED), and text arrives: grow */
+        HIP_OK(hipFree(b.dev));
+        b.dev = nullptr;
+        b.cap = 0;
+    }
+    if (!b.dev) {
+        HIP_OK(hipMalloc((void **)&b.dev, need));
+        b.cap = need;
+        c->n_allocations++;
     }
     return 0;
 }
@@ -968,6 +982,7 @@ static int stage_bytes(qm2_ctx *c, Batch &b, const char *src, size_t n, Slot *ow
         HIP_OK(hipEventRecord(owner->done, c->copy_stream));
         owner->busy = true;
         b.fill += n;
+        c->prof.staged_bytes += n;
         return 0;
     }
     size_t done = 0;
@@ -986,6 +1001,7 @@ static int stage_bytes(qm2_ctx *c, Batch &b, const char *src, size_t n, Slot *ow
         HIP_OK(hipEventRecord(s->done, c->copy_stream));
         s->busy = true;
         b.fill += take;
+        c->prof.staged_bytes += take;
         done += take;
     }
     return 0;
@@ -1017,13 +1033,14 @@ static int stage_packed(qm2_ctx *c, Slot &s, const qm2_packed &p, const uint64_t
         if (b0.fill && (!b0.packed || b0.fill / QM2_PACKED_BLOCK_BYTES * 64 + positions > c->batch_bytes) && batch_flush(c)) return 1;
     }
     Batch &b = c->batch[c->cur];
-    if (batch_ready(c, b)) return 1;
+    if (batch_ready(c, b, batch_packed_bytes(c))) return 1;
     if (b.fill == 0) { b.packed = true; b.packed_nl = 0; b.carry = 0; b.raw = false; b.wraps.clear(); }
     const uint64_t pos0 = b.fill / QM2_PACKED_BLOCK_BYTES * 64;
     HIP_OK(hipMemcpyAsync(b.dev + b.fill, s.host, p.n_blocks * QM2_PACKED_BLOCK_BYTES, hipMemcpyHostToDevice, c->copy_stream));
     HIP_OK(hipEventRecord(s.done, c->copy_stream));
     s.busy = true;
     b.fill += p.n_blocks * QM2_PACKED_BLOCK_BYTES;
+    c->prof.staged_bytes += p.n_blocks * QM2_PACKED_BLOCK_BYTES;
     b.packed_nl += p.n_newlines;
     for (uint64_t i = 0; i < p.n_wraps; i++) b.wraps.push_back(wraps[i] + pos0);
     if (b.fill / QM2_PACKED_BLOCK_BYTES * 64 >= c->batch_bytes) return batch_flush(c);
@@ -1087,7 +1104,7 @@ static int submit_lines(qm2_ctx *c, const char *buf, size_t n, Slot *owner)
             continue;
         }
         Batch &b = c->batch[c->cur];
-        if (batch_ready(c, b)) return 1;
+        if (batch_ready(c, b, batch_text_bytes(c))) return 1;
         const size_t at = b.fill;             /* first staged byte of this part lands at dev[at] */
         if (pt.carry) b.carry = pt.carry;     /* (only ever the first bytes of an empty batch) */
         if (stage_bytes(c, b, buf + pt.off - pt.carry, pt.carry + pt.take, owner)) return 1;
@@ -1133,6 +1150,113 @@ extern "C" int qm2_staging_commit(qm2_ctx *c, char *buf, size_t n)
         return fail("qm2_staging_commit: buffer must end with a newline (whole sequence lines only)");
     if (use_device(c)) return 1;
     return submit_lines(c, buf, n, owner);
+}
+
+/* qm2_submit with the packing spread over n_threads host threads: the caller's buffer is cut into pieces of whole lines,
+ * the threads pack them into pinned staging buffers (qm2_pack_lines), the calling thread hands the buffers out and
+ * commits the pieces in order — so that one call feeds the link at what several cores pack (a single thread packs
+ * ~30 GB/s of text on a Zen 5 core, the link takes the packed form of ~137 G bases/s). */
+extern "C" int qm2_submit_threads(qm2_ctx *c, const char *buf, size_t n, uint32_t n_threads)
+{
+    if (!c) return fail("qm2_submit_threads: null context");
+    if (c->keys_pending) return fail("qm2: the key table has not been loaded yet (qm2_keys_from_fd)");
+    if (n == 0) return 0;
+    if (!buf) return fail("qm2_submit_threads: null buffer");
+    if (buf[n - 1] != '\n') return fail("qm2_submit_threads: buffer must end with a newline (whole sequence lines only)");
+    if (use_device(c)) return 1;
+    size_t free_slots = 0;
+    for (auto &s : c->slots) free_slots += s.lent ? 0 : 1;
+    if (n_threads == 0 || (c->flags & QM2_FLAG_SUBMIT_ASCII) || free_slots < 2) return (c->flags & QM2_FLAG_SUBMIT_ASCII) ? submit_lines(c, buf, n, nullptr) : submit_packing(c, buf, n);
+    const size_t piece_cap = std::min<size_t>((c->staging_bytes / QM2_PACKED_BLOCK_BYTES) * 64, c->batch_bytes) & ~(size_t)63;
+    /* pieces of ~32 MiB of text (what a reader thread of the CLI handles at a time), whole lines */
+    const size_t piece_max = std::min<size_t>(piece_cap, (size_t)32 << 20);
+    if (piece_max < 4096) return submit_packing(c, buf, n);
+    struct Job { size_t off = 0, len = 0; Slot *slot = nullptr; qm2_packed p = {0, 0, 0}; uint64_t wraps[64]; int rc = 0; bool done = false; bool ascii = false; };
+    std::vector<Job> jobs;
+    for (size_t off = 0; off < n;) {
+        size_t take = std::min(piece_max, n - off);
+        bool ascii = false;
+        if (take < n - off) {
+            const void *nl = memrchr(buf + off, '\n', take);
+            if (nl) take = (size_t)((const char *)nl - (buf + off)) + 1;
+            else { take = (size_t)((const char *)memchr(buf + off, '\n', n - off) - (buf + off)) + 1; ascii = true; }   /* a line longer than a piece */
+        }
+        Job j;
+        j.off = off; j.len = take; j.ascii = ascii;
+        jobs.push_back(j);
+        off += take;
+    }
+    const size_t window = std::min<size_t>(std::min<size_t>((size_t)n_threads + 2, free_slots - 1), jobs.size());
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    size_t next_job = 0, issued = 0;              /* jobs [next_job, issued) wait for a thread */
+    bool quit = false;
+    auto worker = [&]() {
+        for (;;) {
+            Job *j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return quit || next_job < issued; });
+                if (next_job >= issued) return;
+                j = &jobs[next_job++];
+            }
+            if (!j->ascii) j->rc = qm2_pack_lines(buf + j->off, j->len, j->slot->host, c->staging_bytes, j->wraps, 64, &j->p);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                j->done = true;
+            }
+            cv_done.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    const size_t n_workers = std::min<size_t>(n_threads, jobs.size());
+    for (size_t t = 0; t < n_workers; t++) pool.emplace_back(worker);
+    int rc = 0;
+    size_t committed = 0;
+    auto issue_one = [&]() -> int {
+        Job &j = jobs[issued];
+        if (!j.ascii) {
+            Slot *s = nullptr;
+            for (size_t tries = 0; tries < c->slots.size() && !s; tries++) {
+                Slot &cand = c->slots[c->next_slot];
+                c->next_slot = (c->next_slot + 1) % (uint32_t)c->slots.size();
+                if (!cand.lent) s = &cand;
+            }
+            if (!s) return fail("qm2_submit_threads: every staging buffer is held by qm2_staging_acquire");
+            if (qm2_slot_ready(c, *s)) return 1;
+            s->lent = true;                       /* (ours until its piece is committed) */
+            j.slot = s;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            issued++;
+        }
+        cv_work.notify_one();
+        return 0;
+    };
+    while (!rc && committed < jobs.size()) {
+        while (!rc && issued < jobs.size() && issued - committed < window) rc = issue_one();
+        if (rc) break;
+        Job &j = jobs[committed];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return j.done; });
+        }
+        if (j.slot) j.slot->lent = false;
+        if (j.ascii || j.rc == 2) rc = submit_lines(c, buf + j.off, j.len, nullptr);          /* does not pack: the ASCII way */
+        else if (j.rc) rc = fail("qm2_submit_threads: packing failed");
+        else rc = stage_packed(c, *j.slot, j.p, j.wraps);
+        committed++;
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        quit = true;
+        /* (jobs issued but not committed after an error: their threads finish them, nobody looks) */
+    }
+    cv_work.notify_all();
+    for (auto &t : pool) t.join();
+    for (size_t i = committed; i < issued; i++) if (jobs[i].slot) jobs[i].slot->lent = false;
+    return rc;
 }
 
 extern "C" int qm2_staging_commit_packed(qm2_ctx *c, char *buf, const qm2_packed *p, const uint64_t *wraps)
@@ -1293,12 +1417,13 @@ extern "C" int qm2_staging_commit_raw(qm2_ctx *c, char *buf, size_t offset, size
     }
     if (c->raw_verdict) return 0;
     Batch &b = c->batch[c->cur];
-    if (batch_ready(c, b)) return 1;
+    if (batch_ready(c, b, batch_text_bytes(c))) return 1;
     if (b.fill == 0) { b.raw = true; b.raw_fastq = fastq ? 1u : 0u; b.raw_skip = skip; b.carry = 0; }
     HIP_OK(hipMemcpyAsync(b.dev + b.fill, buf + offset, n, hipMemcpyHostToDevice, c->copy_stream));
     HIP_OK(hipEventRecord(owner->done, c->copy_stream));
     owner->busy = true;
     b.fill += n;
+    c->prof.staged_bytes += n;
     return 0;
 }
 
@@ -1447,7 +1572,7 @@ extern "C" int qm2_prepare(qm2_ctx *c, uint64_t batch_bytes, uint32_t what)
     const uint64_t bb = batch_bytes ? batch_bytes : (uint64_t)c->batch_bytes;
     if (what & QM2_PREPARE_HOST) {
         if (bb > c->batch_bytes) return fail("qm2_prepare: batch larger than the context's device batch");
-        for (auto &b : c->batch) if (batch_ready(c, b)) return 1;
+        for (auto &b : c->batch) if (batch_ready(c, b, (what & QM2_PREPARE_PACKED) ? batch_packed_bytes(c) : batch_text_bytes(c))) return 1;
         for (auto &s : c->slots) if (qm2_slot_ready(c, s)) return 1;
     }
     if (what & QM2_PREPARE_RAW) {

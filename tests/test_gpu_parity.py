@@ -558,6 +558,16 @@ def test_packed_entry_points(qm2, torch_cuda, tmp_path):
                     c.submit_packed(blob, piece=piece)
                     depth, st = c.finish()
                 assert st == exp_st and np.array_equal(depth, exp_depth), (k, flags, piece, batch)
+            # qm2_submit_threads: the library's own threads pack, the caller commits nothing itself
+            for thr, staging in ((1, 1 << 20), (3, 200_000), (8, 1 << 21), (0, 1 << 20)):
+                with qm2.Counter(keys, k=k, flags=flags, staging_bytes=staging, n_staging=6, batch_bytes=1 << 20) as c:
+                    c.submit_threads(blob, thr)
+                    cut = blob.find(b"\n", len(blob) // 2) + 1
+                    c.submit_threads(blob[:cut], thr)
+                    depth, st = c.finish()
+                    assert c.profile()["staged_bytes"] > 0
+                e2, s2 = ol.count_lines(keys, k, blob + blob[:cut])
+                assert st == s2 and np.array_equal(depth, e2), (k, flags, thr, staging)
             # already on the device
             blocks, p, wraps = qm2.pack_lines(blob)
             assert p.n_wraps > 0
