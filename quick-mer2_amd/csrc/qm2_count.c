@@ -232,7 +232,7 @@ static int count_on_devices(qm2_dict_file *d, const char *reads, int n_strip, co
     uint64_t in_size;
     sniff_input(reads, &regular, &fastq, &in_size);
     int want_raw = regular && n_strip > 0 && reader_mode() == READER_RAW;
-    const int want_packed = n_strip > 0 && reader_mode() == READER_PACKED;
+    int want_packed = n_strip > 0 && reader_mode() == READER_PACKED;
     const uint32_t what = QM2_PREPARE_HOST | (want_raw ? QM2_PREPARE_RAW : 0u) | (want_raw && fastq ? QM2_PREPARE_FASTQ : 0u);
     /* one loader thread per replica: each reads the .qm through the page cache and feeds its own GPU over its own
      * PCIe link, so N replicas load in about the time of one (the contexts share nothing but the file descriptor,
@@ -298,6 +298,15 @@ static int count_on_devices(qm2_dict_file *d, const char *reads, int n_strip, co
             if (qm2_finish(ctxs[i], NULL, &s1)) { rc = 1; break; }
             verdict |= qm2_raw_verdict(ctxs[i]);
             st->n_bases += s1.n_bases; st->n_kmers += s1.n_kmers; st->n_probes += s1.n_probes; st->n_hits += s1.n_hits;
+        }
+        if (rc == 3 && want_packed) {                          /* ('>' at a FASTQ sequence position: qm2_host.h) */
+            if (timing) printf("QM2 packed input given up ('>' at a FASTQ sequence position): host line discipline in order\n");
+            want_packed = 0;
+            rc = 0;
+            for (int i = 0; i < n_dev && !rc; i++) rc = qm2_reset(ctxs[i]);
+            if (rc) break;
+            pass = 0;                                          /* (one more go) */
+            continue;
         }
         if (rc == 1 || !want_raw || (rc == 0 && verdict == 0)) break;
         /* a raw block was refused (or did not fit a buffer): everything again through the host line discipline */
@@ -445,7 +454,9 @@ int qm2_main_count(int argc, char **argv)
      * fill the PCIe link (hg38 scale, 30.7 GB of FASTQ from /dev/shm, a 16-core share of a 256-thread host: -t 8 / 12 / 16 / 24
      * -> 19.0 / 22.9 / 19.3 / 20.9 G bases/s; chr22 scale 20.4 / 23.5 / 21.6); before that it was 12.6 / 20.8 / 19.2 at 12 / 16 / 24 */
     const long cores = sysconf(_SC_NPROCESSORS_ONLN);
-    int n_strip = getopt_seen_t ? (int)thread_count : (cores >= 24 ? 12 : cores >= 16 ? 8 : 4);
+    /* (round 5: with the packing on the reader threads the link is no longer the bound, the threads are — hg38 scale, a 16-CPU share:
+     *  -t 12 / 16 -> 32.0 / 39.3 G bases/s of FASTQ, profiles/r05_c3/cli_end_to_end_100M_reads.txt) */
+    int n_strip = getopt_seen_t ? (int)thread_count : (cores >= 32 ? 16 : cores >= 24 ? 12 : cores >= 16 ? 8 : 4);
     if (n_strip > 32) n_strip = 32;
 
     const int timing = getenv("QM2_TIMING") != NULL;   /* extra phase lines; off by default so that
@@ -550,6 +561,16 @@ int qm2_main_count(int argc, char **argv)
     qm2_stats st;
     memset(&st, 0, sizeof st);
     if (rc == 0) rc = qm2_finish(ctx, NULL, &st);             /* :458-479; counts stay on the device */
+    if (rc == 3 && out.commit_packed) {
+        /* packed pieces are committed in any order; a FASTQ sequence-position line that starts with '>' (:398) changes what the
+         * lines BEHIND it are, which only a pass in order can follow: everything again, from zeroed counters, as ASCII lines */
+        if (timing) printf("QM2 packed input given up ('>' at a FASTQ sequence position): host line discipline in order\n");
+        out.commit_packed = NULL;
+        rc = qm2_reset(ctx);
+        if (!rc) rc = qm2_stream_reads(reads, &out, n_strip);
+        memset(&st, 0, sizeof st);
+        if (!rc) rc = qm2_finish(ctx, NULL, &st);
+    }
     if (want_raw && (rc == 2 || (rc == 0 && qm2_raw_verdict(ctx) != 0))) {
         if (timing) printf("QM2 raw input refused (verdict %u): host line discipline\n", qm2_raw_verdict(ctx));
         out.commit_raw = NULL;

@@ -64,7 +64,10 @@ typedef struct {
  * is only ever called from the calling thread and must be able to lend n_threads + 1 buffers at
  * a time.  Returns 0, or 1 after printing a message, or 2 when raw hand-over (commit_raw) met
  * something it cannot pass on (a line longer than a buffer): nothing is printed, the caller
- * starts over without commit_raw. */
+ * starts over without commit_raw; or 3 when packed hand-over (commit_packed) of a regular file met a
+ * FASTQ sequence-position line that starts with '>' (its pieces are committed in any order, so what
+ * such a line does to the lines behind it cannot be followed): nothing is printed, the caller starts
+ * over — from zeroed counters — without commit_packed. */
 int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads);
 /* bytes of text per block (= per acquired buffer) when a regular file is read block-wise */
 size_t qm2_reader_block_bytes(void);

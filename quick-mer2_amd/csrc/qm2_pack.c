@@ -27,9 +27,7 @@
 typedef struct {
     uint64_t *out;                 /* blocks (3 words each) */
     size_t    cap_blocks, n_blocks;
-    uint64_t  hi, lo, bad;         /* the block being filled */
-    unsigned  fill;                /* positions in it */
-    uint64_t  n_pos;               /* positions appended so far */
+    uint64_t  n_pos;               /* positions appended */
     uint64_t  n_newlines;
     uint64_t *wraps;
     size_t    wraps_cap, n_wraps;
@@ -98,12 +96,15 @@ static inline uint64_t nlmask_portable(const uint8_t *p)
 #define QM2_TARGET
 #define QM2_MASKS64(p, hi, lo, nl, nn) masks64_portable((const uint8_t *)(p), hi, lo, nl, nn)
 #define QM2_NLMASK(p) nlmask_portable((const uint8_t *)(p))
+#define QM2_GTMASK(p) 0ull          /* (only the pext builds look at it) */
 #define QM2_SPREAD(x) spread_portable(x)
 #include "qm2_pack_body.h"
 #undef QM2_ISA
 #undef QM2_TARGET
 #undef QM2_MASKS64
 #undef QM2_NLMASK
+#undef QM2_GTMASK
+#undef QM2_HAVE_PEXT
 #undef QM2_SPREAD
 
 #if defined(__x86_64__)
@@ -118,22 +119,26 @@ AVX2_T static inline void masks64_avx2(const uint8_t *p, uint64_t *hi, uint64_t 
     *nl = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a, cn)) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b, cn)) << 32);
     *nn = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a, cN)) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b, cN)) << 32);
 }
-AVX2_T static inline uint64_t nlmask_avx2(const uint8_t *p)
+AVX2_T static inline uint64_t eqmask_avx2(const uint8_t *p, char ch)
 {
-    const __m256i cn = _mm256_set1_epi8('\n');
+    const __m256i cn = _mm256_set1_epi8(ch);
     return (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)p), cn)) |
            ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + 32)), cn)) << 32);
 }
 #define QM2_ISA avx2
 #define QM2_TARGET AVX2_T
 #define QM2_MASKS64(p, hi, lo, nl, nn) masks64_avx2((const uint8_t *)(p), hi, lo, nl, nn)
-#define QM2_NLMASK(p) nlmask_avx2((const uint8_t *)(p))
+#define QM2_NLMASK(p) eqmask_avx2((const uint8_t *)(p), '\n')
+#define QM2_GTMASK(p) eqmask_avx2((const uint8_t *)(p), '>')
+#define QM2_HAVE_PEXT 1
 #define QM2_SPREAD(x) _pdep_u64((uint64_t)(x), 0x5555555555555555ull)
 #include "qm2_pack_body.h"
 #undef QM2_ISA
 #undef QM2_TARGET
 #undef QM2_MASKS64
 #undef QM2_NLMASK
+#undef QM2_GTMASK
+#undef QM2_HAVE_PEXT
 #undef QM2_SPREAD
 
 #define AVX512_T __attribute__((target("avx512f,avx512bw,bmi2")))
@@ -149,12 +154,16 @@ AVX512_T static inline void masks64_avx512(const uint8_t *p, uint64_t *hi, uint6
 #define QM2_TARGET AVX512_T
 #define QM2_MASKS64(p, hi, lo, nl, nn) masks64_avx512((const uint8_t *)(p), hi, lo, nl, nn)
 #define QM2_NLMASK(p) ((uint64_t)_mm512_cmpeq_epi8_mask(_mm512_loadu_si512((const void *)(p)), _mm512_set1_epi8('\n')))
+#define QM2_GTMASK(p) ((uint64_t)_mm512_cmpeq_epi8_mask(_mm512_loadu_si512((const void *)(p)), _mm512_set1_epi8('>')))
+#define QM2_HAVE_PEXT 1
 #define QM2_SPREAD(x) _pdep_u64((uint64_t)(x), 0x5555555555555555ull)
 #include "qm2_pack_body.h"
 #undef QM2_ISA
 #undef QM2_TARGET
 #undef QM2_MASKS64
 #undef QM2_NLMASK
+#undef QM2_GTMASK
+#undef QM2_HAVE_PEXT
 #undef QM2_SPREAD
 #endif
 

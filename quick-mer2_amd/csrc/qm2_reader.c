@@ -34,6 +34,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "qm2_host.h"
@@ -183,6 +184,16 @@ static int pack_whole_lines(const char *p, size_t n, line_state *st, char *obuf,
     return 0;
 }
 
+static int pack_whole_lines_cap(const char *p, size_t n, line_state *st, char *obuf, size_t ocap, qm2_packed *packed, uint64_t *wraps, size_t wraps_cap)
+{
+    qm2_line_state ps = {(uint32_t)st->fastq, (uint32_t)st->skip, 0};
+    const int rc = qm2_pack_reads(p, n, &ps, obuf, ocap, wraps, wraps_cap, packed);
+    if (rc) return rc;
+    st->skip = (int)ps.skip;
+    if (ps.desync) st->desync = 1;
+    return 0;
+}
+
 static void strip_block(strip_job *j)
 {
     j->is_packed = 0;
@@ -301,6 +312,7 @@ typedef struct {
     line_state  st_end;
     int         too_big, rc;
     int         raw_mode;                  /* read straight into obuf, do not strip */
+    double      t_read, t_count, t_wait, t_pack;   /* QM2_READER_TIMING */
     int         pack_mode;                 /* strip and pack (qm2_lines_out.commit_packed) */
     int         is_packed;                 /* obuf holds `packed` */
     qm2_packed  packed;
@@ -385,6 +397,9 @@ static line_state pf_state(const pf_shared *sh, size_t before)
     return st;
 }
 
+/* QM2_READER_TIMING=1: where the block workers' time goes (seconds summed over the workers, printed at the end of the file) */
+static double pf_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
 static void *pf_main(void *arg)
 {
     pf_worker *w = (pf_worker *)arg;
@@ -394,13 +409,17 @@ static void *pf_main(void *arg)
         if (w->quit) return NULL;
         const size_t b = w->block;
         w->olen = 0; w->too_big = 0;
+        const double t0 = pf_now();
         w->rc = atomic_load(&sh->stop) ? 0 : pf_load(w);
+        const double t1 = pf_now();
         if (w->too_big) w->lo = w->hi = 0;
         if (w->rc || atomic_load(&sh->stop)) w->lo = w->hi = 0;
         /* (FASTA has no line numbering to keep: a line is dropped for its first byte alone, :398) */
         size_t lines = sh->fastq ? count_newlines(w->raw + w->lo, w->hi - w->lo) : 0;
         if (sh->fastq && w->hi > w->lo && w->raw[w->hi - 1] != '\n') lines++;       /* last line of the file, no newline */
+        const double t2 = pf_now();
         while (!atomic_load_explicit(&sh->known[b], memory_order_acquire) && !atomic_load(&sh->stop)) sched_yield();
+        const double t3 = pf_now();
         w->before = sh->lines_before[b];
         sh->lines_before[b + 1] = w->before + lines;
         atomic_store_explicit(&sh->known[b + 1], 1, memory_order_release);
@@ -422,6 +441,7 @@ static void *pf_main(void *arg)
             }
         }
         w->st_end = st;
+        w->t_read += t1 - t0; w->t_count += t2 - t1; w->t_wait += t3 - t2; w->t_pack += pf_now() - t3;
         sem_post(&w->done);
     }
 }
@@ -563,6 +583,7 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
     }
     if (!rc) rc = out_flush(&os);
     else if (os.buf) (void)out->commit(out->user, os.buf, 0);
+    double t_read = 0, t_count = 0, t_wait = 0, t_pack = 0;
     for (int w = 0; w < n_workers; w++) {
         ws[w].quit = 1;
         sem_post(&ws[w].start);
@@ -570,8 +591,270 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
         sem_destroy(&ws[w].start);
         sem_destroy(&ws[w].done);
         if (!raw_mode) free(ws[w].raw);
+        t_read += ws[w].t_read; t_count += ws[w].t_count; t_wait += ws[w].t_wait; t_pack += ws[w].t_pack;
     }
+    if (getenv("QM2_READER_TIMING"))
+        printf("QM2 reader: %d workers, %zu blocks of %zu bytes; seconds summed over the workers: pread %.3f, newline count %.3f, waiting for the line count of the blocks before %.3f, %s %.3f\n",
+               n_workers, sh.n_blocks, sh.block, t_read, t_count, t_wait, raw_mode ? "-" : "strip / pack", t_pack);
     free(sh.lines_before); free(sh.known); free(ws); free(tids);
+    return rc;
+}
+
+
+/* ---- regular files, packed hand-over: small blocks that stay in the cache, no per-block hand-off ----------------- *
+ * (ABI 6.)  With the packing on the host the link no longer bounds the count phase — the reader does: pread's copy out
+ * of the page cache, the newline count, the line discipline and the packing all pass over the text.  Measured on the
+ * GPU box's host (tools/micro/mmap_probe, reader_probe; profiles/r05_c3/micro_*.txt): pread into a private buffer and
+ * packing from it runs at 80-85 GB/s of FASTQ text with 32 MiB blocks and 16 threads, at 140-146 GB/s with 4 MiB blocks
+ * (the private buffer stays in the thread's L2 / L3 share: pread writes and the two passes read cache, not DRAM);
+ * mapping the file costs more in page-table work than it saves.  Hence this arrangement:
+ *   - blocks of 4 MiB (QM2_BLOCK_BYTES overrides), block b OWNS the lines that start inside it (pf_load, as above);
+ *   - the workers take blocks from a shared counter themselves; nothing is handed over per block;
+ *   - FASTQ: a worker counts its block's lines while the block is hot, publishes the count, and waits for the count of
+ *     the blocks before it (they are being read at the same moment by the other workers) — the line state at its first
+ *     line follows from that (pf_state);
+ *   - it packs what the line discipline keeps (qm2_pack_reads) BEHIND the pieces already in its own staging buffer:
+ *     a piece is whole 64-position blocks, so pieces simply follow each other; only full buffers travel to the calling
+ *     thread, which commits them (qm2_lines_out.commit_packed) as they come — counting does not care about the order;
+ *   - a FASTQ sequence-position line that starts with '>' (QuicKmer.c:398: dropped WITHOUT the three discards) makes the
+ *     line state of every later block something the line count does not give; pieces of later blocks may already have
+ *     been committed by then, so the whole input is given up: return 3, and the caller starts over from zeroed counters
+ *     without commit_packed (the serial-exact path above).  A block that does not pack (more run-counter wraps than a
+ *     piece's list holds) goes through out->submit as ASCII lines. */
+typedef struct pk_buf {
+    char       *buf;                       /* a staging buffer from out->acquire; NULL: `ascii` is malloc'ed lines for out->submit */
+    size_t      cap;
+    qm2_packed  p;                         /* the pieces in it, as one */
+    uint64_t    wraps[QM2_WRAPS_CAP];
+    char       *ascii;
+    size_t      ascii_len;
+    struct pk_buf *next;
+} pk_buf;
+
+typedef struct {
+    pf_shared        sh;
+    atomic_size_t    next_block;
+    pthread_mutex_t  mu;
+    pthread_cond_t   cv_free, cv_main;
+    pk_buf          *free_q, *full_q, *full_tail;
+    int              workers_active, failed, desync, closing;
+} pk_shared;
+
+typedef struct { pk_shared *ps; pf_worker w; double t_read, t_count, t_wait, t_pack; } pk_worker;
+
+static pk_buf *pk_get_free(pk_shared *ps)
+{
+    pthread_mutex_lock(&ps->mu);
+    while (!ps->free_q && !ps->closing) { pthread_cond_signal(&ps->cv_main); pthread_cond_wait(&ps->cv_free, &ps->mu); }
+    pk_buf *b = ps->free_q;
+    if (b) ps->free_q = b->next;
+    pthread_mutex_unlock(&ps->mu);
+    if (b) { b->next = NULL; memset(&b->p, 0, sizeof b->p); }
+    return b;
+}
+
+static void pk_put_full(pk_shared *ps, pk_buf *b)
+{
+    b->next = NULL;
+    pthread_mutex_lock(&ps->mu);
+    if (ps->full_tail) ps->full_tail->next = b; else ps->full_q = b;
+    ps->full_tail = b;
+    pthread_cond_signal(&ps->cv_main);
+    pthread_mutex_unlock(&ps->mu);
+}
+
+static void *pk_main(void *arg)
+{
+    pk_worker *kw = arg;
+    pk_shared *ps = kw->ps;
+    pf_shared *sh = &ps->sh;
+    pf_worker *w = &kw->w;
+    pk_buf *cur = NULL;
+    int failed = 0;
+    for (;;) {
+        const size_t b = atomic_fetch_add(&ps->next_block, 1);
+        if (b >= sh->n_blocks) break;
+        w->block = b;
+        const double t0 = pf_now();
+        int rc = atomic_load(&sh->stop) ? 0 : pf_load(w);
+        if (rc || atomic_load(&sh->stop)) w->lo = w->hi = 0;
+        const double t1 = pf_now();
+        size_t lines = sh->fastq ? count_newlines(w->raw + w->lo, w->hi - w->lo) : 0;
+        if (sh->fastq && w->hi > w->lo && w->raw[w->hi - 1] != '\n') lines++;       /* last line of the file, no newline */
+        const double t2 = pf_now();
+        while (!atomic_load_explicit(&sh->known[b], memory_order_acquire) && !atomic_load(&sh->stop)) sched_yield();
+        const size_t before = sh->lines_before[b];
+        sh->lines_before[b + 1] = before + lines;
+        atomic_store_explicit(&sh->known[b + 1], 1, memory_order_release);
+        const double t3 = pf_now();
+        kw->t_read += t1 - t0; kw->t_count += t2 - t1; kw->t_wait += t3 - t2;
+        if (rc) { failed = 1; break; }
+        if (atomic_load(&sh->stop)) break;
+        if (w->hi == w->lo) continue;
+        const size_t n = w->hi - w->lo, need = qm2_packed_bound(n);
+        if (cur && (cur->cap - (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES < need || cur->p.n_wraps + 8 > QM2_WRAPS_CAP)) { pk_put_full(ps, cur); cur = NULL; }
+        if (!cur) { cur = pk_get_free(ps); if (!cur) break; }
+        line_state st = pf_state(sh, before);
+        qm2_packed piece;
+        uint64_t *wr = cur->wraps + cur->p.n_wraps;
+        int prc = need <= cur->cap - (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES
+                      ? pack_whole_lines_cap(w->raw + w->lo, n, &st, cur->buf + (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES,
+                                             cur->cap - (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES, &piece, wr, QM2_WRAPS_CAP - (size_t)cur->p.n_wraps)
+                      : 2;
+        if (prc == 1) { failed = 1; break; }
+        if (prc == 2) {                                  /* does not pack (or is larger than a whole buffer): as ASCII lines */
+            pk_buf *a = calloc(1, sizeof *a);
+            char *lines_buf = malloc(n + 2);
+            if (!a || !lines_buf) { free(a); free(lines_buf); failed = 1; break; }
+            static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL, NULL, NULL};
+            out_state os = {&none, lines_buf, n + 2, 0};
+            st = pf_state(sh, before);
+            if (strip_range(w->raw + w->lo, n, &st, &os)) { free(a); free(lines_buf); failed = 1; break; }
+            a->ascii = lines_buf; a->ascii_len = os.len;
+            pk_put_full(ps, a);
+        } else {
+            const uint64_t pos0 = 64 * cur->p.n_blocks;
+            for (uint64_t i = 0; i < piece.n_wraps; i++) wr[i] += pos0;
+            cur->p.n_blocks += piece.n_blocks; cur->p.n_newlines += piece.n_newlines; cur->p.n_wraps += piece.n_wraps;
+        }
+        kw->t_pack += pf_now() - t3;
+        if (st.desync) {                                 /* the blocks behind this one were given a state that is not theirs */
+            pthread_mutex_lock(&ps->mu); ps->desync = 1; pthread_mutex_unlock(&ps->mu);
+            atomic_store(&sh->stop, 1);
+            break;
+        }
+    }
+    if (failed) atomic_store(&sh->stop, 1);
+    pthread_mutex_lock(&ps->mu);
+    if (failed) ps->failed = 1;
+    if (cur) {                                           /* what is in hand goes back, full or not (an empty one is just returned) */
+        cur->next = NULL;
+        if (ps->full_tail) ps->full_tail->next = cur; else ps->full_q = cur;
+        ps->full_tail = cur;
+    }
+    ps->workers_active--;
+    pthread_cond_signal(&ps->cv_main);
+    pthread_mutex_unlock(&ps->mu);
+    return NULL;
+}
+
+static int stream_blocks_packed(int fd, size_t size, const qm2_lines_out *out, int n_threads)
+{
+    pk_shared ps;
+    memset(&ps, 0, sizeof ps);
+    pf_shared *sh = &ps.sh;
+    sh->fd = fd; sh->size = size;
+    {
+        char head[1 << 12];
+        size_t off = 0;
+        ssize_t r = pread_full(fd, head, sizeof head, 0);
+        if (r < 0) return 1;
+        if (r > 0 && head[0] == '@') {                       /* :393-395: FASTQ, and that line is consumed */
+            sh->fastq = 1;
+            for (;;) {
+                const char *nl = memchr(head, '\n', (size_t)r);
+                if (nl) { sh->start = off + (size_t)(nl - head) + 1; break; }
+                off += (size_t)r;
+                r = pread_full(fd, head, sizeof head, off);
+                if (r <= 0) { sh->start = size; break; }
+            }
+        }
+    }
+    const char *env = getenv("QM2_BLOCK_BYTES");
+    sh->block = env ? qm2_reader_block_bytes() : ((size_t)4 << 20);
+    sh->n_blocks = (size - sh->start + sh->block - 1) / sh->block;
+    sh->lines_before = calloc(sh->n_blocks + 2, sizeof(size_t));
+    sh->known = calloc(sh->n_blocks + 2, sizeof(atomic_int));
+    pk_worker *ws = calloc((size_t)n_threads, sizeof *ws);
+    pthread_t *tids = calloc((size_t)n_threads, sizeof *tids);
+    pk_buf *bufs = calloc((size_t)n_threads + 1, sizeof *bufs);
+    int rc = 0;
+    if (!sh->lines_before || !sh->known || !ws || !tids || !bufs) { puts("Memory allocation failed"); rc = 1; }
+    pthread_mutex_init(&ps.mu, NULL);
+    pthread_cond_init(&ps.cv_free, NULL);
+    pthread_cond_init(&ps.cv_main, NULL);
+    int n_workers = 0, n_bufs = 0;
+    if (!rc) {
+        atomic_store(&sh->known[0], 1);
+        /* the buffers the workers fill: as many as there are workers + 1 (what qm2_stream_reads promises to hold at a time) */
+        for (int i = 0; i < n_threads + 1 && (size_t)i < sh->n_blocks + 1; i++) {
+            if (out->acquire(out->user, &bufs[i].buf, &bufs[i].cap)) { rc = 1; break; }
+            n_bufs++;
+            bufs[i].next = ps.free_q;
+            ps.free_q = &bufs[i];
+        }
+        ps.workers_active = 0;
+        for (int t = 0; t < n_threads && (size_t)t < sh->n_blocks && !rc; t++) {
+            ws[t].ps = &ps;
+            ws[t].w.sh = sh;
+            ws[t].w.raw_cap = sh->block + ((size_t)1 << 20);
+            ws[t].w.raw = malloc(ws[t].w.raw_cap);
+            if (!ws[t].w.raw) break;
+            pthread_mutex_lock(&ps.mu); ps.workers_active++; pthread_mutex_unlock(&ps.mu);
+            if (pthread_create(&tids[t], NULL, pk_main, &ws[t])) {
+                pthread_mutex_lock(&ps.mu); ps.workers_active--; pthread_mutex_unlock(&ps.mu);
+                free(ws[t].w.raw); ws[t].w.raw = NULL;
+                break;
+            }
+            n_workers++;
+        }
+        if (!n_workers && sh->n_blocks) { puts("Memory allocation failed"); rc = 1; }
+    }
+    /* the calling thread: commit what comes back full, lend the buffer out again */
+    while (!rc) {
+        pthread_mutex_lock(&ps.mu);
+        while (!ps.full_q && ps.workers_active > 0) pthread_cond_wait(&ps.cv_main, &ps.mu);
+        pk_buf *b = ps.full_q;
+        if (b) { ps.full_q = b->next; if (!ps.full_q) ps.full_tail = NULL; }
+        const int active = ps.workers_active;
+        pthread_mutex_unlock(&ps.mu);
+        if (!b) { if (active == 0) break; continue; }
+        if (b->ascii) {                                      /* lines that did not pack */
+            if (out->submit(out->user, b->ascii, b->ascii_len)) rc = 1;
+            free(b->ascii);
+            free(b);
+            continue;
+        }
+        if (b->p.n_blocks ? out->commit_packed(out->user, b->buf, &b->p, b->wraps) : out->commit(out->user, b->buf, 0)) { rc = 1; b->buf = NULL; break; }
+        b->buf = NULL;
+        pthread_mutex_lock(&ps.mu);
+        const int more = ps.workers_active > 0;
+        pthread_mutex_unlock(&ps.mu);
+        if (more) {
+            if (out->acquire(out->user, &b->buf, &b->cap)) { rc = 1; break; }
+            pthread_mutex_lock(&ps.mu);
+            b->next = ps.free_q; ps.free_q = b;
+            pthread_cond_signal(&ps.cv_free);
+            pthread_mutex_unlock(&ps.mu);
+        }
+    }
+    /* shut down: wake whoever waits for a buffer, join, give the buffers back */
+    if (rc) atomic_store(&sh->stop, 1);
+    pthread_mutex_lock(&ps.mu);
+    ps.closing = 1;
+    pthread_cond_broadcast(&ps.cv_free);
+    pthread_mutex_unlock(&ps.mu);
+    double t_read = 0, t_count = 0, t_wait = 0, t_pack = 0;
+    for (int t = 0; t < n_workers; t++) {
+        pthread_join(tids[t], NULL);
+        free(ws[t].w.raw);
+        t_read += ws[t].t_read; t_count += ws[t].t_count; t_wait += ws[t].t_wait; t_pack += ws[t].t_pack;
+    }
+    for (pk_buf *b = ps.full_q; b;) {                        /* (after an error: pieces nobody committed) */
+        pk_buf *nx = b->next;
+        if (b->ascii) { free(b->ascii); free(b); }
+        b = nx;
+    }
+    for (int i = 0; i < n_bufs; i++) if (bufs[i].buf) (void)out->commit(out->user, bufs[i].buf, 0);
+    if (getenv("QM2_READER_TIMING"))
+        printf("QM2 reader: %d workers, %zu blocks of %zu bytes, packed; seconds summed over the workers: pread %.3f, newline count %.3f, waiting for the line count of the blocks before %.3f, line discipline + packing %.3f\n",
+               n_workers, sh->n_blocks, sh->block, t_read, t_count, t_wait, t_pack);
+    if (!rc && ps.failed) rc = 1;
+    if (!rc && ps.desync) rc = 3;
+    pthread_mutex_destroy(&ps.mu);
+    pthread_cond_destroy(&ps.cv_free);
+    pthread_cond_destroy(&ps.cv_main);
+    free(sh->lines_before); free(sh->known); free(ws); free(tids); free(bufs);
     return rc;
 }
 
@@ -594,7 +877,9 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads)
         char first = 0;
         if (fstat(ring.fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && pread(ring.fd, &first, 1, 0) == 1 &&
             (first == '@' || getenv("QM2_READER_BLOCKS") || out->commit_raw || out->commit_packed)) {
-            const int brc = stream_blocks(ring.fd, (size_t)sb.st_size, out, n_threads);
+            const int brc = out->commit_packed && !out->commit_raw && !getenv("QM2_READER_OLD_BLOCKS")
+                                ? stream_blocks_packed(ring.fd, (size_t)sb.st_size, out, n_threads)
+                                : stream_blocks(ring.fd, (size_t)sb.st_size, out, n_threads);
             close(ring.fd);
             return brc;
         }

@@ -133,15 +133,20 @@ int main(int argc, char **argv) { O = fopen(argv[2], "wb"); CAP = (size_t)atol(a
     subprocess.run(["gcc", "-O1", "-pthread", "-I", src, "-o", exe, str(harness),
                     os.path.join(src, "qm2_reader.c"), os.path.join(src, "qm2_pack.c")], check=True)
 
-    def content(codes, bad):
-        """what of a position stream the k-mers depend on: the codes of the non-reset positions, and between which
-        of them a reset lies (a packed piece does not tell a line end from an 'N', and ends in filler)"""
+    def runs_of(codes, bad):
+        """What of a position stream the k-mers depend on, whatever order its pieces came in: the multiset of its runs of
+        non-reset positions (a packed piece does not tell a line end from an 'N', ends in filler, and the reader's workers
+        hand their pieces over as they fill up)."""
         good = np.flatnonzero(~bad)
-        return codes[good], np.diff(good) > 1, len(good)
+        if len(good) == 0:
+            return []
+        cut = np.flatnonzero(np.diff(good) > 1) + 1
+        c = codes[good].astype(np.uint8)
+        return sorted(x.tobytes() for x in np.split(c, cut))
 
     def packed_content(blob):
         import test_pack_cpu as tp
-        codes, bad, at, n_newlines = [], [], 0, 0
+        runs, at, n_newlines, n_pos = [], 0, 0, 0
         while at < len(blob):
             a, nl, nw = np.frombuffer(blob, dtype=np.uint64, count=3, offset=at)
             at += 24
@@ -152,13 +157,12 @@ int main(int argc, char **argv) { O = fopen(argv[2], "wb"); CAP = (size_t)atol(a
                 n_newlines += int(nl)
             else:                                       # ASCII lines
                 c, b = tp.expect(blob[at:at + int(a)])
+                n_newlines += blob[at:at + int(a)].count(b"\n")
                 at += int(a)
-                n_newlines += int(np.count_nonzero(np.frombuffer(blob[at - int(a):at], np.uint8) == 10))
-            codes.append(c)
-            bad.append(b)
-        codes = np.concatenate(codes) if codes else np.zeros(0, np.uint8)
-        bad = np.concatenate(bad) if bad else np.zeros(0, bool)
-        return content(codes, bad), len(codes) - n_newlines
+            runs += runs_of(c, b)
+            n_pos += len(c)
+        return sorted(runs), n_pos - n_newlines
+
     import oracle_lib as ol
     import synth
     cases = synth.kat_cases(synth.kat_reference())
@@ -194,14 +198,21 @@ int main(int argc, char **argv) { O = fopen(argv[2], "wb"); CAP = (size_t)atol(a
         # oracle's stripped stream, position for position (modulo filler), and its base count
         import test_pack_cpu as tp
         ec, eb = tp.expect(exp)
-        want, want_bases = content(ec, eb), len(exp) - exp.count(b"\n")
+        want, want_bases = runs_of(ec, eb), len(exp) - exp.count(b"\n")
         for batch, thr in ((64 << 20, 1), (64 << 20, 3), (64 << 20, 8), (40 << 20, 2)):
-            for env in ({}, {"QM2_READER_STREAM": "1"}):
+            for env in ({}, {"QM2_READER_STREAM": "1"}, {"QM2_BLOCK_BYTES": "65536"}, {"QM2_READER_OLD_BLOCKS": "1"}):
                 outp = str(tmp_path / "packed.bin")
-                subprocess.run([exe, str(p), outp, str(batch), str(thr), "packed"], check=True, env=dict(os.environ, **env))
+                r = subprocess.run([exe, str(p), outp, str(batch), str(thr), "packed"], env=dict(os.environ, **env))
+                if r.returncode == 3:
+                    # a '>' at a FASTQ sequence position: the block reader's pieces are in no order, it gives the input up
+                    # (the CLI then starts over on the in-order path); the streaming arrangement follows it serially
+                    assert name == "fq_desync" and "QM2_READER_STREAM" not in env and "QM2_READER_OLD_BLOCKS" not in env, (name, env)
+                    continue
+                assert r.returncode == 0, (name, thr, env)
+                assert not (name == "fq_desync" and ("QM2_READER_STREAM" not in env and "QM2_READER_OLD_BLOCKS" not in env)), (name, env)
                 got, got_bases = packed_content(open(outp, "rb").read())
                 assert got_bases == want_bases, (name, thr, env)
-                assert got[2] == want[2] and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (name, thr, env)
+                assert got == want, (name, thr, env)
         # raw hand-over (QM2_READER=raw): blocks of untouched text + the line state at their
         # first byte; applying the device's rule (tests restate it here) to each block must give `exp`
         if name not in ("fq_desync", "gt_in_fastq_seq_pos"):

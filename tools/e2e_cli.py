@@ -11,8 +11,8 @@ Checks on the way: the reference's progress lines (`Read %liG kmers`, QuicKmer.c
 n_kmers >> 30, and no allocation happens inside the count phase (qm2_prepare)."""
 import os
 import re
+import hashlib
 import subprocess
-import xxhash
 import sys
 import time
 
@@ -99,16 +99,17 @@ if os.environ.get("QM2_E2E_SETTLE"):
     time.sleep(float(os.environ["QM2_E2E_SETTLE"]))
 cli = os.environ.get("QM2_E2E_CLI") or os.path.join(ROOT, "quick-mer2_amd", "quicKmer2")
 runs = [(f, t, e) for f in ("reads.fq", "reads.fa")
-        for t, e in (("4", {}), ("8", {}), ("12", {}), ("8", {"QM2_READER_RAW": "0"}), ("4", {"QM2_READER_RAW": "0", "QM2_READER_STREAM": "1"}))]
+        for t, e in (("8", {}), ("12", {}), ("16", {}), ("12", {"QM2_READER": "raw"}), ("8", {"QM2_READER": "lines"}), ("4", {"QM2_READER": "lines", "QM2_READER_STREAM": "1"}))]
 reps = 4
 if scale == "c3":
-    runs, reps = [("reads.fq", "8", {}), ("reads.fq", "12", {})], 2
-# QM2_E2E_RUNS="fq:12,fq:24,fq:12:0+0,fa:8::host,fa:12:s0": file : threads [: devices joined by '+' (s0+1 = --shards 0,1)] [: host]
+    runs, reps = [("reads.fq", "12", {}), ("reads.fq", "16", {}), ("reads.fq", "12", {"QM2_READER": "raw"})], 2
+# QM2_E2E_RUNS="fq:12,fq:24,fq:12:0+0,fa:8::lines,fa:12:s0,fq:12::raw": file : threads [: devices joined by '+' (s0+1 = --shards 0,1)]
+# [: packed | raw | lines (QM2_READER; "host" = lines)]
 if os.environ.get("QM2_E2E_RUNS"):
     runs = []
     for item in os.environ["QM2_E2E_RUNS"].split(","):
         f = item.split(":") + ["", "", ""]
-        extra = {"QM2_READER_RAW": "0"} if f[3] == "host" else {}
+        extra = {"QM2_READER": {"host": "lines"}.get(f[3], f[3])} if f[3] else {}
         if f[2]:
             extra["_devices"] = f[2].replace("+", ",")
         runs.append(("reads." + f[0], f[1], extra))
@@ -135,7 +136,7 @@ for name, thr, extra in runs:
     # the outputs of every arrangement of the same input have to be the same bytes (.bin: the depth per dictionary k-mer, .txt: the GC curve)
     sums = []
     for suffix in (".bin", ".txt"):
-        h = xxhash.xxh3_128()
+        h = hashlib.blake2b(digest_size=16)
         try:
             with open(os.path.join(work, "out" + suffix), "rb") as fh:
                 for piece in iter(lambda: fh.read(1 << 26), b""):
@@ -152,13 +153,14 @@ for name, thr, extra in runs:
     ok = ok and bool(good)
     print("== %s -t %s %s%s rc=%d  count phase best: %.3f s = %.2f G bases/s; wall best %.2f s (incl. .qm load, upload, epilogue); "
           "progress lines %d, allocations in the count phase %s%s | %s" %
-          (name, thr, ("--devices %s " % devs) if devs else "", "host strip, read(2) stream" if "QM2_READER_STREAM" in extra else "host strip, pread blocks" if extra else "device line discipline",
+          (name, thr, ("--devices %s " % devs) if devs else "", "host strip, read(2) stream" if "QM2_READER_STREAM" in extra else
+           {"lines": "host strip to ASCII lines, pread blocks", "raw": "raw text, device line discipline", "packed": "packed by the reader threads"}[extra.get("QM2_READER", "packed")],
            r.returncode, best, n_reads * 150 / best / 1e9, min(walls), len(prog), al.group(1) if al else "?", "" if good else "  <-- CHECK FAILED",
            load.group(0) if load else ""), flush=True)
 for name, got in out_sums.items():
     same = len(set(got)) == 1 and "missing" not in got[0]
     ok = ok and same
-    print("== %s: .bin and .txt of the %d arrangements above are the same bytes: %s (xxh3-128 %s / %s)" % (name, len(got), same, got[0][0], got[0][1]), flush=True)
+    print("== %s: .bin and .txt of the %d arrangements above are the same bytes: %s (blake2b-128 %s / %s)" % (name, len(got), same, got[0][0], got[0][1]), flush=True)
 print(out)
 for d_ in {work, reads_dir}:
     shutil.rmtree(d_, ignore_errors=True)
