@@ -263,6 +263,11 @@ def cpu_legs(args, wl, pyqm2, torch, keys, buf0, nbytes0, H, k, local, n_unique)
     return out
 
 
+def part_like(p1, p0):
+    """the timed steps ran the partitioned pipeline (the realistic batch is only meaningful on the same path)"""
+    return p1["partitioned_batches"] - p0["partitioned_batches"] > 0
+
+
 def sum64(torch, counters, piece=1 << 28):
     """Sum of a large int32 tensor in int64 without a full-size int64 temporary."""
     return sum(int(counters[a:a + piece].sum(dtype=torch.int64)) for a in range(0, counters.numel(), piece))
@@ -458,6 +463,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-binary", action="store_true", help="CPU leg: the oracle port only")
     ap.add_argument("--no-streamed", action="store_true", help="skip the host-fed (PCIe-inclusive) regions")
+    ap.add_argument("--no-realistic", action="store_true", help="skip the c3r batch (half the reads from elsewhere, 5 % from 1000 repeat families)")
     ap.add_argument("--no-random-access", action="store_true", help="skip the random-access microbenchmark (roofline.random_access)")
     ap.add_argument("--no-geometry-check", action="store_true",
                     help="skip the partitioned-vs-direct comparison of all counters at the benchmarked batch geometry")
@@ -704,6 +710,64 @@ def main():
                     "bytes": gbytes, "partitioned": {"checksum": "%016x" % cs_p[0], "sum": cs_p[1], "nonzero_slots": cs_p[2], **gp},
                     "direct": {"checksum": "%016x" % cs_d[0], "sum": cs_d[1], "nonzero_slots": cs_d[2], **gd}}
         assert geometry["equal"], geometry
+
+    # ---- a less friendly batch beside the friendly one: the steps above read reads drawn from the dictionary's own
+    #      genome (hit fraction 0.85); real WGS against a unique-k-mer dictionary hits about half and has repeat
+    #      families.  c3r = the last resident batch with every second read replaced by random sequence (what an unrelated genome's
+    #      reads are to this table: no hits) and 5 % of the reads replaced by copies of 1000 reads (every k-mer of those occurs
+    #      ~3000 times per batch: the spill list's case, tools/heavy_hitters.py).  Same table, same context, same plan. ----
+    realistic = None
+    if rank == 0 and world == 1 and not args.no_realistic and n_batches >= 3 and wl["len_lo"] == wl["len_hi"] and part_like(prof1, prof0):
+        rl_, m_ = wl["len_lo"], wl["reads"]
+        rbuf, rbytes, rbases = batches[n_batches - 1]
+        rows = rbuf.view(m_, rl_ + 1)
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        piece = 2_000_000
+        for a in range(1, m_, 2 * piece):                       # rows a, a + 2, ...: random reads
+            idx = torch.arange(a, min(m_, a + 2 * piece), 2, device=dev)
+            rows[idx, :rl_] = lut[torch.randint(0, 4, (idx.numel(), rl_), device=dev, generator=g, dtype=torch.int64)]
+            del idx
+        fam = rows[torch.arange(0, 2000, 2, device=dev)].clone()      # 1000 reads of the genome's own (even rows)
+        n_rep = m_ // 20
+        where = torch.randint(0, m_, (n_rep,), device=dev, generator=g)
+        rows[where] = fam[torch.randint(0, 1000, (n_rep,), device=dev, generator=g)]
+        del where, fam
+        torch.cuda.synchronize()
+        ctx.reset()
+        ctx.submit_device(rbuf.data_ptr(), rbytes)                    # warm-up + this batch's own statistics
+        _, rs = ctx.finish(want_depth=False)
+        rp0 = ctx.profile()
+        cs_p = pyqm2.tools.checksum_u32(counters.data_ptr(), H)
+        r_steps = max(3, args.steps // 4)
+        torch.cuda.synchronize()
+        tA = time.perf_counter()
+        for _ in range(r_steps):
+            ctx.submit_device(rbuf.data_ptr(), rbytes)
+        ctx.sync()
+        torch.cuda.synchronize()
+        r_sec = time.perf_counter() - tA
+        rp1 = ctx.profile()
+        ctx.reset()
+        dctx = pyqm2.Counter(None, hash_size=H, k=k, device=local, flags=pyqm2.FLAG_DIRECT, ext_keys=keys.data_ptr(),
+                             ext_counters=counters.data_ptr())
+        dctx.submit_device(rbuf.data_ptr(), rbytes)
+        _, rd = dctx.finish(want_depth=False)
+        dctx.close()
+        cs_d = pyqm2.tools.checksum_u32(counters.data_ptr(), H)
+        ctx.reset()
+        realistic = {"bases_per_s": round(r_steps * rs["n_bases"] / r_sec, 1), "ms_per_step": round(1e3 * r_sec / r_steps, 3), "steps": r_steps,
+                     "what": "c3r: the same table and plan; every second read random sequence (an unrelated genome's reads: no hits), 5 %% of the reads "
+                             "copies of 1000 reads (repeat families: ~%d copies of each of their k-mers per batch)" % (n_rep // 1000),
+                     "hit_fraction": round(rs["n_hits"] / max(1, rs["n_kmers"]), 4), "probes_per_kmer": round(rs["n_probes"] / max(1, rs["n_kmers"]), 4),
+                     "spilled_kmers_per_step": (rp1["spilled_kmers"] - rp0["spilled_kmers"]) // r_steps,
+                     "fallback_batches": rp1["fallback_batches"] - rp0["fallback_batches"],
+                     "kernel_ms_per_step": {c: round((rp1["class_ms"][c] - rp0["class_ms"][c]) / r_steps, 3) for c in rp1["class_ms"]
+                                            if rp1["class_ms"][c] - rp0["class_ms"][c] > 0.05 * r_steps},
+                     "partitioned_equals_direct": bool(cs_p == cs_d and rs == rd),
+                     "checksum": "%016x" % cs_p[0]}
+        assert realistic["partitioned_equals_direct"], (realistic, cs_d, rd)
 
     # ---- roofline: per-kernel HIP-event times (recorded on the stream the kernels run on) -----
     kern_ms = prof1["kernel_ms"] - prof0["kernel_ms"]
@@ -1014,6 +1078,8 @@ def main():
                        "fold_ms": round(fold_ms, 2),
                        "counts_conserved": counts_conserved, "spilled_kmers": prof1["spilled_kmers"] - prof0["spilled_kmers"]},
             "kernel_only_bases_per_s": roofline["kernel_only_bases_per_s"],
+            "realistic_bases_per_s": realistic["bases_per_s"] if realistic else None,
+            "realistic": realistic,
             "streamed_bases_per_s": streamed["streamed_bases_per_s"] if streamed else None,
             "h2d_GBps": streamed["h2d_GBps"] if streamed else None,
             "streamed": streamed,

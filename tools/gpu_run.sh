@@ -22,10 +22,11 @@ line() {                      # the figures of a bench line that one looks at fi
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 r = d["roofline"]
-print("%.2f G bases/s, %.3f ms/step, frac %.4f | %s | streamed %s / fastq %s | exact at the bench batch: %s | conserved: %s" % (
+print("%.2f G bases/s, %.3f ms/step, frac %.4f | %s | host-fed packed %s, FASTQ %s (ASCII %s, raw FASTQ %s) | realistic %s | exact at the bench batch: %s | conserved: %s" % (
     d["value"] / 1e9, d["ms_per_step"], r["frac"],
     {k: round(v["ms_per_step"], 2) for k, v in r.get("kernels", {}).items() if v["ms_per_step"] > 0.05} or r.get("kernel_ms_per_step"),
-    d.get("streamed_bases_per_s"), (d.get("streamed") or {}).get("streamed_raw_fastq_bases_per_s"),
+    d.get("streamed_bases_per_s"), (d.get("streamed") or {}).get("streamed_fastq_bases_per_s"), (d.get("streamed") or {}).get("streamed_ascii_bases_per_s"),
+    (d.get("streamed") or {}).get("streamed_raw_fastq_bases_per_s"), d.get("realistic_bases_per_s"),
     d["config"].get("partitioned_equals_direct_at_bench_batch"), d["config"].get("counts_conserved")))
 EOF
 }
@@ -45,11 +46,11 @@ bench)        # the driver's own command line (default workload), full line
     line $O/bench_default.json ;;
 quick)        # kernel work: a short bench without the CPU legs and streamed regions; extra args go to bench.py
     shift
-    step 300 $O/bench_quick${QM2_SUFFIX:-}.json python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-streamed "$@"
+    step 300 $O/bench_quick${QM2_SUFFIX:-}.json python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-streamed --no-random-access --no-realistic "$@"
     line $O/bench_quick${QM2_SUFFIX:-}.json ;;
 variant)      # the same with another build of the library: tools/gpu_run.sh variant <lib.so> <suffix> [bench args]
     lib=$2; suf=$3; shift 3
-    QM2_LIB=$PWD/$lib step 300 $O/bench_variant_$suf.json python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-streamed "$@"
+    QM2_LIB=$PWD/$lib step 300 $O/bench_variant_$suf.json python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-streamed --no-random-access --no-realistic "$@"
     line $O/bench_variant_$suf.json
     grep STAMPS $O/bench_variant_$suf.err || true ;;
 profile)      # rocprofv3 kernel trace + the PMC passes (tools/profile.sh), the SQ counters; summary under gpurun_out/prof_<tag>_<wl>/

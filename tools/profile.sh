@@ -13,7 +13,7 @@ ROOTDIR=$(pwd)
 OUT=$ROOTDIR/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-streamed --no-geometry-check --no-random-access $*"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-streamed --no-geometry-check --no-random-access --no-realistic $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err" || echo "trace pass failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_rd" -- python3 bench.py $ARGS > "$OUT/bench_pmc_rd.json" 2> "$OUT/pmc_rd.err" || echo "pmc_rd failed"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_wr" -- python3 bench.py $ARGS > "$OUT/bench_pmc_wr.json" 2> "$OUT/pmc_wr.err" || echo "pmc_wr failed"
