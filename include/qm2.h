@@ -324,6 +324,10 @@ int qm2_probe_subslabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint64_t sub_
  * peer_stride = n_regions, d_fill + g * n_subs, ...): the 8 sub-regions of a sender count as 8 peers. */
 int qm2_route_xcd_device(qm2_ctx *c, const void *d_seq_bytes, size_t n, const uint64_t *d_suppress, uint64_t n_suppress,
                          uint64_t *d_slabs, uint64_t region_cap, uint32_t n_regions, uint32_t *d_fill, uint64_t *d_call);
+/* ... for text that starts in the middle of a line (qm2_route_device_carry's contract).  ABI 6. */
+int qm2_route_xcd_device_carry(qm2_ctx *c, const void *d_seq_bytes, size_t n, uint32_t carry, const uint64_t *d_suppress,
+                               uint64_t n_suppress, uint64_t *d_slabs, uint64_t region_cap, uint32_t n_regions, uint32_t *d_fill,
+                               uint64_t *d_call);
 
 /* Probe + increment for an array of canonical k-mers already on this device
  * (QuicKmer.c:283-293: the worker's batch loop).  d_n (device u64, may be

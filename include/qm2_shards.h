@@ -22,6 +22,11 @@
  * The host looks at one word per rank and round (did every slab fit: skewed input such as poly-A sends everything
  * to one owner); a round that does not fit is cut at a line end and routed again — exact for any input.
  *
+ * QM2_SHARDS_ROUTE = xcd | flat picks the exchange layout.  flat: the above.  xcd (the default for tables of 2^23 slots
+ * and more): the senders route by 10 bits — G owners x 1024 / G sub-slabs, each in 8 per-XCD sub-regions of fixed
+ * capacity (qm2_route_xcd_device) — an owner's part travels as 8 whole blocks per sender with the fills alongside, and
+ * what a shard receives is the first level of its own partition (qm2_probe_subslabs_device: one split, not two).
+ *
  * The text is fed like qm2_staging_acquire / qm2_staging_commit / qm2_submit: whole '\n'-terminated sequence lines
  * (the CLI's host line discipline), dealt to the ranks a batch at a time.
  */
@@ -57,7 +62,9 @@ int qm2_shards_finish(qm2_shards *s, qm2_stats *st);
 qm2_ctx *qm2_shards_result(qm2_shards *s);
 
 /* what the run did: rounds, rounds that had to be cut and routed again, bytes that went over the wire */
-typedef struct { uint64_t rounds, rerouted, exchanged_bytes; } qm2_shards_info;
+typedef struct { uint64_t rounds, rerouted, exchanged_bytes; uint32_t ten_bit_route; uint32_t flat_fallbacks; } qm2_shards_info;
+/* (ten_bit_route: 1 = QM2_SHARDS_ROUTE=xcd is in force; flat_fallbacks: pieces that overflowed its sub-regions however they
+ *  were cut and went round with one slab per owner) */
 int qm2_shards_get_info(qm2_shards *s, qm2_shards_info *info);
 
 void qm2_shards_close(qm2_shards *s);

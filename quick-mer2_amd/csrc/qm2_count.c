@@ -398,8 +398,10 @@ static int count_on_shards(qm2_dict_file *d, const char *reads, int n_strip, con
             memset(&info, 0, sizeof info);
             (void)g_shards.get_info(S, &info);
             const double sec = (tc.tv_sec - tb.tv_sec) + 1e-9 * (tc.tv_nsec - tb.tv_nsec);
-            printf("QM2 phase count %.3f s (%.2f G bases/s) on %d hash-range shards: %llu rounds, %llu cut and routed again, %.2f GB exchanged\n",
-                   sec, st.n_bases / sec / 1e9, n_dev, (unsigned long long)info.rounds, (unsigned long long)info.rerouted, info.exchanged_bytes / 1e9);
+            printf("QM2 phase count %.3f s (%.2f G bases/s) on %d hash-range shards: %llu rounds, %llu cut and routed again, %.2f GB exchanged; %s, %u pieces fell back to one slab per owner\n",
+                   sec, st.n_bases / sec / 1e9, n_dev, (unsigned long long)info.rounds, (unsigned long long)info.rerouted, info.exchanged_bytes / 1e9,
+                   info.ten_bit_route ? "10-bit route (whole sub-slab blocks, one split behind the wire)" : "one slab per owner (filled parts, two splits behind the wire)",
+                   info.flat_fallbacks);
         }
         rc = qm2_write_outputs(d, g_shards.result(S), ref_prefix, out_prefix);
     }

@@ -1736,6 +1736,13 @@ extern "C" int qm2_route_xcd_device(qm2_ctx *c, const void *d_seq, size_t n, con
     return route_device(c, d_seq, n, d_sup, n_sup, d_slabs, region_cap, n_regions, 8, d_fill, d_call);
 }
 
+extern "C" int qm2_route_xcd_device_carry(qm2_ctx *c, const void *d_seq, size_t n, uint32_t carry, const uint64_t *d_sup, uint64_t n_sup,
+                                          uint64_t *d_slabs, uint64_t region_cap, uint32_t n_regions, uint32_t *d_fill, uint64_t *d_call)
+{
+    if (carry > kCarry || carry > n) return fail("qm2_route_xcd_device_carry: at most %u look-back bytes, and no more than the text", (unsigned)kCarry);
+    return route_device(c, d_seq, n, d_sup, n_sup, d_slabs, region_cap, n_regions, 8, d_fill, d_call, carry);
+}
+
 static int route_device(qm2_ctx *c, const void *d_seq, size_t n, const uint64_t *d_sup, uint64_t n_sup,
                         uint64_t *d_slabs, uint64_t slab_cap, uint32_t n_owners, uint32_t xcd_subs, uint32_t *d_fill, uint64_t *d_call,
                         uint32_t carry)

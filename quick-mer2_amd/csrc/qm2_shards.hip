@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -96,6 +97,20 @@ struct qm2_shards {
     uint32_t  k = 30;
     size_t    batch_bytes = 0, staging_bytes = (size_t)64 << 20, cap = 0;
     bool      fake = false, comms = false;
+    /* The exchange layout (QM2_SHARDS_ROUTE = xcd | flat).
+     *   flat  one slab per owner (qm2_route_device); only the filled part of a slab travels; the receiver splits what it
+     *         got twice (qm2_probe_slabs_device) — rounds 1-4's layout, and the fall-back for tables below 2^23 slots.
+     *   xcd   the senders' 10-bit route (qm2_route_xcd_device): 1024 regions = G owners x n_subs sub-slabs, each in 8
+     *         per-XCD sub-regions of a fixed capacity `cap`, x-major; an owner's part of it — 8 blocks of n_subs x cap
+     *         k-mers per sender — travels whole, fills alongside, and IS the first level of the receiver's own partition
+     *         (qm2_probe_subslabs_device: one split instead of two; 8 logical shards on one GPU: 94 % of a replica's
+     *         rate against 78 %, profiles/r04_c3/bench_sharded_8_logical_20M.json).  Which of the two the wire
+     *         prefers — whole blocks with ~13 % of room in them, or filled parts only — is for the first run on more
+     *         than one GPU to measure; both are exact. */
+    bool      xcd = false, xcd_now = false;   /* xcd_now / cap_now: the round being run (round_range's fall-back to one slab per owner) */
+    size_t    cap_now = 0, cap_flat = 0;
+    uint32_t  n_subs = 1;              /* xcd: sub-slabs per owner (1024 / G) */
+    size_t    n_fill = 0;              /* fill entries of a rank's route: G (flat) or 8 x 1024 (xcd) */
     std::vector<Rank> r;
     std::vector<Slot> slots;
     uint32_t  next_slot = 0;
@@ -104,7 +119,7 @@ struct qm2_shards {
     qm2::LineStream ls;             /* an over-long line across staged pieces: run-counter wraps, look-back */
     qm2_ctx  *result = nullptr;
     unsigned long long n_bases = 0, n_kmers = 0;
-    qm2_shards_info info = {0, 0, 0};
+    qm2_shards_info info = {0, 0, 0, 0, 0};
 };
 
 /* qm2_shard_span's rule with the keys read from the file: the owned range extended past its middle-facing edge over
@@ -157,9 +172,31 @@ extern "C" int qm2_shards_open(qm2_shards **out, int dict_fd, uint64_t hash_size
     s->batch_bytes = batch_bytes ? (size_t)batch_bytes
                                  : (size_t)std::min<uint64_t>(std::max<uint64_t>(per + per / 2, 1ull << 30), 6ull << 30);
     if (s->batch_bytes < 2 * s->staging_bytes) s->staging_bytes = std::max<size_t>(s->batch_bytes / 2, 4096);
+    {
+        /* the 10-bit route needs a shard whose own range leaves a level to split behind the sub-slabs (2^12-slot buckets,
+         * 10 routed bits: tables of 2^23 slots and more) and at most 1024 / 2 owners */
+        const char *mode = getenv("QM2_SHARDS_ROUTE");
+        const bool can = hash_size >= (1ull << 23) && n_devices <= 512 && k <= 30;
+        if (mode && !strcmp(mode, "xcd") && !can) { delete s; return fail("QM2_SHARDS_ROUTE=xcd needs a table of at least 2^23 slots (and k <= 30)"); }
+        s->xcd = can && !(mode && !strcmp(mode, "flat"));
+        s->n_subs = s->xcd ? 1024u / (uint32_t)n_devices : 1u;
+        s->n_fill = s->xcd ? (size_t)8 * 1024 : (size_t)n_devices;
+    }
+    if (s->xcd) {
+        /* a sub-region takes its share of a batch's k-mers (at most one per byte) with 12 % head-room and the spread of
+         * uniform hashing — what qm2_prepare gives the text level's own sub-regions; a round that overflows one is cut
+         * and routed again like a flat one */
+        const double mean = (double)s->batch_bytes / (8.0 * 1024.0);
+        s->cap = ((size_t)(mean * 1.12 + 8.0 * std::sqrt(mean + 1.0)) + 256) & ~(size_t)1;
+    } else
     /* a slab takes a rank's share of one batch with 30 % head-room (uniform hashing spreads the k-mers evenly) and at
      * least one whole commit, so that cutting a round — at commit ends, then rank by rank — always ends in pieces that fit */
     s->cap = (std::max<size_t>((size_t)((double)s->batch_bytes / n_devices * 1.3), s->staging_bytes) + 4096) & ~(size_t)1;
+    s->xcd_now = s->xcd;
+    s->cap_now = s->cap;
+    s->info.ten_bit_route = s->xcd ? 1u : 0u;
+    /* (one slab per owner, a whole commit wide: what a piece falls back to that overflows the 10-bit route however it is cut) */
+    s->cap_flat = (s->staging_bytes + 4096) & ~(size_t)1;
     s->r.resize((size_t)n_devices);
     *out = s;                            /* from here on qm2_shards_close cleans up */
     for (int g = 0; g < n_devices; g++) {
@@ -187,18 +224,22 @@ extern "C" int qm2_shards_open(qm2_shards **out, int dict_fd, uint64_t hash_size
         S_OK(hipSetDevice(R.dev));
         S_OK(hipMalloc((void **)&R.text, s->batch_bytes + 64));
         for (ExSet &e : R.set) {
-            S_OK(hipMalloc((void **)&e.slabs, (size_t)n_devices * s->cap * sizeof(uint64_t)));
-            S_OK(hipMalloc((void **)&e.recv, (size_t)n_devices * s->cap * sizeof(uint64_t)));
-            S_OK(hipMalloc((void **)&e.fill, (size_t)n_devices * sizeof(uint32_t)));
-            S_OK(hipMalloc((void **)&e.incoming, (size_t)n_devices * sizeof(uint32_t)));
+            /* (xcd: 8 x 1024 regions out, 8 G "peers" x n_subs sub-slabs in — the same number either way) */
+            const size_t n_regions = s->xcd ? (size_t)8 * 1024 : (size_t)n_devices;
+            const size_t elems = std::max(n_regions * s->cap, s->xcd ? (size_t)n_devices * s->cap_flat : (size_t)0);
+            S_OK(hipMalloc((void **)&e.slabs, elems * sizeof(uint64_t)));
+            if (n_devices > 1) S_OK(hipMalloc((void **)&e.recv, elems * sizeof(uint64_t)));
+            S_OK(hipMalloc((void **)&e.fill, s->n_fill * sizeof(uint32_t)));
+            S_OK(hipMalloc((void **)&e.incoming, s->n_fill * sizeof(uint32_t)));
             S_OK(hipMalloc((void **)&e.call, 3 * sizeof(unsigned long long)));
             S_OK(hipEventCreateWithFlags(&e.probed, hipEventDisableTiming));
         }
         S_OK(hipHostMalloc((void **)&R.call_host, 3 * sizeof(unsigned long long), hipHostMallocPortable));
-        S_OK(hipHostMalloc((void **)&R.fill_host, (size_t)n_devices * sizeof(uint32_t), hipHostMallocPortable));
-        S_OK(hipHostMalloc((void **)&R.incoming_host, (size_t)n_devices * sizeof(uint32_t), hipHostMallocPortable));
-        /* the shard's partition buffers, ahead of the first round */
-        if (qm2_prepare(R.ctx, (uint64_t)s->cap * (uint64_t)n_devices, 0)) return 1;
+        S_OK(hipHostMalloc((void **)&R.fill_host, s->n_fill * sizeof(uint32_t), hipHostMallocPortable));
+        S_OK(hipHostMalloc((void **)&R.incoming_host, s->n_fill * sizeof(uint32_t), hipHostMallocPortable));
+        /* the shard's partition buffers, ahead of the first round (xcd: the plan behind the sub-slabs is made by the first
+         * qm2_probe_subslabs_device, with the k-mers that really arrived as its bound) */
+        if (!s->xcd && qm2_prepare(R.ctx, (uint64_t)s->cap * (uint64_t)n_devices, 0)) return 1;
     }
     if (n_devices > 1 && !s->fake) {
         std::vector<ncclComm_t> comms((size_t)n_devices);
@@ -219,6 +260,10 @@ static int round_range(qm2_shards *s, const std::vector<size_t> &lo, const std::
 {
     const int G = s->G;
     const int w = s->turn;
+    /* (the layout of THIS round: the context's, or — a piece that overflows the 10-bit route's small regions however it is
+     * cut — one slab per owner in the same buffers, see below) */
+    const bool xcd = s->xcd_now;
+    const size_t cap = s->cap_now, n_fill = xcd ? s->n_fill : (size_t)G;
     bool any = false;
     for (int g = 0; g < G; g++) any = any || hi[(size_t)g] > lo[(size_t)g];
     if (!any) return 0;
@@ -237,7 +282,7 @@ static int round_range(qm2_shards *s, const std::vector<size_t> &lo, const std::
         e.busy = false;
         S_OK(hipSetDevice(R.dev));
         S_OK(hipStreamWaitEvent(R.s_route, R.copied, 0));
-        S_OK(hipMemsetAsync(e.fill, 0, (size_t)G * sizeof(uint32_t), R.s_route));
+        S_OK(hipMemsetAsync(e.fill, 0, n_fill * sizeof(uint32_t), R.s_route));
         S_OK(hipMemsetAsync(e.call, 0, 3 * sizeof(unsigned long long), R.s_route));
         if (hi[(size_t)g] > lo[(size_t)g]) {
             /* the piece's wrap positions, relative to its first byte (long lines are rare: a small blocking copy) */
@@ -253,13 +298,16 @@ static int round_range(qm2_shards *s, const std::vector<size_t> &lo, const std::
                 S_OK(hipMemcpy(R.d_wraps, sup.data(), sup.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
             }
             /* (a piece that starts at the text's first byte may start with the look-back of a cut line) */
-            if (qm2_route_device_carry(R.rctx, R.text + lo[(size_t)g], hi[(size_t)g] - lo[(size_t)g], lo[(size_t)g] == 0 ? (uint32_t)R.carry0 : 0u,
-                                       sup.empty() ? nullptr : R.d_wraps, sup.size(), e.slabs, s->cap, (uint32_t)G, e.fill, (uint64_t *)e.call))
+            const uint32_t carry = lo[(size_t)g] == 0 ? (uint32_t)R.carry0 : 0u;
+            if (xcd ? qm2_route_xcd_device_carry(R.rctx, R.text + lo[(size_t)g], hi[(size_t)g] - lo[(size_t)g], carry, sup.empty() ? nullptr : R.d_wraps,
+                                                    sup.size(), e.slabs, cap, 1024u, e.fill, (uint64_t *)e.call)
+                       : qm2_route_device_carry(R.rctx, R.text + lo[(size_t)g], hi[(size_t)g] - lo[(size_t)g], carry,
+                                                sup.empty() ? nullptr : R.d_wraps, sup.size(), e.slabs, cap, (uint32_t)G, e.fill, (uint64_t *)e.call))
                 return 1;
         }
         S_OK(hipSetDevice(R.dev));
         S_OK(hipMemcpyAsync(R.call_host, e.call, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.s_route));
-        S_OK(hipMemcpyAsync(R.fill_host, e.fill, (size_t)G * sizeof(uint32_t), hipMemcpyDeviceToHost, R.s_route));
+        S_OK(hipMemcpyAsync(R.fill_host, e.fill, n_fill * sizeof(uint32_t), hipMemcpyDeviceToHost, R.s_route));
     }
     bool unfit = false;
     for (int g = 0; g < G; g++) {
@@ -289,6 +337,18 @@ static int round_range(qm2_shards *s, const std::vector<size_t> &lo, const std::
              * k-mer): half of the ranks now, the others in a round of their own; one rank's one commit always fits */
             std::vector<int> live;
             for (int g = 0; g < G; g++) if (hi[(size_t)g] > lo[(size_t)g]) live.push_back(g);
+            if (live.size() < 2 && xcd) {
+                /* one commit of one rank, and a sub-region of the 10-bit route still overflows (a flood of one k-mer: poly-A):
+                 * this piece goes round with ONE slab per owner — in the same buffers, each slab a whole commit wide, so it
+                 * fits whatever it holds — and is split twice on the other side; the rounds behind it route by 10 bits again */
+                s->xcd_now = false;
+                s->cap_now = s->cap_flat;
+                s->info.flat_fallbacks++;
+                const int rc = round_range(s, lo, hi, depth + 1);
+                s->xcd_now = true;
+                s->cap_now = s->cap;
+                return rc;
+            }
             if (live.size() < 2) return fail("qm2 shards: the k-mers between two line ends do not fit an owner's slab (one line of a single repeated k-mer, longer than a rank's share of a batch?)");
             std::vector<size_t> hi_a(hi), lo_b(lo);
             for (size_t i = 0; i < live.size(); i++) {
@@ -311,7 +371,59 @@ static int round_range(qm2_shards *s, const std::vector<size_t> &lo, const std::
         S_OK(hipSetDevice(R.dev));
         S_OK(hipEventRecord(R.routed, R.s_route));
         S_OK(hipStreamWaitEvent(R.s_probe, R.routed, 0));
-        if (qm2_probe_slabs_device(R.ctx, R.set[w].slabs, s->cap, 1, R.set[w].fill)) return 1;
+        if (xcd) {
+            /* what was routed is what is probed: 8 "peers" (the router's XCD sub-regions) of 1024 sub-slabs, 1024 regions apart */
+            uint64_t bound = 0;
+            for (size_t i = 0; i < s->n_fill; i++) bound += std::min<uint64_t>(R.fill_host[i], cap);
+            if (qm2_probe_subslabs_device(R.ctx, R.set[w].slabs, cap, 8, 1024, 1024, R.set[w].fill, bound + 64)) return 1;
+        } else if (qm2_probe_slabs_device(R.ctx, R.set[w].slabs, cap, 1, R.set[w].fill)) return 1;
+    } else if (xcd) {
+        /* exchange, 10-bit route: sender g's region (x, p * n_subs + sub) -> receiver p's sub-slab ((x * G + g), sub): for
+         * every (sender, receiver, XCD) one block of n_subs x cap k-mers, whole; the fills travel through the host, which
+         * has them anyway (the fit verdict) */
+        const size_t ns = s->n_subs, blk = ns * cap;
+        std::vector<uint64_t> bound((size_t)G, 0);
+        for (int p = 0; p < G; p++)
+            for (int g = 0; g < G; g++)
+                for (int x = 0; x < 8; x++)
+                    for (size_t q = 0; q < ns; q++) {
+                        const uint32_t f = s->r[(size_t)g].fill_host[(size_t)x * 1024 + (size_t)p * ns + q];
+                        s->r[(size_t)p].incoming_host[((size_t)x * (size_t)G + (size_t)g) * ns + q] = f;
+                        bound[(size_t)p] += std::min<uint64_t>(f, cap);
+                    }
+        if (!s->fake) N_OK(ncclGroupStart());
+        for (int g = 0; g < G; g++) {
+            Rank &R = s->r[(size_t)g];
+            ExSet &e = R.set[w];
+            S_OK(hipSetDevice(R.dev));
+            S_OK(hipMemcpyAsync(e.incoming, R.incoming_host, n_fill * sizeof(uint32_t), hipMemcpyHostToDevice, R.s_route));
+            for (int p = 0; p < G; p++)
+                for (int x = 0; x < 8; x++) {
+                    const uint64_t *out = e.slabs + ((size_t)x * 1024 + (size_t)p * ns) * cap;
+                    if (p == g || s->fake) {
+                        S_OK(hipMemcpyAsync(s->r[(size_t)p].set[w].recv + ((size_t)x * (size_t)G + (size_t)g) * blk, out, blk * sizeof(uint64_t),
+                                            hipMemcpyDeviceToDevice, R.s_route));
+                        continue;
+                    }
+                    N_OK(ncclSend(out, blk, ncclUint64, p, R.comm, R.s_route));
+                    N_OK(ncclRecv(e.recv + ((size_t)x * (size_t)G + (size_t)p) * blk, blk, ncclUint64, p, R.comm, R.s_route));
+                    s->info.exchanged_bytes += blk * sizeof(uint64_t);
+                }
+        }
+        if (!s->fake) N_OK(ncclGroupEnd());
+        for (int g = 0; g < G; g++) {
+            Rank &R = s->r[(size_t)g];
+            S_OK(hipSetDevice(R.dev));
+            S_OK(hipEventRecord(R.routed, R.s_route));
+        }
+        for (int g = 0; g < G; g++) {
+            Rank &R = s->r[(size_t)g];
+            S_OK(hipSetDevice(R.dev));
+            for (int q = 0; q < G; q++)
+                if (q == g || s->fake) S_OK(hipStreamWaitEvent(R.s_probe, s->r[(size_t)q].routed, 0));
+            /* 8 G "peers" (sender x XCD) of n_subs sub-slabs, side by side: the first level of this shard's own partition */
+            if (qm2_probe_subslabs_device(R.ctx, R.set[w].recv, cap, 8u * (uint32_t)G, (uint32_t)ns, 0, R.set[w].incoming, bound[(size_t)g] + 64)) return 1;
+        }
     } else {
         for (int p = 0; p < G; p++)
             for (int g = 0; g < G; g++) s->r[(size_t)p].incoming_host[g] = s->r[(size_t)g].fill_host[p];
@@ -326,12 +438,12 @@ static int round_range(qm2_shards *s, const std::vector<size_t> &lo, const std::
                 if (p == g || s->fake) {
                     /* own slab (or, in the one-GPU rehearsal, every slab): a device-to-device copy into the receiver's buffer */
                     if (n_out)
-                        S_OK(hipMemcpyAsync(s->r[(size_t)p].set[w].recv + (size_t)g * s->cap, e.slabs + (size_t)p * s->cap, n_out * sizeof(uint64_t),
+                        S_OK(hipMemcpyAsync(s->r[(size_t)p].set[w].recv + (size_t)g * cap, e.slabs + (size_t)p * cap, n_out * sizeof(uint64_t),
                                             hipMemcpyDeviceToDevice, R.s_route));
                     continue;
                 }
-                if (n_out) N_OK(ncclSend(e.slabs + (size_t)p * s->cap, n_out, ncclUint64, p, R.comm, R.s_route));
-                if (n_in) N_OK(ncclRecv(e.recv + (size_t)p * s->cap, n_in, ncclUint64, p, R.comm, R.s_route));
+                if (n_out) N_OK(ncclSend(e.slabs + (size_t)p * cap, n_out, ncclUint64, p, R.comm, R.s_route));
+                if (n_in) N_OK(ncclRecv(e.recv + (size_t)p * cap, n_in, ncclUint64, p, R.comm, R.s_route));
                 s->info.exchanged_bytes += n_out * sizeof(uint64_t);
             }
         }
@@ -348,7 +460,7 @@ static int round_range(qm2_shards *s, const std::vector<size_t> &lo, const std::
             S_OK(hipSetDevice(R.dev));
             for (int q = 0; q < G; q++)
                 if (q == g || s->fake) S_OK(hipStreamWaitEvent(R.s_probe, s->r[(size_t)q].routed, 0));
-            if (qm2_probe_slabs_device(R.ctx, R.set[w].recv, s->cap, (uint32_t)G, R.set[w].incoming)) return 1;
+            if (qm2_probe_slabs_device(R.ctx, R.set[w].recv, cap, (uint32_t)G, R.set[w].incoming)) return 1;
         }
     }
     for (int g = 0; g < G; g++) {

@@ -111,6 +111,36 @@ class HipEngine:
                               call.data_ptr())
         return slabs, fill, call
 
+    def new_set_xcd(self, n_regions, cap):
+        """Exchange buffers of the 10-bit route: (slabs [8][n_regions][cap], fill [8][n_regions], call, recv, incoming) — x-major,
+        as qm2_route_xcd_device writes them; recv / incoming take [8][world][n_subs] with world * n_subs = n_regions."""
+        t = self.torch
+        return (t.empty(8 * n_regions * cap, dtype=t.int64, device=self.device), t.zeros(8 * n_regions, dtype=t.int32, device=self.device),
+                t.zeros(3, dtype=t.int64, device=self.device), t.empty(8 * n_regions * cap, dtype=t.int64, device=self.device),
+                t.zeros(8 * n_regions, dtype=t.int32, device=self.device))
+
+    def route_xcd(self, rctx, d_lines, n_regions, cap, bufs, after=None):
+        """route() by 10 bits: n_regions = owners x sub-slabs (<= 1024), every region in 8 per-XCD sub-regions of `cap` k-mers"""
+        if after is not None:
+            self.s_route.wait_event(after)
+        slabs, fill, call = bufs[0], bufs[1], bufs[2]
+        fill.zero_()
+        call.zero_()
+        if d_lines is not None and d_lines.numel():
+            rctx.route_xcd_device(d_lines.data_ptr(), d_lines.numel(), slabs.data_ptr(), cap, n_regions, fill.data_ptr(), call.data_ptr())
+        return slabs, fill, call
+
+    def probe_subslabs_after(self, ctx, works, slabs, cap, n_peers, n_subs, fill, peer_stride=0):
+        """probe_after() for sub-slabs that are the first level of the shard's own partition (qm2_probe_subslabs_device)"""
+        with self.torch.cuda.stream(self.s_probe):
+            for w in works:
+                if w is not None:
+                    w.wait()
+            ctx.probe_subslabs_device(slabs.data_ptr(), cap, n_peers, n_subs, fill.data_ptr(), kmers_bound=0, peer_stride=peer_stride)
+            ev = self.torch.cuda.Event()
+            ev.record(self.s_probe)
+        return ev
+
     class _After:
         """what a work handle is to a collective: the prober stream waits for the router stream's work so far"""
         def __init__(self, torch, stream):
@@ -197,7 +227,7 @@ class ShardedJob:
     and routed again, by every rank alike — exact for any input, never an error and never a hang.
     Every rank must call count / count_local the same number of times (an empty call is fine)."""
 
-    def __init__(self, dist, engine, keys, k, torch, batch_bytes=None, resident=None, flags=0):
+    def __init__(self, dist, engine, keys, k, torch, batch_bytes=None, resident=None, flags=0, route=None):
         """keys: the host key table; or None with resident = (H, (own_lo, own_hi, lo, hi), device pointer to the
         span's keys) when the table is already on the device (bench.py)."""
         self.dist, self.engine, self.torch = dist, engine, torch
@@ -222,8 +252,27 @@ class ShardedJob:
         self.batch_bytes = int(batch_bytes) if batch_bytes else 1 << 26
         # a slab takes a rank's share of one batch with 30 % head-room (uniform hashing spreads the k-mers evenly)
         self.cap = (int(self.batch_bytes / self.world * 1.3) + 64) & ~1
+        # The exchange layout (route = "xcd" | "flat"; None: QM2_SHARDS_ROUTE, else xcd where the library can run it — tables
+        # of 2^23 slots and more).  flat: one slab per owner, split twice by the receiver.  xcd: the senders' 10-bit route
+        # (qm2_route_xcd_device) — owners x 1024 / owners sub-slabs, each in 8 per-XCD sub-regions of a fixed capacity,
+        # x-major — exchanged with one all-to-all per XCD slice (a slice is owner-major: equal splits), and what a shard
+        # receives IS the first level of its own partition (qm2_probe_subslabs_device: one split).  Both exact; which one
+        # the wire prefers (whole blocks with ~13 % of room in them, or less data split once more) is for the first run on
+        # more than one GPU to say.
+        import os as _os
+        if route is None:
+            route = _os.environ.get("QM2_SHARDS_ROUTE")
+        can = self.H >= (1 << 23) and self.world <= 512 and k <= 30 and hasattr(engine, "route_xcd")
+        assert route in (None, "xcd", "flat"), route
+        self.xcd = (route == "xcd") or (route is None and can)
+        self.n_subs = 1024 // self.world if self.xcd else 1
+        if self.xcd:
+            mean = self.batch_bytes / (8.0 * 1024.0)
+            self.sub_cap = (int(mean * 1.12 + 8.0 * (mean + 1.0) ** 0.5) + 256) & ~1
         self.n_bases = self.n_kmers = 0
-        self.rounds = self.retries = 0
+        self.rounds = self.retries = self.flat_fallbacks = 0
+        self._xsets = None                    # the 10-bit route's two sets of exchange buffers
+        self._xbusy = [None, None]
         self._keep = []
         self._sets = None                     # two sets of exchange buffers, used in turn
         self._busy = [None, None]             # per set: the probe that reads it has finished (engine event)
@@ -260,13 +309,66 @@ class ShardedJob:
         out.append(rest)
         return out
 
-    def _round(self, d_lines, depth=0):
+    def _round_xcd(self, d_lines, depth=0):
+        """One round by the 10-bit route.  A piece that overflows its small sub-regions is cut like a flat one; once every
+        rank's piece is small enough for one slab per owner to hold it whatever it is made of (a flood of one k-mer),
+        it goes round the flat way."""
+        t, dist, W, eng = self.torch, self.dist, self.world, self.engine
+        have = d_lines is not None and d_lines.numel() > 0
+        self.rounds += 1
+        nr, cap, ns = W * self.n_subs, self.sub_cap, self.n_subs
+        if self._xsets is None:
+            self._xsets = [eng.new_set_xcd(nr, cap), eng.new_set_xcd(nr, cap)]
+            if self._acc is None:
+                self._acc = self._xsets[0][2].clone()
+        which = self._turn
+        bufs = self._xsets[which]
+        with eng.on_router():
+            slabs, fill, call = eng.route_xcd(self.rctx, d_lines if have else None, nr, cap, bufs, after=self._xbusy[which])
+            self._xbusy[which] = None
+            flag = t.stack([call[2], t.tensor(d_lines.numel() if have else 0, dtype=call.dtype, device=call.device)])
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            fits, largest = int(flag[0].item()) == 0, int(flag[1].item())
+            works = []
+            if fits:
+                if W == 1:
+                    recv, incoming, works = slabs, fill, [eng.routed()]
+                else:
+                    recv, incoming = bufs[3], bufs[4]
+                    blk = nr * cap                       # one XCD slice: [owner][sub][cap], owner-major
+                    for x in range(8):
+                        works.append(dist.all_to_all_single(incoming[x * nr:(x + 1) * nr], fill[x * nr:(x + 1) * nr], async_op=True))
+                        works.append(dist.all_to_all_single(recv[x * blk:(x + 1) * blk], slabs[x * blk:(x + 1) * blk], async_op=True))
+                self._acc += call
+        if not fits:
+            assert depth < 48, "a batch keeps overflowing its sub-slabs"
+            self.retries += 1
+            if largest <= self.cap:                   # (the same number on every rank) one slab per owner holds any such piece
+                self.flat_fallbacks += 1
+                self._round(d_lines, depth + 1, flat=True)
+                return
+            halves = eng.split_lines(d_lines) if have else (None, None)
+            self._round_xcd(halves[0], depth + 1)
+            self._round_xcd(halves[1], depth + 1)
+            return
+        # received: slice x holds [sender][sub][cap] — 8 W "peers" of n_subs sub-slabs side by side (W = 1: what was routed,
+        # 8 peers 1024 regions apart)
+        self._xbusy[which] = eng.probe_subslabs_after(self.ctx, works, recv, cap, 8 * W if W > 1 else 8, ns if W > 1 else nr, incoming,
+                                                      peer_stride=0 if W > 1 else nr)
+        self._keep = (self._keep + [d_lines])[-2:]
+        self._turn ^= 1
+
+    def _round(self, d_lines, depth=0, flat=False):
+        if self.xcd and not flat:
+            return self._round_xcd(d_lines, depth)
         t, dist, W, eng = self.torch, self.dist, self.world, self.engine
         have = d_lines is not None and d_lines.numel() > 0
         self.rounds += 1
         if self._sets is None:
             self._sets = [eng.new_set(W, self.cap), eng.new_set(W, self.cap)]
-            self._acc = self._sets[0][2].clone()
+            if self._acc is None:
+                self._acc = self._sets[0][2].clone()
+                self._acc.zero_()
         which = self._turn
         bufs = self._sets[which]
         with eng.on_router():
@@ -289,8 +391,8 @@ class ShardedJob:
             assert depth < 48, "a batch keeps overflowing its slabs"
             self.retries += 1
             halves = eng.split_lines(d_lines) if have else (None, None)
-            self._round(halves[0], depth + 1)
-            self._round(halves[1], depth + 1)
+            self._round(halves[0], depth + 1, flat)
+            self._round(halves[1], depth + 1, flat)
             return
         self._busy[which] = eng.probe_after(self.ctx, (w1, w2), recv, self.cap, W, incoming)
         self._keep = (self._keep + [d_lines])[-2:]      # (the text of the rounds still being routed)

@@ -65,7 +65,7 @@ class Dup(C.Structure):
 
 
 # every symbol include/qm2.h and include/qm2_tools.h declare
-ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_route_device_carry", "qm2_probe_slabs_device", "qm2_probe_subslabs_device", "qm2_route_xcd_device", "qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
+ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_route_device_carry", "qm2_probe_slabs_device", "qm2_probe_subslabs_device", "qm2_route_xcd_device", "qm2_route_xcd_device_carry", "qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
                "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_chain_gc_sums_fd", "qm2_submit_raw_device", "qm2_staging_commit_raw", "qm2_raw_verdict",
                "qm2_packed_bound", "qm2_pack_lines", "qm2_pack_reads", "qm2_pack_isa", "qm2_pack_isa_select", "qm2_staging_commit_packed", "qm2_submit_packed_device", "qm2_submit_threads",
@@ -142,6 +142,8 @@ def lib():
     L.qm2_probe_subslabs_device.argtypes = [vp, vp, u64, u32, u32, u32, vp, u64]
     L.qm2_route_xcd_device.restype = C.c_int
     L.qm2_route_xcd_device.argtypes = [vp, vp, C.c_size_t, vp, u64, vp, u64, u32, vp, vp]
+    L.qm2_route_xcd_device_carry.restype = C.c_int
+    L.qm2_route_xcd_device_carry.argtypes = [vp, vp, C.c_size_t, u32, vp, u64, vp, u64, u32, vp, vp]
     L.qm2_chain_gather.restype = C.c_int
     L.qm2_chain_gather.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.qm2_submit_raw_device.restype = C.c_int

@@ -303,6 +303,55 @@ def test_cli_shards_config4_from_the_c_host(tmp_path):
     assert r.returncode != 0 and b"listed twice" in r.stdout
 
 
+def test_cli_shards_ten_bit_route_and_flat(tmp_path):
+    """Config 4's two exchange layouts from the C host (QM2_SHARDS_ROUTE): the senders' 10-bit route — G owners x 1024 / G
+    sub-slabs in 8 per-XCD sub-regions, whole blocks over the wire, ONE split behind it (qm2_route_xcd_device ->
+    qm2_probe_subslabs_device) — is the default from 2^23 slots on; `flat` is rounds 1-4's one slab per owner.  A dictionary
+    of the mini reference in 2^23 slots (qm2-mkdict, the reference's `search -e 0` re-stated), 1 / 2 / 4 logical ranks on
+    the one GPU (device-to-device copies in RCCL's place), small rounds; then a poly-A flood, which overflows the small
+    sub-regions however the round is cut and goes round with one slab per owner: .bin = the oracle's counts every time."""
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    r = subprocess.run([os.path.join(ROOT, "quick-mer2_amd", "qm2-mkdict"), "-k", "30", "-s", "8M", "-e", "0", "-w", "1000", "-c", ctrl, fa],
+                       stdout=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stdout
+    qm = ol.load_qm(fa + ".qm")
+    assert qm["H"] == 1 << 23
+    order = ol.chain_order(qm)
+    lines = ol.strip_reads(rfq)
+    exp_depth, exp_st = ol.count_lines(qm["keys"], 30, lines)
+    exp_bin = exp_depth[order].astype("<u2").tobytes()
+    fake = dict(os.environ, QM2_SHARDS_FAKE_EXCHANGE="1", QM2_SHARDS_BATCH_BYTES="200000", QM2_TIMING="1")
+    for devs in ("0", "0,0", "0,0,0,0"):
+        for mode in ("xcd", "flat", None):
+            env = dict(fake) if mode is None else dict(fake, QM2_SHARDS_ROUTE=mode)
+            out = str(tmp_path / ("r_%d_%s" % (len(devs), mode)))
+            r = subprocess.run([CLI, "count", "-t", "3", "--shards", devs, fa, rfq, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env)
+            text = r.stdout.decode(errors="replace")
+            assert r.returncode == 0, text
+            assert ("total %d kmers" % exp_st["n_kmers"]) in text
+            assert open(out + ".bin", "rb").read() == exp_bin, (devs, mode)
+            assert ("10-bit route" in text) == (mode != "flat"), text
+            assert int(text.split(" rounds,")[0].split()[-1]) >= 2, text
+    # the flood: 30000 poly-A reads in front (4.5 M copies of k-mer 0 for ONE sub-region of a few thousand places)
+    flood = (b"A" * 150 + b"\n") * 30000 + lines
+    p = tmp_path / "flood.fa"
+    p.write_bytes(b">r\n" + flood.replace(b"\n", b"\n>r\n")[:-3])
+    e2, s2 = ol.count_lines(qm["keys"], 30, flood)
+    for devs in ("0", "0,0,0,0"):
+        out = str(tmp_path / ("flood_%d" % len(devs)))
+        r = subprocess.run([CLI, "count", "-t", "2", "--shards", devs, fa, str(p), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900,
+                           env=dict(fake, QM2_SHARDS_ROUTE="xcd"))
+        text = r.stdout.decode(errors="replace")
+        assert r.returncode == 0, text
+        assert ("total %d kmers" % s2["n_kmers"]) in text
+        assert open(out + ".bin", "rb").read() == e2[order].astype("<u2").tobytes(), devs
+        assert int(text.split(" pieces fell back")[0].split()[-1]) >= 1, text
+    # asked for on a table that is too small for it: said so
+    r = subprocess.run([CLI, "count", "--shards", "0", os.path.join(GOLD, "mini", "ref.fa"), rfq, str(tmp_path / "small")], stdout=subprocess.PIPE, timeout=120,
+                       env=dict(os.environ, QM2_SHARDS_ROUTE="xcd"))
+    assert r.returncode != 0 and b"2^23" in r.stdout
+
+
 @pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="needs two GPUs: RCCL between two ranks")
 def test_cli_shards_on_two_physical_gpus(tmp_path):
     """Config 4 over the wire: `--shards 0,1` (ncclSend / ncclRecv between two GPUs) against the reference's vectors."""

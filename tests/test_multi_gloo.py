@@ -20,6 +20,16 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 
 
+def djb_np(kmers):
+    """DJBHash_encode (QuicKmer.c:66-76) of a uint64 array, vectorised (checked against the oracle's in OracleEngine.route)"""
+    x = np.asarray(kmers, dtype=np.uint64)
+    h = np.full(x.shape, 5381, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for i in range(8):
+            h = h * np.uint64(33) + ((x >> np.uint64(8 * i)) & np.uint64(0xFF))
+    return h
+
+
 class OracleEngine:
     """CPU stand-in for HipEngine: same method contract, oracle arithmetic."""
 
@@ -94,8 +104,9 @@ class OracleEngine:
         L = self.ol.lib()
         lgH = int(np.log2(c.H))
         shift = lgH - int(np.log2(n_owners))
-        owner = np.array([(L.qm2o_djb(int(x)) & (c.H - 1)) >> shift for x in kmers], dtype=np.int64) \
-            if n_owners > 1 else np.zeros(len(kmers), dtype=np.int64)
+        owner = ((djb_np(kmers) & np.uint64(c.H - 1)) >> np.uint64(shift)).astype(np.int64) if n_owners > 1 else np.zeros(len(kmers), dtype=np.int64)
+        for x in kmers[:50]:
+            assert L.qm2o_djb(int(x)) == int(djb_np(np.array([x]))[0])
         lost = 0
         for g in range(n_owners):
             sel = kmers[owner == g].view(np.int64)
@@ -105,6 +116,50 @@ class OracleEngine:
             slabs[g * cap:g * cap + keep] = torch.from_numpy(sel[:keep].copy())
         call[0], call[1], call[2] = nb, len(kmers), lost
         return slabs, fill, call
+
+    def new_set_xcd(self, n_regions, cap):
+        return (torch.zeros(8 * n_regions * cap, dtype=torch.int64), torch.zeros(8 * n_regions, dtype=torch.int32),
+                torch.zeros(3, dtype=torch.int64), torch.zeros(8 * n_regions * cap, dtype=torch.int64),
+                torch.zeros(8 * n_regions, dtype=torch.int32))
+
+    def route_xcd(self, c, d_lines, n_regions, cap, bufs, after=None):
+        """the contract of qm2_route_xcd_device: region = the top bits of the home slot, every region in 8 sub-regions
+        (which of the 8 a k-mer lands in is the device's business: any is right), x-major, fill = what was ROUTED"""
+        slabs, fill, call = bufs[0], bufs[1], bufs[2]
+        fill.zero_()
+        call.zero_()
+        if d_lines is None or d_lines.numel() == 0:
+            return slabs, fill, call
+        kmers, nb = self.ol.extract(d_lines.numpy().tobytes(), c.k)
+        L = self.ol.lib()
+        shift = int(np.log2(c.H)) - int(np.log2(n_regions))
+        region = ((djb_np(kmers) & np.uint64(c.H - 1)) >> np.uint64(shift)).astype(np.int64)
+        xs = (np.arange(len(kmers)) * 5 + 3) % 8
+        at_all = xs * n_regions + region
+        order = np.argsort(at_all, kind="stable")
+        ats, starts, counts = np.unique(at_all[order], return_index=True, return_counts=True)
+        km = kmers[order].view(np.int64)
+        lost = 0
+        for at, st, n in zip(ats.tolist(), starts.tolist(), counts.tolist()):
+            fill[at] = n
+            keep = min(n, cap)
+            lost += n - keep
+            slabs[at * cap:at * cap + keep] = torch.from_numpy(km[st:st + keep].copy())
+        call[0], call[1], call[2] = nb, len(kmers), lost
+        return slabs, fill, call
+
+    def probe_subslabs_after(self, c, works, slabs, cap, n_peers, n_subs, fill, peer_stride=0):
+        for w in works:
+            if w is not None:
+                w.wait()
+        stride = peer_stride or n_subs
+        for p in range(n_peers):
+            for q in range(n_subs):
+                at = p * stride + q
+                n = min(int(fill[at]), cap)
+                if n:
+                    self._probe_np(c, slabs[at * cap:at * cap + n].numpy().view(np.uint64))
+        return None
 
     def probe_after(self, c, works, slabs, cap, n_slabs, fill):
         for w in works:
@@ -136,7 +191,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, qm_path, lines, out_dir, batch_bytes=None):
+def _worker(rank, world, port, mode, qm_path, lines, out_dir, batch_bytes=None, route="flat"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -149,20 +204,21 @@ def _worker(rank, world, port, mode, qm_path, lines, out_dir, batch_bytes=None):
     if mode == "replica":
         job = multi.ReplicaJob(dist, eng, qm["keys"], qm["k"])
     else:
-        job = multi.ShardedJob(dist, eng, qm["keys"], qm["k"], torch, batch_bytes=batch_bytes)
+        job = multi.ShardedJob(dist, eng, qm["keys"], qm["k"], torch, batch_bytes=batch_bytes, route=route)
+        assert job.xcd == (route == "xcd")
     half = lines.rfind(b"\n", 0, len(lines) // 2) + 1
     job.count(lines[:half])              # two "batches"
     job.count(lines[half:])
     depth = job.finish()
     np.save(os.path.join(out_dir, "depth_%s_%d.npy" % (mode, rank)), depth)
     if mode == "sharded":
-        np.save(os.path.join(out_dir, "info_%d.npy" % rank), np.array([job.rounds, job.retries, job.n_bases, job.n_kmers]))
+        np.save(os.path.join(out_dir, "info_%d.npy" % rank), np.array([job.rounds, job.retries, job.n_bases, job.n_kmers, job.flat_fallbacks]))
     job.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,world", [("replica", 2), ("sharded", 2), ("sharded", 4)])
-def test_multi_rank_counts_equal_single_process(mode, world, tmp_path):
+@pytest.mark.parametrize("mode,world,route", [("replica", 2, "flat"), ("sharded", 2, "flat"), ("sharded", 4, "flat"), ("sharded", 4, "xcd")])
+def test_multi_rank_counts_equal_single_process(mode, world, route, tmp_path):
     import oracle_lib as ol
     import synth
     qm_path = os.path.join(HERE, "golden", "kat", "ref.fa.qm")
@@ -172,14 +228,16 @@ def test_multi_rank_counts_equal_single_process(mode, world, tmp_path):
     p.write_bytes(cases["reads_fa"][1][:120_000] + b"\n" + cases["polyA"][1])
     lines = ol.strip_reads(str(p))
     exp, _ = ol.count_lines(qm["keys"], qm["k"], lines)
-    mp.spawn(_worker, args=(world, _free_port(), mode, qm_path, lines, str(tmp_path)), nprocs=world, join=True)
+    # (xcd: the 10-bit route — one all-to-all per XCD slice, what arrives is the receivers' first partition level;
+    #  small batches so that the poly-A lines overflow a sub-region and go round the flat way)
+    mp.spawn(_worker, args=(world, _free_port(), mode, qm_path, lines, str(tmp_path), 20000 if route == "xcd" else 400000, route), nprocs=world, join=True)
     for r in range(world):
         got = np.load(str(tmp_path / ("depth_%s_%d.npy" % (mode, r))))
         assert np.array_equal(got, exp), (mode, world, r)
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_skewed_input_is_cut_and_rerouted_not_hung(world, tmp_path):
+@pytest.mark.parametrize("world,route", [(2, "flat"), (4, "flat"), (2, "xcd")])
+def test_sharded_skewed_input_is_cut_and_rerouted_not_hung(world, route, tmp_path):
     """Poly-A (every k-mer goes to ONE owner) with slabs sized for an even spread: the ranks decide
     together that the batch does not fit, cut it and route it again — exact counts, no error, no hang
     (round 1 raised on one rank only and left the others in the collective).  Small batches also
@@ -194,8 +252,8 @@ def test_sharded_skewed_input_is_cut_and_rerouted_not_hung(world, tmp_path):
     p.write_bytes(poly + cases["reads_fa"][1][:40_000] + b"\n" + poly)
     lines = ol.strip_reads(str(p))
     exp, exp_st = ol.count_lines(qm["keys"], qm["k"], lines)
-    mp.spawn(_worker, args=(world, _free_port(), "sharded", qm_path, lines, str(tmp_path), 6000), nprocs=world, join=True)
-    retries = 0
+    mp.spawn(_worker, args=(world, _free_port(), "sharded", qm_path, lines, str(tmp_path), 6000, route), nprocs=world, join=True)
+    retries = fallbacks = 0
     bases = kmers = 0
     for r in range(world):
         got = np.load(str(tmp_path / ("depth_sharded_%d.npy" % r)))
@@ -204,7 +262,9 @@ def test_sharded_skewed_input_is_cut_and_rerouted_not_hung(world, tmp_path):
         retries += int(info[1])
         bases += int(info[2])
         kmers += int(info[3])
+        fallbacks += int(info[4])
     assert retries > 0                                  # the skew did overflow the slabs
+    assert fallbacks == 0 or route == "xcd"             # (the 10-bit route's small sub-regions may send a flood round the flat way)
     assert bases == exp_st["n_bases"] and kmers == exp_st["n_kmers"]   # nothing counted twice, nothing lost
 
 
