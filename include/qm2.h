@@ -163,6 +163,9 @@ typedef struct {
                                   spill list by the direct path (skewed input; 0 on uniform reads)            */
     uint64_t staged_bytes;     /* bytes the host pipeline has copied to the device (qm2_submit*, qm2_staging_commit*): what
                                   crossed the link — packed pieces count their blocks (ABI 6)                  */
+    uint64_t refused_batches;  /* batches that were large enough for the partitioned pipeline but took the direct kernel because its
+                                  buffers (partition scratch, interior counters, table image) did not fit in device memory;
+                                  qm2_last_error() holds the allocation's message                               */
     uint64_t replans;          /* times the partition plan was torn down and rebuilt because the caller alternated between
                                   qm2_probe_subslabs_device and the other entry points (each costs a stream sync + the
                                   re-allocation of the partition buffers)                                      */
@@ -251,6 +254,13 @@ int qm2_prepare(qm2_ctx *c, uint64_t batch_bytes, uint32_t what);
 /* Zero counters and statistics (a fresh calloc, :360). */
 int qm2_reset(qm2_ctx *c);
 
+/* The caller has rewritten the key table behind qm2_opts.ext_keys (or is about to count against other keys in the same
+ * device array): everything the context derived from the keys — the look at the runs of occupied slots, the table image
+ * bucket_count streams — is made again in front of the next batch.  Counters and statistics are not touched.  Without this
+ * call a context goes on matching against the image of the OLD keys (the image is made once per context: include/qm2.h,
+ * qm2_opts.ext_keys).  Waits for the work submitted so far.  ABI 6. */
+int qm2_keys_changed(qm2_ctx *c);
+
 void qm2_close(qm2_ctx *c);
 
 /* Device pointers, for callers that reduce counters across GPUs with RCCL or
@@ -312,6 +322,10 @@ int qm2_route_device_carry(qm2_ctx *c, const void *d_seq_bytes, size_t n, uint32
  * text -> 10-bit route -> exchange -> ONE split -> count, as many passes as an unsharded table takes.
  * kmers_bound: an upper estimate of the k-mers in the call (sizes the partition buffers; 0 = every sub-slab full).
  * Needs a context with an own range at least two levels deep behind the sub-slabs; otherwise an error message. */
+/* (A context may mix this entry point with the others, but its partition plan comes in two kinds — level 0 of its own
+ *  making, or given by the sub-slabs — and every change of kind tears the plan down and rebuilds it: a stream
+ *  synchronisation and the re-allocation of the partition buffers, tens of GB at hg38 scale; qm2_profile.replans counts
+ *  them.  A caller that alternates per batch pays that per batch: keep one context per kind.) */
 int qm2_probe_subslabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint64_t sub_cap, uint32_t n_peers,
                               uint32_t n_subs, uint32_t peer_stride, const uint32_t *d_fill, uint64_t kmers_bound);
 

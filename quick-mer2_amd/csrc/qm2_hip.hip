@@ -694,7 +694,7 @@ static int launch_batch(qm2_ctx *c, const uint8_t *data, size_t n, size_t carry,
         if (!ok) part = false;
     }
     const uint64_t bound = seq_bound && seq_bound < n ? seq_bound : (uint64_t)n;
-    if (part && part_reserve(c, bound)) part = false;                /* no memory: direct */
+    if (part && part_reserve(c, bound)) { part = false; c->prof.refused_batches++; }   /* no memory: direct (qm2_profile says so) */
     if (part && table_image(c)) return 1;
     if (part) {
         c->prof.partitioned_batches++;
@@ -1635,6 +1635,17 @@ extern "C" int qm2_reset(qm2_ctx *c)
     HIP_OK(hipStreamSynchronize(c->stream));
     memset(&c->prof, 0, sizeof c->prof);
     c->n_allocations = 0;
+    return 0;
+}
+
+extern "C" int qm2_keys_changed(qm2_ctx *c)
+{
+    if (!c) return fail("qm2_keys_changed: null context");
+    if (qm2_sync(c)) return 1;
+    std::lock_guard<std::mutex> guard(c->runs_mu);
+    c->img_ready = false;                                     /* the table image is made again (table_image) */
+    c->part.runs = 0;                                         /* ... and so is the look at the runs of occupied slots (runs_fit) */
+    if (c->part.shared) { (void)hipFree(c->part.shared); c->part.shared = nullptr; }
     return 0;
 }
 

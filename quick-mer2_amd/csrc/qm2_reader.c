@@ -610,9 +610,10 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
  * mapping the file costs more in page-table work than it saves.  Hence this arrangement:
  *   - blocks of 4 MiB (QM2_BLOCK_BYTES overrides), block b OWNS the lines that start inside it (pf_load, as above);
  *   - the workers take blocks from a shared counter themselves; nothing is handed over per block;
- *   - FASTQ: a worker counts its block's lines while the block is hot, publishes the count, and waits for the count of
- *     the blocks before it (they are being read at the same moment by the other workers) — the line state at its first
- *     line follows from that (pf_state);
+ *   - FASTQ: the line state at a block's first line follows from the line count (mod 4) of the blocks before it
+ *     (pf_state), which are being read at the same moment by the other workers.  A worker does not wait for it: it packs
+ *     under a guess of the state read off its block's first lines — the same single pass tells how many lines the block
+ *     holds, mod 4, which is what it passes on — and packs again in the rare case the guess was wrong;
  *   - it packs what the line discipline keeps (qm2_pack_reads) BEHIND the pieces already in its own staging buffer:
  *     a piece is whole 64-position blocks, so pieces simply follow each other; only full buffers travel to the calling
  *     thread, which commits them (qm2_lines_out.commit_packed) as they come — counting does not care about the order;
@@ -640,7 +641,7 @@ typedef struct {
     int              workers_active, failed, desync, closing;
 } pk_shared;
 
-typedef struct { pk_shared *ps; pf_worker w; double t_read, t_count, t_wait, t_pack; } pk_worker;
+typedef struct { pk_shared *ps; pf_worker w; double t_read, t_count, t_wait, t_pack; unsigned long repacked; } pk_worker;
 
 static pk_buf *pk_get_free(pk_shared *ps)
 {
@@ -663,6 +664,64 @@ static void pk_put_full(pk_shared *ps, pk_buf *b)
     pthread_mutex_unlock(&ps->mu);
 }
 
+/* Which FASTQ line state does a block most likely start in?  Looks at its first lines: with `s` lines to drop before the
+ * first sequence line, line i plays role (i - s) mod 4 — 0 sequence, 1 the '+' line, 2 qualities (as long as their
+ * sequence), 3 the '@' header.  Only a guess (a quality line may start with '@' or '+'): pk_main packs with it and checks
+ * it against the line count of the blocks before, which is what decides (:451-455). */
+static int guess_fastq_skip(const char *p, size_t n)
+{
+    size_t start[12], len[12];
+    int nl = 0;
+    for (size_t at = 0; at < n && nl < 12; nl++) {
+        const char *e = memchr(p + at, '\n', n - at);
+        start[nl] = at;
+        len[nl] = e ? (size_t)(e - (p + at)) : n - at;
+        if (!e) { nl++; break; }
+        at += len[nl] + 1;
+    }
+    for (int s = 0; s < 4; s++) {
+        int ok = 1;
+        for (int i = 0; i < nl && ok; i++) {
+            const int role = ((i - s) % 4 + 4) % 4;
+            const char c = len[i] ? p[start[i]] : 0;
+            if (role == 1 && c != '+') ok = 0;
+            if (role == 3 && c != '@') ok = 0;
+            if (role == 2 && i >= 2 && i + 1 < nl && len[i] != len[i - 2]) ok = 0;      /* (the block's last line listed may be cut short) */
+        }
+        if (ok) return s;
+    }
+    return 0;
+}
+
+/* one block's kept lines behind the pieces already in `cur` (or, what does not pack, as ASCII lines in *ascii_out); the
+ * line state *st is updated; 0, or 1 on an error */
+static int pk_pack_block(pk_shared *ps, pf_worker *w, pk_buf *cur, line_state *st, qm2_packed *piece, pk_buf **ascii_out)
+{
+    const size_t n = w->hi - w->lo, used = (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES;
+    const line_state st0 = *st;
+    *ascii_out = NULL;
+    memset(piece, 0, sizeof *piece);
+    const int prc = qm2_packed_bound(n) <= cur->cap - used
+                        ? pack_whole_lines_cap(w->raw + w->lo, n, st, cur->buf + used, cur->cap - used, piece, cur->wraps + cur->p.n_wraps,
+                                               QM2_WRAPS_CAP - (size_t)cur->p.n_wraps)
+                        : 2;
+    if (prc == 1) return 1;
+    if (prc == 2) {                                  /* does not pack (or is larger than a whole buffer): as ASCII lines */
+        pk_buf *a = calloc(1, sizeof *a);
+        char *lines_buf = malloc(n + 2);
+        if (!a || !lines_buf) { free(a); free(lines_buf); return 1; }
+        static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL, NULL, NULL};
+        out_state os = {&none, lines_buf, n + 2, 0};
+        *st = st0;
+        if (strip_range(w->raw + w->lo, n, st, &os)) { free(a); free(lines_buf); return 1; }
+        a->ascii = lines_buf; a->ascii_len = os.len;
+        *ascii_out = a;
+        memset(piece, 0, sizeof *piece);
+    }
+    (void)ps;
+    return 0;
+}
+
 static void *pk_main(void *arg)
 {
     pk_worker *kw = arg;
@@ -679,45 +738,49 @@ static void *pk_main(void *arg)
         int rc = atomic_load(&sh->stop) ? 0 : pf_load(w);
         if (rc || atomic_load(&sh->stop)) w->lo = w->hi = 0;
         const double t1 = pf_now();
-        size_t lines = sh->fastq ? count_newlines(w->raw + w->lo, w->hi - w->lo) : 0;
-        if (sh->fastq && w->hi > w->lo && w->raw[w->hi - 1] != '\n') lines++;       /* last line of the file, no newline */
+        const size_t n = w->hi - w->lo;
+        /* FASTQ: ONE pass over the block while it is hot — packed under a GUESS of its line state, which also tells how many
+         * lines it holds mod 4 (every line start is one step of :451-455: lines = skip_in - skip_out mod 4) — and only then
+         * the wait for the blocks before, whose line count decides.  A wrong guess (a handful of blocks per file at most:
+         * quality lines that look like headers) packs again.  FASTA keeps no state. */
+        line_state st = pf_state(sh, 0);
+        qm2_packed piece;
+        pk_buf *ascii = NULL;
+        int guess = 0, packed_once = 0;
+        memset(&piece, 0, sizeof piece);
+        if (!rc && n) {
+            if (cur && (cur->cap - (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES < qm2_packed_bound(n) || cur->p.n_wraps + 8 > QM2_WRAPS_CAP)) { pk_put_full(ps, cur); cur = NULL; }
+            if (!cur) { cur = pk_get_free(ps); if (!cur) break; }
+            guess = sh->fastq ? guess_fastq_skip(w->raw + w->lo, n) : 0;
+            st.skip = guess;
+            if (pk_pack_block(ps, w, cur, &st, &piece, &ascii)) { failed = 1; rc = 1; }
+            packed_once = 1;
+        }
         const double t2 = pf_now();
         while (!atomic_load_explicit(&sh->known[b], memory_order_acquire) && !atomic_load(&sh->stop)) sched_yield();
-        const size_t before = sh->lines_before[b];
-        sh->lines_before[b + 1] = before + lines;
-        atomic_store_explicit(&sh->known[b + 1], 1, memory_order_release);
+        const size_t before = sh->lines_before[b];                  /* (mod 4 from here on: all the state there is) */
         const double t3 = pf_now();
-        kw->t_read += t1 - t0; kw->t_count += t2 - t1; kw->t_wait += t3 - t2;
-        if (rc) { failed = 1; break; }
-        if (atomic_load(&sh->stop)) break;
-        if (w->hi == w->lo) continue;
-        const size_t n = w->hi - w->lo, need = qm2_packed_bound(n);
-        if (cur && (cur->cap - (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES < need || cur->p.n_wraps + 8 > QM2_WRAPS_CAP)) { pk_put_full(ps, cur); cur = NULL; }
-        if (!cur) { cur = pk_get_free(ps); if (!cur) break; }
-        line_state st = pf_state(sh, before);
-        qm2_packed piece;
-        uint64_t *wr = cur->wraps + cur->p.n_wraps;
-        int prc = need <= cur->cap - (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES
-                      ? pack_whole_lines_cap(w->raw + w->lo, n, &st, cur->buf + (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES,
-                                             cur->cap - (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES, &piece, wr, QM2_WRAPS_CAP - (size_t)cur->p.n_wraps)
-                      : 2;
-        if (prc == 1) { failed = 1; break; }
-        if (prc == 2) {                                  /* does not pack (or is larger than a whole buffer): as ASCII lines */
-            pk_buf *a = calloc(1, sizeof *a);
-            char *lines_buf = malloc(n + 2);
-            if (!a || !lines_buf) { free(a); free(lines_buf); failed = 1; break; }
-            static const qm2_lines_out none = {buf_acquire, buf_commit, buf_submit, NULL, NULL, NULL};
-            out_state os = {&none, lines_buf, n + 2, 0};
+        const int correct = sh->fastq ? (int)((4 - (before & 3)) & 3) : 0;
+        if (packed_once && !rc && sh->fastq && correct != guess && !atomic_load(&sh->stop)) {
+            if (ascii) { free(ascii->ascii); free(ascii); ascii = NULL; }
             st = pf_state(sh, before);
-            if (strip_range(w->raw + w->lo, n, &st, &os)) { free(a); free(lines_buf); failed = 1; break; }
-            a->ascii = lines_buf; a->ascii_len = os.len;
-            pk_put_full(ps, a);
-        } else {
+            if (pk_pack_block(ps, w, cur, &st, &piece, &ascii)) { failed = 1; rc = 1; }
+            kw->repacked++;
+        }
+        const size_t lines4 = sh->fastq && packed_once ? (size_t)((correct - st.skip) & 3) : 0;
+        sh->lines_before[b + 1] = (before + lines4) & 3;
+        atomic_store_explicit(&sh->known[b + 1], 1, memory_order_release);
+        kw->t_read += t1 - t0; kw->t_pack += (t2 - t1) + (pf_now() - t3); kw->t_wait += t3 - t2;
+        if (rc) { failed = 1; if (ascii) { free(ascii->ascii); free(ascii); } break; }
+        if (atomic_load(&sh->stop)) { if (ascii) { free(ascii->ascii); free(ascii); } break; }
+        if (!n) continue;
+        if (ascii) pk_put_full(ps, ascii);
+        else {
             const uint64_t pos0 = 64 * cur->p.n_blocks;
+            uint64_t *wr = cur->wraps + cur->p.n_wraps;
             for (uint64_t i = 0; i < piece.n_wraps; i++) wr[i] += pos0;
             cur->p.n_blocks += piece.n_blocks; cur->p.n_newlines += piece.n_newlines; cur->p.n_wraps += piece.n_wraps;
         }
-        kw->t_pack += pf_now() - t3;
         if (st.desync) {                                 /* the blocks behind this one were given a state that is not theirs */
             pthread_mutex_lock(&ps->mu); ps->desync = 1; pthread_mutex_unlock(&ps->mu);
             atomic_store(&sh->stop, 1);
@@ -834,11 +897,12 @@ static int stream_blocks_packed(int fd, size_t size, const qm2_lines_out *out, i
     ps.closing = 1;
     pthread_cond_broadcast(&ps.cv_free);
     pthread_mutex_unlock(&ps.mu);
-    double t_read = 0, t_count = 0, t_wait = 0, t_pack = 0;
+    double t_read = 0, t_wait = 0, t_pack = 0;
+    unsigned long repacked = 0;
     for (int t = 0; t < n_workers; t++) {
         pthread_join(tids[t], NULL);
         free(ws[t].w.raw);
-        t_read += ws[t].t_read; t_count += ws[t].t_count; t_wait += ws[t].t_wait; t_pack += ws[t].t_pack;
+        t_read += ws[t].t_read; t_wait += ws[t].t_wait; t_pack += ws[t].t_pack; repacked += ws[t].repacked;
     }
     for (pk_buf *b = ps.full_q; b;) {                        /* (after an error: pieces nobody committed) */
         pk_buf *nx = b->next;
@@ -847,8 +911,9 @@ static int stream_blocks_packed(int fd, size_t size, const qm2_lines_out *out, i
     }
     for (int i = 0; i < n_bufs; i++) if (bufs[i].buf) (void)out->commit(out->user, bufs[i].buf, 0);
     if (getenv("QM2_READER_TIMING"))
-        printf("QM2 reader: %d workers, %zu blocks of %zu bytes, packed; seconds summed over the workers: pread %.3f, newline count %.3f, waiting for the line count of the blocks before %.3f, line discipline + packing %.3f\n",
-               n_workers, sh->n_blocks, sh->block, t_read, t_count, t_wait, t_pack);
+        printf("QM2 reader: %d workers, %zu blocks of %zu bytes, packed; seconds summed over the workers: pread %.3f, line discipline + packing (one pass, under a guessed line state) %.3f, "
+               "waiting for the line count of the blocks before %.3f; %lu blocks packed again (wrong guess)\n",
+               n_workers, sh->n_blocks, sh->block, t_read, t_pack, t_wait, repacked);
     if (!rc && ps.failed) rc = 1;
     if (!rc && ps.desync) rc = 3;
     pthread_mutex_destroy(&ps.mu);

@@ -44,7 +44,7 @@ class Profile(C.Structure):
     _fields_ = [("n_launches", C.c_uint64), ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double),
                 ("class_launches", C.c_uint64 * 8), ("class_ms", C.c_double * 8),
                 ("partitioned_batches", C.c_uint64), ("direct_batches", C.c_uint64), ("fallback_batches", C.c_uint64),
-                ("allocations", C.c_uint64), ("spilled_kmers", C.c_uint64), ("staged_bytes", C.c_uint64), ("replans", C.c_uint64)]
+                ("allocations", C.c_uint64), ("spilled_kmers", C.c_uint64), ("staged_bytes", C.c_uint64), ("refused_batches", C.c_uint64), ("replans", C.c_uint64)]
 
 
 class Packed(C.Structure):
@@ -65,7 +65,7 @@ class Dup(C.Structure):
 
 
 # every symbol include/qm2.h and include/qm2_tools.h declare
-ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_route_device_carry", "qm2_probe_slabs_device", "qm2_probe_subslabs_device", "qm2_route_xcd_device", "qm2_route_xcd_device_carry", "qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset",
+ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_route_device_carry", "qm2_probe_slabs_device", "qm2_probe_subslabs_device", "qm2_route_xcd_device", "qm2_route_xcd_device_carry", "qm2_prepare", "qm2_stats_peek", "qm2_open", "qm2_submit", "qm2_staging_acquire", "qm2_staging_commit", "qm2_submit_device", "qm2_sync", "qm2_finish", "qm2_reset", "qm2_keys_changed",
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
                "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_chain_gc_sums_fd", "qm2_submit_raw_device", "qm2_staging_commit_raw", "qm2_raw_verdict",
                "qm2_packed_bound", "qm2_pack_lines", "qm2_pack_reads", "qm2_pack_isa", "qm2_pack_isa_select", "qm2_staging_commit_packed", "qm2_submit_packed_device", "qm2_submit_threads",
@@ -112,6 +112,8 @@ def lib():
     L.qm2_finish.argtypes = [vp, vp, C.POINTER(Stats)]
     L.qm2_reset.restype = C.c_int
     L.qm2_reset.argtypes = [vp]
+    L.qm2_keys_changed.restype = C.c_int
+    L.qm2_keys_changed.argtypes = [vp]
     L.qm2_prepare.restype = C.c_int
     L.qm2_prepare.argtypes = [vp, u64, u32]
     L.qm2_stats_peek.restype = C.c_int
@@ -418,6 +420,9 @@ class Counter:
     def reset(self):
         _check(lib().qm2_reset(self._h), "qm2_reset")
 
+    def keys_changed(self):
+        _check(lib().qm2_keys_changed(self._h), "qm2_keys_changed")
+
     def prepare(self, batch_bytes=0, host=False, raw=False, fastq=False, no_part=False, packed=False):
         what = (1 if host else 0) | (2 if raw else 0) | (4 if fastq else 0) | (8 if no_part else 0) | (16 if packed else 0)
         _check(lib().qm2_prepare(self._h, int(batch_bytes), what), "qm2_prepare")
@@ -484,7 +489,7 @@ class Counter:
                 "class_ms": {KERNEL_CLASSES[i]: float(p.class_ms[i]) for i in range(7)},
                 "partitioned_batches": int(p.partitioned_batches), "direct_batches": int(p.direct_batches),
                 "fallback_batches": int(p.fallback_batches), "allocations": int(p.allocations),
-                "spilled_kmers": int(p.spilled_kmers), "staged_bytes": int(p.staged_bytes), "replans": int(p.replans)}
+                "spilled_kmers": int(p.spilled_kmers), "staged_bytes": int(p.staged_bytes), "refused_batches": int(p.refused_batches), "replans": int(p.replans)}
 
     @property
     def counters_ptr(self):

@@ -722,6 +722,38 @@ def test_prepare_peek_flush_and_merge(qm2, tmp_path):
             assert np.array_equal(depth, e2)
 
 
+def test_keys_changed_under_a_live_context(qm2, torch_cuda, tmp_path):
+    """A caller's key table (qm2_opts.ext_keys) is digested once per context — the runs of occupied slots, the table image
+    bucket_count streams; a caller that rewrites it says so (qm2_keys_changed, ABI 6) and the next batch counts against the
+    NEW keys on both pipelines.  (Without the call the partitioned pipeline would go on matching the old image: ADVICE r04.)"""
+    torch = torch_cuda
+    qm = ol.load_qm(os.path.join(GOLD, "mini", "ref.fa.qm"))
+    fa, ctrl, rfa, rfq = synth.mini_inputs(str(tmp_path))
+    lines = ol.strip_reads(rfq)
+    keys1 = qm["keys"]
+    keys2 = keys1.copy()
+    occ = np.flatnonzero(keys2)
+    keys2[occ[::3]] = 0                                            # another table in the same array: a third of the keys gone
+    for flags in (qm2.FLAG_PARTITION, qm2.FLAG_DIRECT):
+        d_keys = torch.from_numpy(keys1.view(np.int64).copy()).cuda()
+        d_cnt = torch.zeros(len(keys1), dtype=torch.int32, device="cuda")
+        with qm2.Counter(None, hash_size=len(keys1), k=30, flags=flags, ext_keys=d_keys.data_ptr(), ext_counters=d_cnt.data_ptr()) as c:
+            c.submit(lines)
+            depth, st = c.finish()
+            e1, s1 = ol.count_lines(keys1, 30, lines)
+            assert st == s1 and np.array_equal(depth, e1)
+            d_keys.copy_(torch.from_numpy(keys2.view(np.int64).copy()))
+            torch.cuda.synchronize()
+            c.keys_changed()
+            c.reset()
+            c.submit(lines)
+            depth, st = c.finish()
+            e2, s2 = ol.count_lines(keys2, 30, lines)
+            assert st == s2 and np.array_equal(depth, e2), flags
+            assert s2["n_hits"] < s1["n_hits"]
+            assert c.profile()["refused_batches"] == 0
+
+
 def test_empty_and_degenerate_inputs(qm2):
     qm = kat_qm()
     with qm2.Counter(qm["keys"], k=30) as c:
