@@ -842,7 +842,7 @@ def main():
     del counters
     torch.cuda.empty_cache()
 
-    # ---- the instruction side (what the byte fraction above is bound BY: the three kernels' time x CUs is constant):
+    # ---- the instruction side (what the byte fraction above is bound BY: the three kernels' time x CUs is constant, EXPERIMENTS.md 4.1.3):
     #      VALU wave-instructions per launch (SQ_INSTS_VALU, a PMC pass of tools/profile.sh on these very kernel sources)
     #      against what the chip can issue in the launch's measured time ---------------------------------------------
     if any(valu_k.get(c) for c in per_kernel):

@@ -329,7 +329,7 @@ int qm2_route_device_carry(qm2_ctx *c, const void *d_seq_bytes, size_t n, uint32
 int qm2_probe_subslabs_device(qm2_ctx *c, const uint64_t *d_slabs, uint64_t sub_cap, uint32_t n_peers,
                               uint32_t n_subs, uint32_t peer_stride, const uint32_t *d_fill, uint64_t kmers_bound);
 
-/* qm2_route_device with the text level's per-XCD sub-regions: every one of the n_regions
+/* qm2_route_device with the text level's per-XCD sub-regions (EXPERIMENTS.md section 4.1): every one of the n_regions
  * (<= 1024) regions is cut into 8, one per XCD, so that a 128-byte line of the output only ever passes through one L2
  * (with hundreds of regions the plain layout writes a third of its lines as two masked pieces: 8.9 - 11.9 ms instead
  * of 7.4 per 20 M reads at C3).  Layout x-major: sub-region x of region r = region x * n_regions + r of d_slabs, each of

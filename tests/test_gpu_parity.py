@@ -1518,7 +1518,7 @@ def test_loader_waves_out_of_step(torch_cuda, tmp_path):
     which the last loader wave runs late (-DQM2_TEST_LOADER_SKEW) makes the other waves stage before it flushes — at the
     table's middle the assignment by slice position that the kernel had until round 4 then corrupted the counts of the
     buckets in front of it (448 032 slots of this very workload with round 3's kernel built the same way,
-    tools/history/r4/skew_old_kernel.py; by chance once before, with two processes on the GPU).  The skewed build must equal the direct kernel slot for slot on a table whose
+    git show 702b9be:tools/history/r4/skew_old_kernel.py; by chance once before, with two processes on the GPU).  The skewed build must equal the direct kernel slot for slot on a table whose
     workgroups each cross the middle."""
     torch = torch_cuda
     pkg = os.path.join(ROOT, "quick-mer2_amd")

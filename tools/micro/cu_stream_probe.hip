@@ -1,6 +1,6 @@
 // tools/micro/cu_stream_probe.hip — what can ONE CU pull from HBM, and does that change with how many CUs are pulling?
 //
-// The question behind DESIGN.md section 4.1.3 ("time x CUs is constant"): bucket_count moves 16 GB/s per CU and needs
+// The question behind EXPERIMENTS.md section 4.1.3 ("time x CUs is constant"): bucket_count moves 16 GB/s per CU and needs
 // exactly twice as long on half the CUs.  Is 16 GB/s close to what a CU's memory pipe can do at all — in which case the
 // chip's 8 TB/s is only there for kernels whose 256 CUs each run at their own limit — or is it the kernel's latency hiding?
 //

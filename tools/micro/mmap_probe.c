@@ -7,6 +7,8 @@
  *   pread    into a private buffer of one block (what qm2_reader.c does), then pack from it
  *   mmap     the file mapped once (MAP_SHARED), packed straight from the mapping, pages faulted in as they are touched
  *   mmap+populate   the same with MAP_POPULATE (the time of the mmap call is counted)
+ *   mmap, per block the worker itself maps a block in (MADV_POPULATE_READ), packs from it and lets it go again (MADV_DONTNEED):
+ *                   the page-table work of the two modes above, spread over the threads
  * Rates: bytes of the file per second. */
 #define _GNU_SOURCE
 #include <fcntl.h>
@@ -33,6 +35,9 @@ static void *run(void *arg)
         const char *p;
         if (j->mode == 0) { ssize_t r = pread(j->fd, buf, n, (off_t)off); if (r != (ssize_t)n) { perror("pread"); exit(1); } p = buf; }
         else p = j->map + off;
+#ifdef MADV_POPULATE_READ
+        if (j->mode == 3 && madvise((void *)(j->map + off), n, MADV_POPULATE_READ)) { perror("MADV_POPULATE_READ"); exit(1); }
+#endif
         const char *first = memchr(p, '\n', n);                       /* from a line start on, whole lines */
         const char *last = memrchr(p, '\n', n);
         if (!first || last <= first) continue;
@@ -40,6 +45,7 @@ static void *run(void *arg)
         qm2_packed pk;
         if (qm2_pack_reads(first + 1, (size_t)(last - first), &st, out, qm2_packed_bound(j->block + 4096), wraps, 64, &pk)) { puts("pack failed"); exit(1); }
         j->bases += 64 * pk.n_blocks - pk.n_newlines;
+        if (j->mode == 3) madvise((void *)(j->map + off), n, MADV_DONTNEED);
     }
     free(buf); free(out);
     return NULL;
@@ -52,9 +58,9 @@ int main(int argc, char **argv)
     const int fd = open(argv[1], O_RDONLY);
     struct stat sb;
     if (fd < 0 || fstat(fd, &sb)) { perror(argv[1]); return 1; }
-    static const char *names[3] = {"pread", "mmap", "mmap+populate"};
+    static const char *names[4] = {"pread", "mmap", "mmap+populate", "mmap, per block"};
     for (int rep = 0; rep < 2; rep++)
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < 4; mode++) {
         const double t0 = now();
         const char *map = NULL;
         if (mode) {

@@ -1,6 +1,6 @@
 // tools/micro/ring_probe.hip — does a write -> read round trip through a small ring stay on the die (256 MiB Infinity Cache)?
 //
-// The question behind DESIGN.md section 7 ("take the level-2 round trip out of HBM"): the k-mers of one level-1 parent
+// The question behind EXPERIMENTS.md section 7 ("take the level-2 round trip out of HBM"): the k-mers of one level-1 parent
 // (~47 MB at 50 M reads per batch) are written by split_kmer and read once by bucket_count.  If parents were processed a
 // few at a time through a ring of level-2 buffers, would the ring's lines be served from the Infinity Cache instead of
 // HBM — and how much other traffic between the write and the read (the parent's own level-1 reads, the 48 MB table

@@ -1,6 +1,6 @@
 // tools/micro/superkmer_probe.hip — what would a minimizer front end cost, and how many bytes per k-mer would it hand on?
 //
-// the three passes of the partitioned pipeline move 8 bytes per k-mer twice; a run of
+// EXPERIMENTS.md section 7.1: the three passes of the partitioned pipeline move 8 bytes per k-mer twice; a run of
 // consecutive k-mers that share their canonical minimizer (a "super-k-mer") could travel as one record, the bases
 // once.  This probe measures the two numbers that decide whether that is worth a pipeline: the time of the
 // minimizer pass over a batch of 150-base reads (synthetic text: 150 bases + '\n' per line, no N), and the number

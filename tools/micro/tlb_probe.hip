@@ -1,7 +1,7 @@
 // tools/micro/tlb_probe.hip — what does the per-CU translation cache (UTCL1) hold?
 //
 // split_text writes 1024 streams that lie far apart; rocprofv3 shows one UTCL1 miss per run it writes and
-// the shared UTCL2 busy for the whole kernel.  This probe measures the UTCL1's reach:
+// the shared UTCL2 busy for the whole kernel (EXPERIMENTS.md section 4.1).  This probe measures the UTCL1's reach:
 // every wave stores 512 bytes to stream 0, then to stream 1, ... stream N-1, round and round; streams are S
 // bytes apart.  Run under
 //     rocprofv3 --pmc TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum --output-format csv -d out -- ./tlb_probe

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Address-translation counters of split_text in several processes (its time differs between processes:
-# DESIGN.md section 4.1): one rocprofv3 --pmc pass per process, the bench's own kernel times beside the counters.
+# EXPERIMENTS.md section 4.1): one rocprofv3 --pmc pass per process, the bench's own kernel times beside the counters.
 set -u
 OUT=$(pwd)/gpurun_out/pmc_tlb_${1:-a}
 N=${2:-5}
