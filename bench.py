@@ -463,6 +463,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-binary", action="store_true", help="CPU leg: the oracle port only")
     ap.add_argument("--no-streamed", action="store_true", help="skip the host-fed (PCIe-inclusive) regions")
+    ap.add_argument("--no-bind", action="store_true", help="do not restrict this process to the CPUs of the GPU's NUMA node")
     ap.add_argument("--no-realistic", action="store_true", help="skip the c3r batch (half the reads from elsewhere, 5 % from 1000 repeat families)")
     ap.add_argument("--no-random-access", action="store_true", help="skip the random-access microbenchmark (roofline.random_access)")
     ap.add_argument("--no-geometry-check", action="store_true",
@@ -523,6 +524,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the count path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # the host side of the fed regions (pageable copies of the batches, pinned staging, the packing threads) on the socket
+    # this rank's GPU hangs off (a placement hint; --no-bind or QM2_NO_BIND=1: wherever the scheduler puts them)
+    cpus_near = pyqm2.bind_near_device(local) if not args.no_bind else None
     wl = dict(WORKLOADS[args.workload])
     if args.reads_per_step:
         wl["reads"] = args.reads_per_step
@@ -955,7 +959,7 @@ def main():
                     "bytes_per_base_over_the_link": round(moved / max(1, nbases), 4),
                     "steps": packed_steps, "seconds": round(sec, 3), "allocations_inside": allocs,
                     "device_batch_positions": (step_bytes + 63) & ~63,
-                    "pack_isa": pyqm2.lib().qm2_pack_isa().decode(),
+                    "pack_isa": pyqm2.lib().qm2_pack_isa().decode(), "cpus_of_the_gpus_numa_node_bound_to": cpus_near,
                     "feed": "qm2_submit_threads(ctx, lines, n, %d): one call per step on a 9 GB buffer of sequence lines in pageable memory; the library's threads pack "
                             "32 MiB pieces into the pinned staging buffers (qm2_pack_lines: 2-bit codes + reset flags, what the CLI's reader threads do behind pread), "
                             "the calling thread commits them in order; timed from the first call to the return of qm2_finish" % args.feed_threads}

@@ -489,6 +489,14 @@ int qm2_shard_span(const uint64_t *keys, uint64_t hash_size, uint32_t n_shards,
                    uint32_t g, uint64_t *own_lo, uint64_t *own_hi,
                    uint64_t *span_lo, uint64_t *span_hi);
 
+/* Restrict the CALLING thread (and every thread it starts afterwards) to the CPUs of the NUMA node that HIP device
+ * `device` hangs off (its PCI function's numa_node in sysfs): the threads that read, pack and stage the input then touch
+ * memory — the page cache copy, the pinned staging buffers — on the socket whose PCIe root the DMA leaves through.  A
+ * host-side placement hint and nothing else: returns 0 and changes nothing where the topology cannot be read (no sysfs,
+ * one node, a device without affinity); QM2_NO_BIND=1 in the environment turns it into a no-op.  *n_cpus (may be NULL)
+ * receives how many CPUs the thread may run on afterwards.  ABI 6. */
+int qm2_bind_near_device(int device, uint32_t *n_cpus);
+
 const char *qm2_last_error(void);
 uint32_t    qm2_abi_version(void);
 

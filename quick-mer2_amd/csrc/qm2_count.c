@@ -463,6 +463,8 @@ int qm2_main_count(int argc, char **argv)
 
     const int timing = getenv("QM2_TIMING") != NULL;   /* extra phase lines; off by default so that
                                                           stdout stays the reference's */
+    /* the reader threads, the pinned buffers they fill and the .qm's way to the device on the socket the (first) GPU hangs off */
+    if (n_dev <= 1) (void)qm2_bind_near_device(n_dev == 1 ? devices[0] : -1, NULL);      /* (several GPUs: they may sit on both sockets) */
     struct timespec ta, tb;
     qm2_dict_file d;
     if (qm2_dict_open(ref_prefix, &d)) return 1;

@@ -12,9 +12,11 @@
  * usable HIP device every call fails loudly.
  */
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <thread>
@@ -1869,6 +1871,51 @@ extern "C" int qm2_probe_subslabs_device(qm2_ctx *c, const uint64_t *d_slabs, ui
     src.slabs = d_slabs; src.slab_cap = sub_cap; src.n_slabs = n_peers; src.n_subs = n_subs; src.peer_stride = peer_stride; src.fill = d_fill;
     src.n_upper = bound; src.n_bytes = bound;
     return launch_partitioned(c, src);
+}
+
+/* ---- host placement ---------------------------------------------------------- */
+
+extern "C" int qm2_bind_near_device(int device, uint32_t *n_cpus)
+{
+    cpu_set_t cur;
+    CPU_ZERO(&cur);
+    if (sched_getaffinity(0, sizeof cur, &cur) != 0) { if (n_cpus) *n_cpus = 0; return 0; }
+    if (n_cpus) *n_cpus = (uint32_t)CPU_COUNT(&cur);
+    if (getenv("QM2_NO_BIND")) return 0;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { (void)hipGetLastError(); return 0; }   /* (a hint: whoever needs the device says so) */
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+    if (device >= n_dev) return 0;
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return 0;
+    for (char *q = bus; *q; q++) *q = (char)tolower((unsigned char)*q);
+    char path[256];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    int node = -1;
+    if (!f) return 0;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    if (node < 0) return 0;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return 0;
+    char list[4096] = "";
+    if (!fgets(list, sizeof list, f)) list[0] = 0;
+    fclose(f);
+    cpu_set_t want;
+    CPU_ZERO(&want);
+    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int got = sscanf(tok, "%d-%d", &a, &b);
+        if (got == 1) b = a;
+        if (got < 1) continue;
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &cur)) CPU_SET(c, &want);
+    }
+    if (CPU_COUNT(&want) == 0) return 0;                         /* (none of the node's CPUs is ours: leave things as they are) */
+    if (sched_setaffinity(0, sizeof want, &want) != 0) return 0;
+    if (n_cpus) *n_cpus = (uint32_t)CPU_COUNT(&want);
+    return 0;
 }
 
 /* ---- pure host helper ------------------------------------------------------ */

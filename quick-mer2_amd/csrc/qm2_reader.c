@@ -950,6 +950,19 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads)
         }
     }
     ring.n_slots = n_threads + 3;
+#ifdef F_SETPIPE_SZ
+    /* a pipe (samtools ... | awk ... | quicKmer2 count ref /dev/fd/0 out, README.md:86-94): as large a kernel buffer as an
+     * unprivileged process may ask for (1 MiB by default instead of 64 KiB: fewer hand-overs between the writer and this reader) */
+    {
+        struct stat psb;
+        if (fstat(ring.fd, &psb) == 0 && S_ISFIFO(psb.st_mode)) {
+            long want = 1 << 20;
+            FILE *mx = fopen("/proc/sys/fs/pipe-max-size", "r");
+            if (mx) { long v = 0; if (fscanf(mx, "%ld", &v) == 1 && v > 0) want = v; fclose(mx); }
+            (void)fcntl(ring.fd, F_SETPIPE_SZ, (int)want);
+        }
+    }
+#endif
     line_state ls = {1, 0, 0, lseek(ring.fd, 0, SEEK_CUR) != (off_t)-1, 0};
     out_state os = {out, NULL, 0, 0};
     for (int i = 0; i < ring.n_slots; i++) {

@@ -69,7 +69,7 @@ ABI_SYMBOLS = ["qm2_flush", "qm2_merge_counters", "qm2_route_device", "qm2_route
                "qm2_close", "qm2_counters_device", "qm2_keys_device", "qm2_get_profile",
                "qm2_encode_device", "qm2_probe_device", "qm2_chain_gather", "qm2_chain_fetch", "qm2_keys_from_fd", "qm2_chain_gather_fd", "qm2_chain_gc_sums_fd", "qm2_submit_raw_device", "qm2_staging_commit_raw", "qm2_raw_verdict",
                "qm2_packed_bound", "qm2_pack_lines", "qm2_pack_reads", "qm2_pack_isa", "qm2_pack_isa_select", "qm2_staging_commit_packed", "qm2_submit_packed_device", "qm2_submit_threads",
-               "qm2_shard_span", "qm2_last_error",
+               "qm2_shard_span", "qm2_bind_near_device", "qm2_last_error",
                "qm2_abi_version"]
 TOOL_SYMBOLS = ["qm2t_genome_generate", "qm2t_dict_build", "qm2t_reads_generate",
                 "qm2t_read_offsets", "qm2t_microbench", "qm2t_checksum_u32"]
@@ -179,6 +179,8 @@ def lib():
     L.qm2_chain_fetch.argtypes = [vp, vp, u64, u64]
     L.qm2_shard_span.restype = C.c_int
     L.qm2_shard_span.argtypes = [vp, u64, u32, u32] + [C.POINTER(u64)] * 4
+    L.qm2_bind_near_device.restype = C.c_int
+    L.qm2_bind_near_device.argtypes = [C.c_int, C.POINTER(u32)]
     L.qm2_last_error.restype = C.c_char_p
     L.qm2_abi_version.restype = u32
     L.qm2t_genome_generate.restype = C.c_int
@@ -537,6 +539,13 @@ def pack_reads(text: bytes, fastq, skip=0, wraps_cap=4096, room=None):
     if rc:
         raise Qm2Error("qm2_pack_reads: %d" % rc)
     return out[:3 * p.n_blocks], p, wraps[:p.n_wraps], st
+
+
+def bind_near_device(device=-1):
+    """qm2_bind_near_device: this thread (and the ones it starts) onto the CPUs of the device's NUMA node; -> CPUs it may run on"""
+    n = C.c_uint32(0)
+    _check(lib().qm2_bind_near_device(device, C.byref(n)), "qm2_bind_near_device")
+    return int(n.value)
 
 
 def shard_span(keys, n_shards, g):

@@ -754,6 +754,25 @@ def test_keys_changed_under_a_live_context(qm2, torch_cuda, tmp_path):
             assert c.profile()["refused_batches"] == 0
 
 
+def test_bind_near_device_is_only_a_hint(qm2, tmp_path):
+    """qm2_bind_near_device: the calling thread onto the CPUs of the GPU's NUMA node (a subset of what it had, never empty);
+    counting is what it was.  Run in a child process: the affinity of the test runner stays alone."""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import pyqm2
+before = os.sched_getaffinity(0)
+n = pyqm2.bind_near_device(0)
+after = os.sched_getaffinity(0)
+assert 1 <= n == len(after) and after <= before, (n, len(after), len(before))
+os.environ["QM2_NO_BIND"] = "1"
+assert pyqm2.bind_near_device(0) == len(after)
+print("BIND_OK", len(before), len(after))
+""" % os.path.join(ROOT, "quick-mer2_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "BIND_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_empty_and_degenerate_inputs(qm2):
     qm = kat_qm()
     with qm2.Counter(qm["keys"], k=30) as c:

@@ -97,6 +97,12 @@ torch.cuda.empty_cache()
 # driver's clearing of that memory (which the next process's hipMalloc waits for) from the CLI's own load phase.
 if os.environ.get("QM2_E2E_SETTLE"):
     time.sleep(float(os.environ["QM2_E2E_SETTLE"]))
+# what a pipe carries on this host when nothing is done with the bytes: the ceiling of every `... | quicKmer2 count ref /dev/fd/0 out` below
+for name in ("reads.fq",):
+    t = time.time()
+    subprocess.run("cat %s | cat > /dev/null" % os.path.join(reads_dir, name), shell=True, check=True)
+    sec = time.time() - t
+    print("pipe ceiling: `cat %s | cat > /dev/null` %.2f s = %.2f GB/s" % (name, sec, os.path.getsize(os.path.join(reads_dir, name)) / sec / 1e9), flush=True)
 cli = os.environ.get("QM2_E2E_CLI") or os.path.join(ROOT, "quick-mer2_amd", "quicKmer2")
 runs = [(f, t, e) for f in ("reads.fq", "reads.fa")
         for t, e in (("8", {}), ("12", {}), ("16", {}), ("12", {"QM2_READER": "raw"}), ("8", {"QM2_READER": "lines"}), ("4", {"QM2_READER": "lines", "QM2_READER_STREAM": "1"}))]
@@ -104,14 +110,16 @@ reps = 4
 if scale == "c3":
     runs, reps = [("reads.fq", "12", {}), ("reads.fq", "16", {}), ("reads.fq", "12", {"QM2_READER": "raw"})], 2
 # QM2_E2E_RUNS="fq:12,fq:24,fq:12:0+0,fa:8::lines,fa:12:s0,fq:12::raw": file : threads [: devices joined by '+' (s0+1 = --shards 0,1)]
-# [: packed | raw | lines (QM2_READER; "host" = lines)]
+# [: packed | raw | lines (QM2_READER; "host" = lines)] [: pipe (the input through `cat file |` and /dev/fd/0: README.md:86-94's usage)]
 if os.environ.get("QM2_E2E_RUNS"):
     runs = []
     for item in os.environ["QM2_E2E_RUNS"].split(","):
-        f = item.split(":") + ["", "", ""]
+        f = item.split(":") + ["", "", "", ""]
         extra = {"QM2_READER": {"host": "lines"}.get(f[3], f[3])} if f[3] else {}
         if f[2]:
             extra["_devices"] = f[2].replace("+", ",")
+        if f[4] == "pipe":
+            extra["_pipe"] = "1"
         runs.append(("reads." + f[0], f[1], extra))
 reps = int(os.environ.get("QM2_E2E_REPS", reps))
 ok = True
@@ -120,11 +128,17 @@ for name, thr, extra in runs:
     best, walls = None, []
     extra = dict(extra)
     devs = extra.pop("_devices", None)
+    pipe = extra.pop("_pipe", None)
     for rep in range(reps):
         t = time.time()
+        cat = subprocess.Popen(["cat", os.path.join(reads_dir, name)], stdout=subprocess.PIPE) if pipe else None
         r = subprocess.run([cli, "count"] + (["-t", thr] if thr else []) + ((["--shards", devs[1:]] if devs.startswith("s") else ["--devices", devs]) if devs else []) +
-                           [os.path.join(work, "ref.fa"), os.path.join(reads_dir, name), os.path.join(work, "out")],
+                           [os.path.join(work, "ref.fa"), "/dev/fd/0" if pipe else os.path.join(reads_dir, name), os.path.join(work, "out")],
+                           stdin=cat.stdout if pipe else None,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, QM2_TIMING="1", **extra))
+        if cat:
+            cat.stdout.close()
+            cat.wait()
         walls.append(time.time() - t)
         out = r.stdout.decode(errors="replace")
         m = re.search(r"QM2 phase count ([0-9.]+) s", out)
@@ -153,7 +167,7 @@ for name, thr, extra in runs:
     ok = ok and bool(good)
     print("== %s -t %s %s%s rc=%d  count phase best: %.3f s = %.2f G bases/s; wall best %.2f s (incl. .qm load, upload, epilogue); "
           "progress lines %d, allocations in the count phase %s%s | %s" %
-          (name, thr, ("--devices %s " % devs) if devs else "", "host strip, read(2) stream" if "QM2_READER_STREAM" in extra else
+          (name + (" through a pipe" if pipe else ""), thr, ("--devices %s " % devs) if devs else "", "host strip, read(2) stream" if "QM2_READER_STREAM" in extra else
            {"lines": "host strip to ASCII lines, pread blocks", "raw": "raw text, device line discipline", "packed": "packed by the reader threads"}[extra.get("QM2_READER", "packed")],
            r.returncode, best, n_reads * 150 / best / 1e9, min(walls), len(prog), al.group(1) if al else "?", "" if good else "  <-- CHECK FAILED",
            load.group(0) if load else ""), flush=True)
