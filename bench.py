@@ -46,14 +46,15 @@ VALU_WAVE_INSTS_PER_CU_CYCLE = 1.0
 
 
 def kernel_source_sha16():
-    """Identifies the kernels a PMC file was measured on: sha256 over the device sources of libqm2_hip.so (16 hex digits).
-    tools/summarize_profile.py stamps profiles/traffic_<workload>.json with it; a bench line only quotes the file's
-    counters (roofline.traffic, roofline.valu) when the stamp is that of the tree it runs from."""
+    """Identifies the kernels a PMC file was measured on: sha256 over the device code of libqm2_hip.so — the kernel headers
+    csrc/*.hip.h (16 hex digits; the launch parameters in qm2_hip.hip are not part of it).  tools/summarize_profile.py stamps
+    profiles/traffic_<workload>.json with it; a bench line only quotes the file's counters (roofline.traffic, roofline.valu)
+    when the stamp is that of the tree it runs from."""
     import glob
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, "quick-mer2_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.hip.h")) + [os.path.join(src, "qm2_plan.h")]):
+    for f in sorted(glob.glob(os.path.join(src, "*.hip.h"))):
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
