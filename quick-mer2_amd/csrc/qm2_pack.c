@@ -8,8 +8,9 @@
  * device, which reads these blocks instead of ASCII (qm2_device.hip.h, unpack16).  Plain C, no device code; part of
  * libqm2_hip.so so that the CLI's reader threads, qm2_submit and bench.py share one implementation.
  *
- * Three builds of the same loops (qm2_pack_body.h), chosen once at run time: AVX-512BW + BMI2 (64 text bytes per
- * compare, the masks straight from vpmovb2m / vpcmpeqb, the 2-bit interleave by pdep), AVX2 + BMI2, and portable C.
+ * Builds of the same loops (qm2_pack_body.h), chosen once at run time: AVX-512BW + BMI2 (64 text bytes per compare, the
+ * masks straight from vpmovb2m / vpcmpeqb, the 2-bit interleave by pdep), AVX2 + BMI2, portable C — and, where the CPU has
+ * AVX-512 VBMI2, a pack_reads that compacts the kept bytes with vpcompressb first (below).
  */
 #define _GNU_SOURCE
 #include <stdatomic.h>
@@ -167,6 +168,158 @@ AVX512_T static inline void masks64_avx512(const uint8_t *p, uint64_t *hi, uint6
 #undef QM2_SPREAD
 #endif
 
+#if defined(__x86_64__)
+/* ---- the fourth build: AVX-512 VBMI2 (Zen 4 / 5, Ice Lake and later) -------------------------------------------------
+ * pack_reads in two stages that never touch a bit accumulator: (1) the line discipline works out, per 64-byte group and
+ * with the same mask arithmetic as the pext build (newline / '>' masks, pdep for every fourth line start, the borrow chain
+ * of nl - starts), WHICH BYTES are kept, and vpcompressb moves exactly those to the front of a small scratch buffer that
+ * stays in the L1 / L2; (2) the compacted text — sequence lines, nothing else — is packed a whole block at a time by the
+ * loop of pack_lines (the masks straight from vpmovb2m / vpcmpeqb, two pdep per word).  What it saves are the three pext
+ * and the accumulator's data-dependent "block full?" branch per group: 13.5 -> 16.2 GB/s of FASTQ per thread on Zen 5,
+ * 9.2 -> 11.7 of FASTA (tools/micro/pack_probe 1 128 <isa> 12 3; the line discipline alone runs at 20.5). */
+#define VBMI2_T __attribute__((target("avx512f,avx512bw,avx512vbmi2,bmi2")))
+#define QM2_VB_SCRATCH ((size_t)4 << 10)        /* 4 KiB: 16.2 GB/s per thread on Zen 5, 16 KiB: 14.8 (EXPERIMENTS.md) */
+
+/* whole blocks of the scratch's `fill` bytes -> the sink from block `nb` on; the rest (< 64 bytes) moves to the front (or,
+ * final, is filled up with line ends).  Returns the blocks written, -1 when the output is full; *newlines grows. */
+VBMI2_T static inline __attribute__((always_inline)) long vb_flush(uint8_t *buf, size_t fill, const pack_sink *s, size_t nb, int final, uint64_t *newlines)
+{
+    size_t i = 0;
+    const size_t nb0 = nb;
+    uint64_t lines = 0;
+    if (nb + fill / 64 + (final && (fill & 63)) > s->cap_blocks) return -1;
+    for (; i + 64 <= fill; i += 64) {
+        uint64_t hi, lo, nl, nn;
+        masks64_avx512(buf + i, &hi, &lo, &nl, &nn);
+        lines += (uint64_t)__builtin_popcountll(nl);
+        put_block_avx512(s->out + 3 * nb++, hi, lo, nl | nn);
+    }
+    const size_t rest = fill - i;
+    if (final && rest) {                              /* the last block is filled up with line ends */
+        uint64_t hi, lo, nl, nn;
+        masks_tail_avx512(buf + i, rest, &hi, &lo, &nl, &nn);
+        const uint64_t m = (1ull << rest) - 1;
+        lines += (uint64_t)__builtin_popcountll(nl & m) + (64 - rest);
+        put_block_avx512(s->out + 3 * nb++, hi & m, lo & m, nl | nn);
+    } else if (rest && i) _mm512_storeu_si512((void *)buf, _mm512_loadu_si512((const void *)(buf + i)));
+    *newlines += lines;
+    return (long)(nb - nb0);
+}
+
+VBMI2_T static int pack_reads_vbmi2(const uint8_t *text, size_t n, qm2_line_state *st, pack_sink *s)
+{
+    uint32_t skip = st->skip, desync = st->desync;
+    const uint32_t fastq = st->fastq;
+    int at_line_start = 1, take = 0;
+    size_t line_start = 0;
+    uint64_t line_pos0 = 0;
+    uint8_t *const buf = aligned_alloc(64, QM2_VB_SCRATCH + 128);     /* the kept bytes, compacted; stays in the L1 */
+    if (!buf) return 2;
+    size_t fill = 0, n_blocks = 0;                  /* (locals: the stores into buf must not make the compiler reload them) */
+    uint64_t n_kept = 0, newlines = 0;
+    int rc = 0;
+    for (size_t g = 0; g < n && !rc; g += 64) {
+        size_t cnt = 64;
+        __m512i bytes;
+        if (n - g >= 64) bytes = _mm512_loadu_si512((const void *)(text + g));
+        else {
+            uint8_t tmp[64];
+            cnt = n - g;
+            memset(tmp, '\n', sizeof tmp);
+            memcpy(tmp, text + g, cnt);
+            bytes = _mm512_loadu_si512((const void *)tmp);
+        }
+        const uint64_t valid = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
+        const uint64_t nl = (uint64_t)_mm512_cmpeq_epi8_mask(bytes, _mm512_set1_epi8('\n')) & valid;
+        if (!nl && !take && !at_line_start) continue;                                 /* inside a dropped line */
+        const uint64_t gt = (uint64_t)_mm512_cmpeq_epi8_mask(bytes, _mm512_set1_epi8('>')) & valid;
+        const uint64_t starts = ((nl << 1) | (uint64_t)(at_line_start != 0)) & valid;
+        uint64_t sel;
+        uint64_t kept = fastq ? _pdep_u64(0x1111111111111111ull << skip, starts) : starts & ~gt;
+        if (!(fastq && (kept & gt))) {
+            const uint64_t from = kept | (uint64_t)(!at_line_start && take);
+            sel = ((nl - from) ^ nl) & valid;
+            if (!at_line_start && take && nl) {                                       /* the open kept line ends at the lowest newline */
+                const size_t line_len = g + (size_t)__builtin_ctzll(nl) - line_start;
+                if (line_len >= 65536 && sink_wraps(s, text + line_start, line_len, line_pos0)) { rc = 2; break; }
+            }
+            const unsigned n_starts = (unsigned)__builtin_popcountll(starts);
+            if (fastq) skip = (skip + 4u - (n_starts & 3u)) & 3u;
+            const int ends_with_nl = (int)((nl >> (cnt - 1)) & 1), last_kept = (int)((sel >> (cnt - 1)) & 1);
+            if (!ends_with_nl && last_kept && kept && (!nl || (63 - __builtin_clzll(kept)) > (63 - __builtin_clzll(nl)))) {
+                const unsigned b = 63u - (unsigned)__builtin_clzll(kept);
+                line_start = g + b;
+                line_pos0 = n_kept + (uint64_t)__builtin_popcountll(sel & ((1ull << b) - 1));
+            }
+            at_line_start = ends_with_nl;
+            take = ends_with_nl ? take : last_kept;
+        } else {
+            /* a FASTQ sequence-position line that starts with '>' (:398 drops it WITHOUT the three discards): line by line */
+            sel = 0;
+            size_t pos = 0;
+            while (pos < cnt) {
+                if (at_line_start) {
+                    at_line_start = 0;
+                    if (skip) { skip--; take = 0; }
+                    else if ((gt >> pos) & 1) { desync = 1; take = 0; }
+                    else {
+                        take = 1;
+                        skip = 3;
+                        line_start = g + pos;
+                        line_pos0 = n_kept + (uint64_t)__builtin_popcountll(sel);
+                    }
+                }
+                const uint64_t rest = nl >> pos;
+                size_t len;
+                int ends;
+                if (rest) { len = (size_t)__builtin_ctzll(rest) + 1; ends = 1; }
+                else { len = cnt - pos; ends = 0; }
+                if (take) {
+                    sel |= (len >= 64 ? ~0ull : (1ull << len) - 1) << pos;
+                    if (ends) {
+                        const size_t line_len = g + pos + len - 1 - line_start;
+                        if (line_len >= 65536 && sink_wraps(s, text + line_start, line_len, line_pos0)) { rc = 2; break; }
+                    }
+                }
+                pos += len;
+                if (ends) at_line_start = 1;
+            }
+            if (rc) break;
+        }
+        /* the kept bytes of the group to the front of what the scratch holds (a whole vector is stored: what lies behind
+         * the kept bytes is overwritten by the next group) */
+        _mm512_storeu_si512((void *)(buf + fill), _mm512_maskz_compress_epi8((__mmask64)sel, bytes));
+        const unsigned m = (unsigned)__builtin_popcountll(sel);
+        fill += m;
+        n_kept += m;
+        if (fill >= QM2_VB_SCRATCH) {
+            const long w = vb_flush(buf, fill, s, n_blocks, 0, &newlines);
+            if (w < 0) { rc = 2; break; }
+            n_blocks += (size_t)w;
+            fill &= 63;
+        }
+    }
+    if (!rc && !at_line_start && take) {            /* the text's last line had no '\n': supplied */
+        buf[fill++] = '\n';
+        if (n - line_start >= 65536 && sink_wraps(s, text + line_start, n - line_start, line_pos0)) rc = 2;
+    }
+    if (!rc) {
+        const long w = vb_flush(buf, fill, s, n_blocks, 1, &newlines);
+        if (w < 0) rc = 2;
+        else n_blocks += (size_t)w;
+    }
+    if (!rc) {
+        s->n_blocks = n_blocks;
+        s->n_newlines = newlines;
+        s->n_pos = 64 * (uint64_t)n_blocks;
+        st->skip = skip;
+        st->desync = desync;
+    }
+    free(buf);
+    return rc;
+}
+#endif
+
 /* ---- dispatch -------------------------------------------------------------------------------------------------------- */
 
 typedef struct {
@@ -179,6 +332,7 @@ static const pack_impl impl_portable = {"portable", pack_lines_portable, pack_re
 #if defined(__x86_64__)
 static const pack_impl impl_avx2 = {"avx2", pack_lines_avx2, pack_reads_avx2};
 static const pack_impl impl_avx512 = {"avx512", pack_lines_avx512, pack_reads_avx512};
+static const pack_impl impl_vbmi2 = {"avx512vbmi2", pack_lines_avx512, pack_reads_vbmi2};
 #endif
 
 static const pack_impl *by_name(const char *want)
@@ -188,9 +342,11 @@ static const pack_impl *by_name(const char *want)
     __builtin_cpu_init();
     const int has2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
     const int has512 = has2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw");
+    const int hasvb = has512 && __builtin_cpu_supports("avx512vbmi2");
     if (want && !strcmp(want, "portable")) c = &impl_portable;
     else if (want && !strcmp(want, "avx2")) c = has2 ? &impl_avx2 : &impl_portable;
-    else c = has512 ? &impl_avx512 : has2 ? &impl_avx2 : &impl_portable;
+    else if (want && !strcmp(want, "avx512")) c = has512 ? &impl_avx512 : has2 ? &impl_avx2 : &impl_portable;
+    else c = hasvb ? &impl_vbmi2 : has512 ? &impl_avx512 : has2 ? &impl_avx2 : &impl_portable;
 #else
     (void)want;
 #endif

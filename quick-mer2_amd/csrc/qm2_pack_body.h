@@ -114,9 +114,10 @@ QM2_TARGET static int QM2_FN(pack_reads)(const uint8_t *text, size_t n, qm2_line
         {
             const uint64_t valid = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
             const uint64_t starts = ((nl << 1) | (uint64_t)(at_line_start != 0)) & valid;
-            uint64_t kept = 0;
+            uint64_t kept;
             int fast = 1;
-            if (starts) {
+            {
+                /* (no test for "no line starts here": pdep of nothing is nothing, and the branch would be a coin toss) */
                 const uint64_t gt = cnt >= 64 ? QM2_GTMASK(text + g) : QM2_FN(gt_tail)(text + g, cnt);
                 if (fastq) {
                     kept = _pdep_u64(0x1111111111111111ull << skip, starts);

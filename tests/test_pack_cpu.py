@@ -19,7 +19,7 @@ def pkg():
         ge.build()
     return ge.load_package()
 
-ISAS = ["portable", "avx2", "avx512"]
+ISAS = ["portable", "avx2", "avx512", "avx512vbmi2"]
 
 
 @pytest.fixture(params=ISAS)
@@ -255,3 +255,23 @@ def test_the_three_builds_agree():
         outs.append((b1.tobytes(), p1.n_newlines))
     L.qm2_pack_isa_select(None)
     assert len(set(outs)) == 1 and len(outs) >= 1
+
+
+def test_pack_reads_fuzz_against_the_line_discipline(isa):
+    """byte soup with newlines, '>' and '@' wherever they fall — FASTA and FASTQ from every line state, desynchronising
+    lines included (the model follows :398 / :451-455 literally): position for position the model's strip, packed"""
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"ACGTNacgtn>@+\n\n\n\r\x00\xff", np.uint8)
+    for trial in range(120):
+        n = int(rng.integers(0, 3000))
+        text = alphabet[rng.integers(0, len(alphabet), n)].tobytes()
+        if trial % 3 == 0:
+            text += b"\n"
+        for fastq, skip in ((False, 0), (True, int(rng.integers(0, 4)))):
+            check_reads(text, fastq, skip)
+    # long stretches without a newline across many 64-byte groups, group-aligned and not
+    for n in (63, 64, 65, 127, 128, 129, 4096, 4097):
+        body = alphabet[rng.integers(0, 10, n)].tobytes()
+        for lead in (b"", b"\n", b">x\n", b"AC\n+\nII\n@h\n"):
+            check_reads(lead + body + b"\n" + body[:7], True, 0)
+            check_reads(lead + body, False, 0)

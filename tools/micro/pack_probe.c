@@ -1,12 +1,13 @@
 /* tools/micro/pack_probe.c — the host packers of quick-mer2_amd/csrc/qm2_pack.c alone: bytes of text per second and thread.
  *
- *   pack_probe [threads=1,2,4,8,12,16] [MiB of text per thread=256] [isa=auto|avx512|avx2|portable]
+ *   pack_probe [threads=1,2,4,8,12,16] [MiB of text per thread=256] [isa=auto|avx512vbmi2|avx512|avx2|portable] [kinds=0123] [reps=1]
  *
  * Every thread packs its own slice of synthetic text from pageable memory into its own output buffer (no GPU, no I/O):
  *   lines   150-base sequence lines                                    -> qm2_pack_lines
  *   fastq   "@r..\n" + 150 bases + "\n+\n" + 150 qualities + "\n"      -> qm2_pack_reads (line discipline + packing)
  *   fasta   ">r..\n" + 150 bases + "\n"                                -> qm2_pack_reads
- * beside memcpy of the same text (what the ASCII path's staging copy costs).  Rates are text bytes in, GB/s. */
+ * beside memcpy of the same text (what the ASCII path's staging copy costs).  Rates are text bytes in, GB/s; kinds picks the
+ * rows (0 lines, 1 fastq, 2 fasta, 3 memcpy), reps > 1 prints the best of so many runs over the same text. */
 #define _GNU_SOURCE
 #include <pthread.h>
 #include <stdint.h>
@@ -52,6 +53,8 @@ int main(int argc, char **argv)
     const char *tl = argc > 1 ? argv[1] : "1,2,4,8,12,16";
     const size_t mib = argc > 2 ? (size_t)atol(argv[2]) : 256;
     printf("packers: %s\n", qm2_pack_isa_select(argc > 3 && strcmp(argv[3], "auto") ? argv[3] : NULL));
+    const char *kinds = argc > 4 ? argv[4] : "0123";
+    const int reps = argc > 5 && atoi(argv[5]) > 0 ? atoi(argv[5]) : 1;
     static const char *names[4] = {"lines", "fastq", "fasta", "memcpy (lines)"};
     char list[256];
     snprintf(list, sizeof list, "%s", tl);
@@ -59,6 +62,7 @@ int main(int argc, char **argv)
         const int nt = atoi(tok);
         if (nt < 1 || nt > 256) continue;
         for (int kind = 0; kind < 4; kind++) {
+            if (!strchr(kinds, '0' + kind)) continue;
             job *jobs = calloc((size_t)nt, sizeof *jobs);
             pthread_t *th = calloc((size_t)nt, sizeof *th);
             for (int t = 0; t < nt; t++) {
@@ -77,21 +81,22 @@ int main(int argc, char **argv)
                 jobs[t].out = aligned_alloc(64, (jobs[t].out_cap + 63) & ~(size_t)63);
                 memset(jobs[t].out, 0, jobs[t].out_cap);
             }
-            const double t0 = now();
-            for (int t = 0; t < nt; t++) pthread_create(&th[t], NULL, run, &jobs[t]);
-            double slowest = 0, bytes = 0, bases = 0;
+            double wall = 1e30, bytes = 0, bases = 0;
             int rc = 0;
-            for (int t = 0; t < nt; t++) {
-                pthread_join(th[t], NULL);
-                if (jobs[t].sec > slowest) slowest = jobs[t].sec;
-                bytes += (double)jobs[t].n; bases += (double)jobs[t].bases; rc |= jobs[t].rc;
+            for (int rep = 0; rep < reps; rep++) {
+                const double t0 = now();
+                bytes = bases = 0;
+                for (int t = 0; t < nt; t++) { jobs[t].bases = 0; pthread_create(&th[t], NULL, run, &jobs[t]); }
+                for (int t = 0; t < nt; t++) {
+                    pthread_join(th[t], NULL);
+                    bytes += (double)jobs[t].n; bases += (double)jobs[t].bases; rc |= jobs[t].rc;
+                }
+                if (now() - t0 < wall) wall = now() - t0;
             }
-            const double wall = now() - t0;
             char rate[64] = "";
             if (kind != 3) snprintf(rate, sizeof rate, "  = %.2f G bases/s", bases / wall / 1e9);
             printf("%2d threads  %-15s %7.2f GB/s of text (%6.2f per thread)%s\n", nt, names[kind], bytes / wall / 1e9, bytes / wall / 1e9 / nt, rate);
             if (rc) { puts("a packer refused its input"); return 1; }
-            (void)slowest;
             for (int t = 0; t < nt; t++) { free((void *)jobs[t].text); free(jobs[t].out); }
             free(jobs); free(th);
         }
