@@ -413,16 +413,31 @@ __host__ __device__ __forceinline__ int64_t lane_offset(uint64_t tile0, int lane
     return (int64_t)tile0 - kHaloLanes * kBytesPerLane + (int64_t)lane * kBytesPerLane;
 }
 
+/* The value of the lane below (lane 0 keeps its own): DPP wave_shr:1, a vector-ALU move — __shfl_up is a ds_bpermute_b32,
+ * an LDS round trip in front of everything a chunk does.  Two steps stand in for __shfl_up(x, 2): lane 1 then holds lane
+ * 0's value, not its own, which nobody looks at (lanes < kHaloLanes never emit). */
+__device__ __forceinline__ uint32_t lane_up1(uint32_t x)
+{
+#ifndef QM2_LANE_UP_DPP
+#define QM2_LANE_UP_DPP 1
+#endif
+#if QM2_LANE_UP_DPP
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138, 0xF, 0xF, false);
+#else
+    return __shfl_up(x, 1);
+#endif
+}
+
 /* Build the window for `lane` of a wave whose tile starts at byte tile0.
- * All 64 lanes must call (wave shuffles inside).  PK: packed input. */
+ * All 64 lanes must call (lane shifts inside).  PK: packed input. */
 template <bool K30, bool PK = false>
 __device__ __forceinline__ Window make_window(const SeqView &sv, uint64_t tile0, int lane, uint32_t k)
 {
     const int64_t g = lane_offset(tile0, lane);
     const Packed p = PK ? unpack16(sv, g, load16_packed_raw(sv, g)) : pack16(load16(sv, g));
     Packed p1, p2;
-    p1.fwd = __shfl_up(p.fwd, 1); p1.bad = __shfl_up(p.bad, 1); p1.nl = 0;
-    p2.fwd = __shfl_up(p.fwd, 2); p2.bad = __shfl_up(p.bad, 2); p2.nl = 0;
+    p1.fwd = lane_up1(p.fwd); p1.bad = lane_up1(p.bad); p1.nl = 0;
+    p2.fwd = lane_up1(p1.fwd); p2.bad = lane_up1(p1.bad); p2.nl = 0;
     return assemble_window<K30>(sv, g, lane < kHaloLanes, p, p1, p2, k);
 }
 
@@ -433,8 +448,8 @@ __device__ __forceinline__ Window make_window_from(const SeqView &sv, uint64_t t
     const int64_t g = lane_offset(tile0, lane);
     const Packed p = PK ? unpack16(sv, g, bytes) : pack16(fix16(sv, g, bytes));
     Packed p1, p2;
-    p1.fwd = __shfl_up(p.fwd, 1); p1.bad = __shfl_up(p.bad, 1); p1.nl = 0;
-    p2.fwd = __shfl_up(p.fwd, 2); p2.bad = __shfl_up(p.bad, 2); p2.nl = 0;
+    p1.fwd = lane_up1(p.fwd); p1.bad = lane_up1(p.bad); p1.nl = 0;
+    p2.fwd = lane_up1(p1.fwd); p2.bad = lane_up1(p1.bad); p2.nl = 0;
     return assemble_window<K30>(sv, g, lane < kHaloLanes, p, p1, p2, k);
 }
 

@@ -62,6 +62,17 @@ constexpr int kCountThreads  = QM2_COUNT_THREADS;
 #ifndef QM2_STAMPS_SORT
 #define QM2_STAMPS_SORT 0         /* diagnostic build (-DQM2_STAMPS): 1 = also the phases of sort_chunk in split_text_kernel */
 #endif
+/* The chunk sort's workgroup barriers (sort_chunk).  0: five per chunk (zero the counts | rank | scan per wave | wave totals |
+ * scatter).  2: four — two count arrays take turns and the one not in use is zeroed during the scan of the other, so the chunk
+ * loop has no zero-and-barrier of its own.  Same box, C3: split_text 20.37 ms with five, 20.95 with four; split_kmer 24.23 with
+ * five, 23.85 with four (EXPERIMENTS.md; a three-barrier arrangement in which every wave scans all the counts itself lost on
+ * both: profiles/r05_c3/sort_chunk_three_barriers.patch). */
+#ifndef QM2_SORT_SYNC_TEXT
+#define QM2_SORT_SYNC_TEXT 0
+#endif
+#ifndef QM2_SORT_SYNC_KMER
+#define QM2_SORT_SYNC_KMER 2
+#endif
 #ifndef QM2_COUNT_BLOCKED
 #define QM2_COUNT_BLOCKED 0
 #endif
@@ -164,8 +175,9 @@ __device__ __forceinline__ uint64_t sub_region0(const SplitDst &d, uint32_t fan)
 constexpr int kSpillRuns = kMaxFan;         /* overflowing runs of a chunk that the whole workgroup copies out together: every child may */
 struct SplitLds {
     uint64_t sorted[kSplitSlots + 1];       /* the chunk sorted by child; last = trash slot          */
-    uint32_t hist[kMaxFan + 1];             /* [kMaxFan] = trash bin of the empty slots (keeps the
-                                               rank atomics and the scatter branch-free)             */
+    uint32_t hist[2][kMaxFan + 1];          /* counts per child; [kMaxFan] = trash bin of the empty slots (keeps the rank
+                                               atomics and the scatter branch-free).  Two arrays: with SYNC = 2 they take
+                                               turns chunk by chunk (QM2_SORT_SYNC_*), else only [0] is used */
     uint16_t off[kMaxFan + 2];              /* exclusive prefix of hist (< 2^16: a chunk has <= 16 K k-mers); [kMaxFan] = the
                                                chunk's total: the empty slots scatter behind the real k-mers, where the
                                                copy-out never looks (total + empty slots = kSplitSlots exactly) */
@@ -173,7 +185,6 @@ struct SplitLds {
                                                to slot i + dl.x of the child's region if i < dl.y
                                                (dl.x = reserved start - off, dl.y = off + what fits)  */
     uint32_t wsum[kMaxFan / kWave];
-    uint32_t total;                         /* real k-mers in the sorted chunk                       */
     uint32_t spill_n;                       /* runs of this chunk that did not fit their child ...   */
     uint2    spill_e[kSpillRuns];           /* ... {first element in sorted | how many << 16, place in the spill list} */
 };
@@ -199,10 +210,36 @@ __device__ __attribute__((noinline)) void copy_spills(const SplitLds &L, uint64_
     }
 }
 
+/* Inclusive sum over the wave's 64 lanes in the vector ALU alone (DPP: four shifts inside the rows of 16, then lane 15 and
+ * lane 31 broadcast onwards) — __shfl_up makes every step a ds_bpermute_b32, an LDS round trip with all the waves of the
+ * workgroup in the same phase and nothing to hide it behind. */
+#ifndef QM2_SCAN_DPP
+#define QM2_SCAN_DPP 1
+#endif
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
+{
+#if QM2_SCAN_DPP
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   /* row_shr:1 (lanes without a source add 0) */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   /* row_shr:2 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   /* row_shr:4 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   /* row_shr:8 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   /* row_bcast:15 into rows 1 and 3 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   /* row_bcast:31 into rows 2 and 3 */
+#else
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t v = __shfl_up(x, o);
+        if (lane >= o) x += v;
+    }
+#endif
+    return x;
+}
+
 /* Sort one chunk by child in LDS.  Every thread holds kKpt k-mers km[j] with
  * tag[j] = (child << 16) | rank_in_child (rank from an LDS atomic on hist); empty slots carry
- * child id kMaxFan (trash bin).  On return L.sorted holds the chunk grouped by child and L.dl /
- * L.total say where every element goes; the copy-out (copy_piece) is left to the caller, which
+ * child id kMaxFan (trash bin), counted in L.hist[cur].  On return L.sorted holds the chunk grouped by child and L.dl
+ * says where every element goes; the copy-out (copy_piece) is left to the caller, which
  * interleaves it with the NEXT chunk's compute so that the stores (HBM-bound, ~2 ms per 10 GB)
  * drain behind VALU work instead of stalling every wave at once. */
 /* (diagnostic build, -DQM2_STAMPS -DQM2_STAMPS_SORT=1: the phases of sort_chunk inside split_text_kernel) */
@@ -213,7 +250,8 @@ __device__ __attribute__((noinline)) void copy_spills(const SplitLds &L, uint64_
 #define QM2_SORT_STAMP_ARGS
 #define QM2_SORT_STAMP(I) do { } while (0)
 #endif
-__device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKpt], const uint32_t (&tag)[kKpt],
+template <int SYNC>
+__device__ __forceinline__ void sort_chunk(SplitLds &L, uint32_t cur, const uint64_t (&km)[kKpt], const uint32_t (&tag)[kKpt],
                                            uint64_t child0, uint32_t fan, const SplitDst &d,
                                            unsigned long long &lost QM2_SORT_STAMP_ARGS)
 {
@@ -221,40 +259,33 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
     lds_barrier();                 /* hist complete; every wave is done reading the previous L.sorted / L.dl */
     QM2_SORT_STAMP(21);
     if (tid == 0) L.spill_n = 0;
-    /* exclusive scan of hist[0..fan): thread t takes children t, t + kSplitThreads, ... (kChildPerThread of them:
-     * consecutive lanes = consecutive children, so the reservations below are the contiguous, full-rate atomic shape) */
+    /* thread t takes children t, t + kSplitThreads, ... (kChildPerThread of them: consecutive lanes = consecutive
+     * children, so the reservations below are the contiguous, full-rate atomic shape) */
     constexpr int C = kChildPerThread;
-    constexpr int kScanWaves = (kMaxFan / C) / kWave;          /* waves that hold children */
-    uint32_t mine[C], incl[C];
+    uint32_t mine[C], g[C], off[C];
     const bool holder = tid < kMaxFan / C;
+    if constexpr (SYNC == 2)
+        for (int i = tid; i <= kMaxFan; i += kSplitThreads) L.hist[cur ^ 1u][i] = 0;  /* the next chunk's counts (last read in the scan before this one) */
+    /* exclusive scan of hist[0..fan) */
+    constexpr int kScanWaves = (kMaxFan / C) / kWave;          /* waves that hold children */
+    uint32_t incl[C];
 #pragma unroll
     for (int i = 0; i < C; i++) {
         const int child = tid + i * kSplitThreads;
-        mine[i] = holder && child < (int)fan ? L.hist[child] : 0;
-        incl[i] = mine[i];
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const uint32_t v = __shfl_up(incl[i], o);
-            if (lane >= o) incl[i] += v;
-        }
+        mine[i] = holder && child < (int)fan ? L.hist[cur][child] : 0;
+        incl[i] = wave_scan_incl(mine[i]);
         if (holder && lane == kWave - 1) L.wsum[i * kScanWaves + wave] = incl[i];
     }
     lds_barrier();
     QM2_SORT_STAMP(22);
-    uint32_t g[C], off[C];
     {
         /* sums of the waves before this one: every wave scans the (at most 16) wave totals itself */
         static_assert(kMaxFan / kWave <= kWave, "one lane per wave total");
-        uint32_t ws = lane < kMaxFan / kWave ? L.wsum[lane] : 0u;
-#pragma unroll
-        for (int o = 1; o < kMaxFan / kWave; o <<= 1) {
-            const uint32_t v = __shfl_up(ws, o);
-            if (lane >= o) ws += v;
-        }
+        const uint32_t ws = wave_scan_incl(lane < kMaxFan / kWave ? L.wsum[lane] : 0u);
 #pragma unroll
         for (int i = 0; i < C; i++) {
             const int widx = i * kScanWaves + wave;            /* position of this wave's total for its i-th children */
-            const uint32_t before = widx ? __shfl(ws, widx - 1) : 0u;
+            const uint32_t before = widx ? (uint32_t)__builtin_amdgcn_readlane((int)ws, __builtin_amdgcn_readfirstlane(widx - 1)) : 0u;   /* (uniform: no LDS round trip) */
             off[i] = before + incl[i] - mine[i];
             g[i] = 0;
             if (holder) {
@@ -265,8 +296,8 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, const uint64_t (&km)[kKp
                 if (mine[i]) g[i] = atomicAdd(&d.cursors[child0 + (uint64_t)child], mine[i]);
             }
         }
-        const uint32_t tot = __shfl(ws, kMaxFan / kWave - 1);
-        if (tid == 0) { L.total = tot; L.off[kMaxFan] = (uint16_t)tot; }
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)ws, kMaxFan / kWave - 1);
+        if (tid == 0) L.off[kMaxFan] = (uint16_t)tot;
     }
     lds_barrier();
     QM2_SORT_STAMP(23);
@@ -423,6 +454,12 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
 #ifdef QM2_STAMPS
     unsigned long long st_acc[28] = {0}, st_last = stamp_now();
 #endif
+    constexpr int SYNC = QM2_SORT_SYNC_TEXT;
+    uint32_t hb = 0;            /* which count array this chunk ranks into (SYNC = 2: they take turns, sort_chunk zeroes the other) */
+    if constexpr (SYNC == 2) {
+        for (int i = tid; i < 2 * (kMaxFan + 1); i += kSplitThreads) (&L.hist[0][0])[i] = 0;
+        lds_barrier();
+    }
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint64_t tile = chunk * kSplitWaves + wave;
         const uint4 cur = bytes;
@@ -431,8 +468,10 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
         n_bases += W.n_bases;
         n_kmers += __builtin_popcount(W.emit);
         QM2_STAMP(16);
-        for (int i = tid; i <= kMaxFan; i += kSplitThreads) L.hist[i] = 0;
-        lds_barrier();
+        if constexpr (SYNC == 0) {
+            for (int i = tid; i <= kMaxFan; i += kSplitThreads) L.hist[0][i] = 0;
+            lds_barrier();
+        }
         QM2_STAMP(17);
         uint64_t km[kKpt];
         uint32_t tag[kKpt];
@@ -448,7 +487,7 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
             km[J] = kmer_at<K30, J>(W, k);                                         \
             /* (a select without the branch around the hash was measured: no difference) */ \
             const uint32_t b = (W.emit & (0x8000u >> J)) ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
-            tag[J] = (b << 16) | atomicAdd(&L.hist[b], 1u);      /* (a count: < 2^15) */ \
+            tag[J] = (b << 16) | atomicAdd(&L.hist[hb][b], 1u);      /* (a count: < 2^15) */ \
             if (pend) copy_finish<J, SEG, FIN>(out, oc, oh, dlw, d, child0);       \
             out = out_next;                                                        \
         }
@@ -457,11 +496,12 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_text_
 #undef QM2_T
         QM2_STAMP(18);
 #ifdef QM2_STAMPS
-        sort_chunk(L, km, tag, child0, fan, d, lost, st_acc, st_last, QM2_STAMPS_SORT == 1);
+        sort_chunk<SYNC>(L, hb, km, tag, child0, fan, d, lost, st_acc, st_last, QM2_STAMPS_SORT == 1);
 #else
-        sort_chunk(L, km, tag, child0, fan, d, lost);
+        sort_chunk<SYNC>(L, hb, km, tag, child0, fan, d, lost);
 #endif
         QM2_STAMP(19);
+        hb ^= (uint32_t)(SYNC == 2);
         pend = true;
     }
     if (pend) copy_all<SEG, FIN>(L, d, child0, shift, bits);
@@ -537,9 +577,17 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
         }
     };
     fetch((uint64_t)bx * kSplitSlots);
-    for (uint64_t first = (uint64_t)bx * kSplitSlots; first < n; first += (uint64_t)wgs_per_parent * kSplitSlots) {
-        for (int i = tid; i <= kMaxFan; i += kSplitThreads) L.hist[i] = 0;
+    constexpr int SYNC = QM2_SORT_SYNC_KMER;
+    uint32_t hb = 0;
+    if constexpr (SYNC == 2) {
+        for (int i = tid; i < 2 * (kMaxFan + 1); i += kSplitThreads) (&L.hist[0][0])[i] = 0;
         lds_barrier();
+    }
+    for (uint64_t first = (uint64_t)bx * kSplitSlots; first < n; first += (uint64_t)wgs_per_parent * kSplitSlots) {
+        if constexpr (SYNC == 0) {
+            for (int i = tid; i <= kMaxFan; i += kSplitThreads) L.hist[0][i] = 0;
+            lds_barrier();
+        }
         uint64_t km[kKpt];
         uint32_t tag[kKpt];
 #pragma unroll
@@ -556,7 +604,7 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
             uint32_t oc = 0, oh = 0;                                               \
             const uint64_t dlw = pend ? copy_lookup(L, out, shift, bits, oc, oh) : 0; \
             const uint32_t b = km[J] != kPad ? child_of(km[J], shift, bits) : (uint32_t)kMaxFan; \
-            tag[J] = (b << 16) | atomicAdd(&L.hist[b], 1u);      /* (a count: < 2^15) */ \
+            tag[J] = (b << 16) | atomicAdd(&L.hist[hb][b], 1u);      /* (a count: < 2^15) */ \
             if (pend) copy_finish<J, DST_SEG, FIN>(out, oc, oh, dlw, d, child0);   \
             out = out_next;                                                        \
         }
@@ -564,10 +612,11 @@ __global__ __launch_bounds__(kSplitThreads) QM2_SPLIT_OCCUPANCY void split_kmer_
         QM2_K(8) QM2_K(9) QM2_K(10) QM2_K(11) QM2_K(12) QM2_K(13) QM2_K(14) QM2_K(15)
 #undef QM2_K
 #ifdef QM2_STAMPS
-        { unsigned long long st_none[1], st_t = 0; sort_chunk(L, km, tag, child0, fan, d, lost, st_none, st_t, false); }
+        { unsigned long long st_none[1], st_t = 0; sort_chunk<SYNC>(L, hb, km, tag, child0, fan, d, lost, st_none, st_t, false); }
 #else
-        sort_chunk(L, km, tag, child0, fan, d, lost);
+        sort_chunk<SYNC>(L, hb, km, tag, child0, fan, d, lost);
 #endif
+        hb ^= (uint32_t)(SYNC == 2);
         pend = true;
     }
     if (pend) copy_all<DST_SEG, FIN>(L, d, child0, shift, bits);
