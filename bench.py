@@ -1050,6 +1050,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_legs(args, wl, pyqm2, torch, keys, batches[0][0], batches[0][1], H, k, local, n_unique)
 
+    # what a rank holds of HOST memory at its peak (the text buffers of the host-fed regions, the pinned staging): an N-rank run takes N of these
+    import resource
+    rss_gib = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2.0 ** 20
+    if use_dist:
+        tr = torch.tensor([rss_gib], dtype=torch.float64, device=dev)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        rss_gib = float(tr.item())
+
     if rank == 0:
         out = {
             "metric": "input bases/sec counted vs hg38 k=30 dict",
@@ -1074,7 +1082,7 @@ def main():
                        "hit_fraction": round(d["n_hits"] / max(1, d["n_kmers"]), 4),
                        "parallelism": "replicas x%d (dictionary replicated, reads partitioned, one RCCL reduce per job)" % world
                        if world > 1 else "1 GPU", "inputs": "resident in HBM (value); host-fed rates under `streamed`",
-                       "setup_s": round(t_setup, 1),
+                       "setup_s": round(t_setup, 1), "host_peak_rss_gib_per_rank": round(rss_gib, 1),
                        "final_reduce_ms": round(reduce_ms, 2) if reduce_ms is not None else None,
                        # the same steps with the job's per-job costs (the fold of the 2-byte interiors + the one exchange) charged to them in full (a 30x hg38 job is 10 such steps
                        # per GPU at N = 1 and fewer at N > 1: the exchange is per job, `value` is per step)
