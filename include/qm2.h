@@ -440,6 +440,8 @@ typedef struct {
 } qm2_packed;
 typedef struct {
     uint32_t fastq, skip, desync;
+    uint32_t lines;                  /* out: grows by the number of lines of the text (mod 2^32) — whatever `skip` was on entry, so a
+                                        reader that packs a block under a GUESSED state still learns the state of the block behind it */
 } qm2_line_state;
 size_t qm2_packed_bound(size_t n_text);
 int qm2_pack_lines(const char *lines, size_t n, void *dst, size_t dst_bytes, uint64_t *wraps, size_t wraps_cap,

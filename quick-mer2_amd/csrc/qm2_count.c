@@ -457,13 +457,14 @@ int qm2_main_count(int argc, char **argv)
      * -> 19.0 / 22.9 / 19.3 / 20.9 G bases/s; chr22 scale 20.4 / 23.5 / 21.6); before that it was 12.6 / 20.8 / 19.2 at 12 / 16 / 24 */
     const long cores = sysconf(_SC_NPROCESSORS_ONLN);
     /* (round 5: with the packing on the reader threads the link is no longer the bound, the threads are — hg38 scale, a 16-CPU share:
-     *  -t 12 / 16 -> 32.0 / 39.3 G bases/s of FASTQ, profiles/r05_c3/cli_end_to_end_100M_reads.txt) */
+     *  -t 12 / 16 -> 41 / 50 G bases/s of FASTQ, profiles/r05_c3/cli_end_to_end_100M_reads.txt) */
     int n_strip = getopt_seen_t ? (int)thread_count : (cores >= 32 ? 16 : cores >= 24 ? 12 : cores >= 16 ? 8 : 4);
     if (n_strip > 32) n_strip = 32;
 
     const int timing = getenv("QM2_TIMING") != NULL;   /* extra phase lines; off by default so that
                                                           stdout stays the reference's */
     /* the reader threads, the pinned buffers they fill and the .qm's way to the device on the socket the (first) GPU hangs off */
+    qm2_reader_note_affinity();
     if (n_dev <= 1) (void)qm2_bind_near_device(n_dev == 1 ? devices[0] : -1, NULL);      /* (several GPUs: they may sit on both sockets) */
     struct timespec ta, tb;
     qm2_dict_file d;

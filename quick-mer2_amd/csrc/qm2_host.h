@@ -69,6 +69,10 @@ typedef struct {
  * such a line does to the lines behind it cannot be followed): nothing is printed, the caller starts
  * over — from zeroed counters — without commit_packed. */
 int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads);
+/* Call BEFORE narrowing the process's CPU affinity (qm2_bind_near_device): remembers the CPUs the process may use, so that
+ * the block reader can put its workers on the NUMA node a regular file's cached pages lie on (qm2_reader.c, file_pages_cpus).
+ * Never called: the workers stay where the process is. */
+void qm2_reader_note_affinity(void);
 /* bytes of text per block (= per acquired buffer) when a regular file is read block-wise */
 size_t qm2_reader_block_bytes(void);
 

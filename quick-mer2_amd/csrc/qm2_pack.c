@@ -208,7 +208,7 @@ VBMI2_T static inline __attribute__((always_inline)) long vb_flush(uint8_t *buf,
 
 VBMI2_T static int pack_reads_vbmi2(const uint8_t *text, size_t n, qm2_line_state *st, pack_sink *s)
 {
-    uint32_t skip = st->skip, desync = st->desync;
+    uint32_t skip = st->skip, desync = st->desync, lines = 0;
     const uint32_t fastq = st->fastq;
     int at_line_start = 1, take = 0;
     size_t line_start = 0;
@@ -244,6 +244,7 @@ VBMI2_T static int pack_reads_vbmi2(const uint8_t *text, size_t n, qm2_line_stat
                 if (line_len >= 65536 && sink_wraps(s, text + line_start, line_len, line_pos0)) { rc = 2; break; }
             }
             const unsigned n_starts = (unsigned)__builtin_popcountll(starts);
+            lines += n_starts;
             if (fastq) skip = (skip + 4u - (n_starts & 3u)) & 3u;
             const int ends_with_nl = (int)((nl >> (cnt - 1)) & 1), last_kept = (int)((sel >> (cnt - 1)) & 1);
             if (!ends_with_nl && last_kept && kept && (!nl || (63 - __builtin_clzll(kept)) > (63 - __builtin_clzll(nl)))) {
@@ -260,6 +261,7 @@ VBMI2_T static int pack_reads_vbmi2(const uint8_t *text, size_t n, qm2_line_stat
             while (pos < cnt) {
                 if (at_line_start) {
                     at_line_start = 0;
+                    lines++;
                     if (skip) { skip--; take = 0; }
                     else if ((gt >> pos) & 1) { desync = 1; take = 0; }
                     else {
@@ -314,6 +316,7 @@ VBMI2_T static int pack_reads_vbmi2(const uint8_t *text, size_t n, qm2_line_stat
         s->n_pos = 64 * (uint64_t)n_blocks;
         st->skip = skip;
         st->desync = desync;
+        st->lines += lines;
     }
     free(buf);
     return rc;

@@ -83,7 +83,7 @@ QM2_TARGET static size_t QM2_FN(pack_lines)(const uint8_t *text, size_t n, uint6
  * group at a time.  Returns 0, or 2 when the output or the wrap list does not hold it. */
 QM2_TARGET static int QM2_FN(pack_reads)(const uint8_t *text, size_t n, qm2_line_state *st, pack_sink *s)
 {
-    uint32_t skip = st->skip, desync = st->desync;
+    uint32_t skip = st->skip, desync = st->desync, lines = 0;
     const uint32_t fastq = st->fastq;
     int at_line_start = 1, take = 0;
     size_t line_start = 0;                          /* of the line being taken: where it starts in the text ... */
@@ -139,6 +139,7 @@ QM2_TARGET static int QM2_FN(pack_reads)(const uint8_t *text, size_t n, qm2_line
                     a.n_newlines += (uint64_t)__builtin_popcountll(sel & nl);
                 }
                 const unsigned n_starts = (unsigned)__builtin_popcountll(starts);
+                lines += n_starts;
                 if (fastq) skip = (skip + 4u - (n_starts & 3u)) & 3u;                 /* one step of :451-455 per line start */
                 const int ends_with_nl = (int)((nl >> (cnt - 1)) & 1);
                 const int last_kept = (int)((sel >> (cnt - 1)) & 1);
@@ -158,6 +159,7 @@ QM2_TARGET static int QM2_FN(pack_reads)(const uint8_t *text, size_t n, qm2_line
         while (pos < cnt) {
             if (at_line_start) {
                 at_line_start = 0;
+                lines++;
                 const uint8_t first = text[g + pos];
                 if (skip) { skip--; take = 0; }                                       /* :452-454 */
                 else if (first == '>') { if (fastq) desync = 1; take = 0; }           /* :398 (before :451: no discards) */
@@ -202,6 +204,7 @@ QM2_TARGET static int QM2_FN(pack_reads)(const uint8_t *text, size_t n, qm2_line
     s->n_pos = a.n_pos;
     st->skip = skip;
     st->desync = desync;
+    st->lines += lines;
     return 0;
 }
 

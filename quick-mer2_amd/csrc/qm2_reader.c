@@ -33,7 +33,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -129,6 +131,7 @@ typedef struct {
     int desync;     /* FASTQ: a would-be sequence line started with '>' and was skipped WITHOUT the
                        three discards (:398 comes before :451): from here on the state is no longer
                        a function of the line count, which the parallel path relies on */
+    unsigned lines; /* lines seen (pack_whole_lines*, strip_range): whatever the state on entry */
 } line_state;
 
 static int take_line(line_state *s, out_state *o, const char *line, size_t body)
@@ -176,20 +179,22 @@ static int buf_submit(void *u, const char *p, size_t n) { (void)u; (void)p; (voi
 /* the line discipline and the packing in one pass over whole lines (qm2_pack.c); 0 = packed, 1 = error, 2 = take the ASCII way */
 static int pack_whole_lines(const char *p, size_t n, line_state *st, char *obuf, size_t ocap, qm2_packed *packed, uint64_t *wraps)
 {
-    qm2_line_state ps = {(uint32_t)st->fastq, (uint32_t)st->skip, 0};
+    qm2_line_state ps = {(uint32_t)st->fastq, (uint32_t)st->skip, 0, 0};
     const int rc = qm2_pack_reads(p, n, &ps, obuf, ocap, wraps, QM2_WRAPS_CAP, packed);
     if (rc) return rc;
     st->skip = (int)ps.skip;
+    st->lines += ps.lines;
     if (ps.desync) st->desync = 1;
     return 0;
 }
 
 static int pack_whole_lines_cap(const char *p, size_t n, line_state *st, char *obuf, size_t ocap, qm2_packed *packed, uint64_t *wraps, size_t wraps_cap)
 {
-    qm2_line_state ps = {(uint32_t)st->fastq, (uint32_t)st->skip, 0};
+    qm2_line_state ps = {(uint32_t)st->fastq, (uint32_t)st->skip, 0, 0};
     const int rc = qm2_pack_reads(p, n, &ps, obuf, ocap, wraps, wraps_cap, packed);
     if (rc) return rc;
     st->skip = (int)ps.skip;
+    st->lines += ps.lines;
     if (ps.desync) st->desync = 1;
     return 0;
 }
@@ -386,6 +391,7 @@ static int strip_range(const char *p, size_t n, line_state *st, out_state *os)
         const char *nl = memchr(p + at, '\n', n - at);
         const size_t body = nl ? (size_t)(nl - (p + at)) : n - at;
         if (take_line(st, os, p + at, body)) return 1;
+        st->lines++;
         at += body + 1;
     }
     return 0;
@@ -393,7 +399,7 @@ static int strip_range(const char *p, size_t n, line_state *st, out_state *os)
 
 static line_state pf_state(const pf_shared *sh, size_t before)
 {
-    line_state st = {0, sh->fastq, sh->fastq ? (int)((4 - (before & 3)) & 3) : 0, 1, 0};
+    line_state st = {0, sh->fastq, sh->fastq ? (int)((4 - (before & 3)) & 3) : 0, 1, 0, 0};
     return st;
 }
 
@@ -622,6 +628,61 @@ static int stream_blocks(int fd, size_t size, const qm2_lines_out *out, int n_th
  *     been committed by then, so the whole input is given up: return 3, and the caller starts over from zeroed counters
  *     without commit_packed (the serial-exact path above).  A block that does not pack (more run-counter wraps than a
  *     piece's list holds) goes through out->submit as ASCII lines. */
+/* ---- where the file's cached pages lie ------------------------------------------------------------------------------ *
+ * pread copies the text out of the page cache; when those pages sit on the other socket every byte crosses the
+ * socket-to-socket links first (hg38 scale, a 30.7 GB FASTQ in /dev/shm, 16 workers: 93 GB/s = 38.7 G bases/s with the pages on
+ * the other node, 48.5 with them on the workers' node; EXPERIMENTS.md, round 5).  The packed output is a fifth of the text, so
+ * the workers go where the text is: 64 pages spread over the file are mapped (MAP_POPULATE: never touched from user space, so
+ * a file that shrinks under us cannot raise SIGBUS) and move_pages(2) — asked, not told — says which node each lies on.  A
+ * clear majority (3/4) on one node whose CPUs the process may use binds the workers there; anything else changes nothing. */
+static cpu_set_t g_cpus_before;            /* the process's affinity before anybody narrowed it (qm2_reader_note_affinity) */
+static int       g_cpus_before_set;
+
+void qm2_reader_note_affinity(void)
+{
+    CPU_ZERO(&g_cpus_before);
+    g_cpus_before_set = sched_getaffinity(0, sizeof g_cpus_before, &g_cpus_before) == 0;
+}
+
+static int file_pages_cpus(int fd, size_t size, cpu_set_t *cpus, int *node_out, int *votes_out)
+{
+    enum { kSamples = 64, kMaxNodes = 64 };
+    if (!g_cpus_before_set || getenv("QM2_NO_BIND")) return 0;
+    const long ps = sysconf(_SC_PAGESIZE);
+    if (ps <= 0 || size < (size_t)ps * kSamples * 4) return 0;            /* (small files: not worth a thought) */
+    int votes[kMaxNodes] = {0}, seen = 0;
+    for (int i = 0; i < kSamples; i++) {
+        const off_t off = (off_t)((size / kSamples * (size_t)i) & ~((size_t)ps - 1));
+        void *m = mmap(NULL, (size_t)ps, PROT_READ, MAP_SHARED | MAP_POPULATE, fd, off);
+        if (m == MAP_FAILED) return 0;
+        int status = -1;
+        void *pages[1] = {m};
+        if (syscall(SYS_move_pages, 0, 1UL, pages, NULL, &status, 0) == 0 && status >= 0 && status < kMaxNodes) { votes[status]++; seen++; }
+        munmap(m, (size_t)ps);
+    }
+    int best = -1;
+    for (int n = 0; n < kMaxNodes; n++) if (best < 0 || votes[n] > votes[best]) best = n;
+    if (best < 0 || seen < kSamples / 2 || 4 * votes[best] < 3 * seen) return 0;
+    char path[128], list[4096] = "";
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", best);
+    FILE *f = fopen(path, "r");
+    if (!f) return 0;
+    if (!fgets(list, sizeof list, f)) list[0] = 0;
+    fclose(f);
+    CPU_ZERO(cpus);
+    char *save = NULL;
+    for (char *tok = strtok_r(list, ",\n", &save); tok; tok = strtok_r(NULL, ",\n", &save)) {
+        int a = 0, b = 0;
+        const int got = sscanf(tok, "%d-%d", &a, &b);
+        if (got == 1) b = a;
+        if (got < 1) continue;
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &g_cpus_before)) CPU_SET(c, cpus);
+    }
+    if (CPU_COUNT(cpus) == 0) return 0;
+    *node_out = best; *votes_out = votes[best];
+    return 1;
+}
+
 typedef struct pk_buf {
     char       *buf;                       /* a staging buffer from out->acquire; NULL: `ascii` is malloc'ed lines for out->submit */
     size_t      cap;
@@ -639,9 +700,30 @@ typedef struct {
     pthread_cond_t   cv_free, cv_main;
     pk_buf          *free_q, *full_q, *full_tail;
     int              workers_active, failed, desync, closing;
+    /* the line count of every block (mod 4), published by whoever packed it; sh.lines_before / sh.known are the prefix sums,
+     * advanced by whoever comes by (pk_advance) */
+    uint8_t         *cnt;
+    atomic_int      *have;
+    size_t           frontier;             /* sh.known[frontier] is set; owned by the holder of adv_busy */
+    atomic_flag      adv_busy;
+    int              near_file;            /* the workers run on the CPUs of the node the file's cached pages lie on */
+    cpu_set_t        near_cpus;
 } pk_shared;
 
-typedef struct { pk_shared *ps; pf_worker w; double t_read, t_count, t_wait, t_pack; unsigned long repacked; } pk_worker;
+/* a piece in the buffer in hand that was packed under a GUESSED line state which the blocks before have not confirmed yet */
+typedef struct {
+    size_t   block;
+    int      guess, desync;
+    uint64_t first_blk, n_blk, n_newlines; /* where the piece lies in the buffer, and its share of the buffer's n_newlines */
+    pk_buf  *ascii;                        /* or: the block as ASCII lines (it did not pack), not queued yet */
+} pk_pend;
+
+typedef struct {
+    pk_shared *ps; pf_worker w; double t_read, t_count, t_wait, t_pack, t_buf; unsigned long repacked;
+    int        index, n_workers, first_buffer;
+    pk_pend   *pend; int n_pend, cap_pend;
+    size_t    *redo; int n_redo, cap_redo;
+} pk_worker;
 
 static pk_buf *pk_get_free(pk_shared *ps)
 {
@@ -722,72 +804,191 @@ static int pk_pack_block(pk_shared *ps, pf_worker *w, pk_buf *cur, line_state *s
     return 0;
 }
 
+/* the prefix sums of the published line counts, as far as they go; whoever finds the flag free does it */
+static void pk_advance(pk_shared *ps)
+{
+    pf_shared *sh = &ps->sh;
+    if (atomic_flag_test_and_set_explicit(&ps->adv_busy, memory_order_acquire)) return;
+    size_t f = ps->frontier;
+    while (f < sh->n_blocks && atomic_load_explicit(&ps->have[f], memory_order_acquire)) {
+        sh->lines_before[f + 1] = (sh->lines_before[f] + ps->cnt[f]) & 3;
+        atomic_store_explicit(&sh->known[f + 1], 1, memory_order_release);
+        f++;
+    }
+    ps->frontier = f;
+    atomic_flag_clear_explicit(&ps->adv_busy, memory_order_release);
+}
+
+static void pk_flag_desync(pk_shared *ps)
+{
+    pthread_mutex_lock(&ps->mu); ps->desync = 1; pthread_mutex_unlock(&ps->mu);
+    atomic_store(&ps->sh.stop, 1);
+}
+
+/* Settle the pieces of the buffer in hand whose blocks' line state is known by now (wait: all of them — the buffer is about
+ * to travel).  A piece packed under the right guess stands; one packed under a wrong guess is voided where it lies — its
+ * blocks become 64 resets each, which emit nothing and count as filler — and its block goes on the redo list. */
+static void pk_settle(pk_worker *kw, pk_buf *cur, int wait)
+{
+    pk_shared *ps = kw->ps;
+    pf_shared *sh = &ps->sh;
+    for (int i = 0; i < kw->n_pend;) {
+        pk_pend *e = &kw->pend[i];
+        if (!atomic_load_explicit(&sh->known[e->block], memory_order_acquire)) {
+            pk_advance(ps);
+            if (!atomic_load_explicit(&sh->known[e->block], memory_order_acquire)) {
+                if (!wait) { i++; continue; }
+                const double t0 = pf_now();
+                while (!atomic_load_explicit(&sh->known[e->block], memory_order_acquire) && !atomic_load(&sh->stop)) { sched_yield(); pk_advance(ps); }
+                kw->t_wait += pf_now() - t0;
+            }
+        }
+        if (atomic_load(&sh->stop) && !atomic_load_explicit(&sh->known[e->block], memory_order_acquire)) {      /* given up: nothing of this run is kept */
+            if (e->ascii) { free(e->ascii->ascii); free(e->ascii); }
+            *e = kw->pend[--kw->n_pend];
+            continue;
+        }
+        const int correct = sh->fastq ? (int)((4 - (sh->lines_before[e->block] & 3)) & 3) : 0;
+        if (e->guess == correct) {
+            if (e->ascii) pk_put_full(ps, e->ascii);
+            if (e->desync) pk_flag_desync(ps);           /* the blocks behind this one were given a state that is not theirs */
+        } else {
+            if (e->ascii) { free(e->ascii->ascii); free(e->ascii); }
+            else if (e->n_blk) {
+                uint64_t *blk = (uint64_t *)(void *)cur->buf + 3 * e->first_blk;
+                for (uint64_t j = 0; j < e->n_blk; j++) { blk[3 * j] = 0; blk[3 * j + 1] = 0; blk[3 * j + 2] = ~0ull; }
+                cur->p.n_newlines += 64 * e->n_blk - e->n_newlines;
+                /* (its run-counter wraps stay listed: positions at which nothing is emitted any more) */
+            }
+            if (kw->n_redo < kw->cap_redo) kw->redo[kw->n_redo++] = e->block;
+            else { pthread_mutex_lock(&ps->mu); ps->failed = 1; pthread_mutex_unlock(&ps->mu); atomic_store(&sh->stop, 1); }
+            kw->repacked++;
+        }
+        *e = kw->pend[--kw->n_pend];
+    }
+}
+
+/* the buffer in hand is full (or the file is at its end): settle what it holds and send it to the calling thread */
+static void pk_send(pk_worker *kw, pk_buf **cur)
+{
+    if (!*cur) return;
+    pk_settle(kw, *cur, 1);
+    pk_put_full(kw->ps, *cur);
+    *cur = NULL;
+    kw->first_buffer = 0;
+}
+
+/* One block: read it, pack the lines that start in it behind the pieces of the buffer in hand.  exact = 0: under a guess of
+ * its line state (FASTQ), its line count is published at once and the piece waits for the verdict (pk_settle); exact = 1
+ * (a block whose guess was wrong, or FASTA): under the state its line count before gives.  0, or 1 = stop (error, shut down). */
+static int pk_do_block(pk_worker *kw, pk_buf **curp, size_t b, int exact)
+{
+    pk_shared *ps = kw->ps;
+    pf_shared *sh = &ps->sh;
+    pf_worker *w = &kw->w;
+    w->block = b;
+    const double t0 = pf_now();
+    int rc = atomic_load(&sh->stop) ? 0 : pf_load(w);
+    if (rc || atomic_load(&sh->stop)) w->lo = w->hi = 0;
+    const double t1 = pf_now();
+    kw->t_read += t1 - t0;
+    const size_t n = w->hi - w->lo;
+    unsigned lines = 0;
+    if (!rc && n) {
+        pk_buf *cur = *curp;
+        if (cur && cur->p.n_blocks &&                        /* (normally settled behind the block before: pk_room) */
+            (cur->cap - (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES < qm2_packed_bound(n) || cur->p.n_wraps + 8 > QM2_WRAPS_CAP)) pk_send(kw, curp);
+        if (!*curp) {
+            const double tb = pf_now();
+            *curp = pk_get_free(ps);
+            kw->t_buf += pf_now() - tb;
+            if (!*curp) return 1;
+        }
+        cur = *curp;
+        const double t2 = pf_now();
+        line_state st = pf_state(sh, exact ? sh->lines_before[b] : 0);
+        const int guess = exact || !sh->fastq ? st.skip : guess_fastq_skip(w->raw + w->lo, n);
+        st.skip = guess;
+        qm2_packed piece;
+        pk_buf *ascii = NULL;
+        if (pk_pack_block(ps, w, cur, &st, &piece, &ascii)) rc = 1;
+        kw->t_pack += pf_now() - t2;
+        if (!rc) {
+            lines = st.lines;
+            const uint64_t first = cur->p.n_blocks;
+            if (!ascii) {
+                uint64_t *wr = cur->wraps + cur->p.n_wraps;
+                for (uint64_t i = 0; i < piece.n_wraps; i++) wr[i] += 64 * first;
+                cur->p.n_blocks += piece.n_blocks; cur->p.n_newlines += piece.n_newlines; cur->p.n_wraps += piece.n_wraps;
+            }
+            if (exact || !sh->fastq) {                      /* nothing to confirm */
+                if (ascii) pk_put_full(ps, ascii);
+                if (st.desync) pk_flag_desync(ps);
+            } else {
+                if (kw->n_pend == kw->cap_pend) {
+                    pk_pend *g = realloc(kw->pend, (size_t)(kw->cap_pend ? 2 * kw->cap_pend : 64) * sizeof *g);
+                    if (!g) { if (ascii) { free(ascii->ascii); free(ascii); } rc = 1; }
+                    else { kw->pend = g; kw->cap_pend = kw->cap_pend ? 2 * kw->cap_pend : 64; }
+                }
+                if (!rc) {
+                    const pk_pend e = {b, guess, st.desync, first, ascii ? 0 : piece.n_blocks, ascii ? 0 : piece.n_newlines, ascii};
+                    kw->pend[kw->n_pend++] = e;
+                }
+            }
+        }
+    }
+    if (!exact) {                                        /* the block's line count, whatever became of it: the blocks behind wait for nothing else */
+        ps->cnt[b] = (uint8_t)(lines & 3u);
+        atomic_store_explicit(&ps->have[b], 1, memory_order_release);
+        pk_advance(ps);
+    }
+    /* Will the next block fit?  If not the buffer travels NOW, with this block's count already out: settling it may wait for
+     * blocks before, and whoever waits for this one should not wait for those as well.  (A worker's FIRST buffer counts as
+     * full at (index + 1) / n_workers of its size: all buffers fill at the same pace, and handing them over at the same moment
+     * made the workers queue for the one spare buffer — 12 % of their time.) */
+    if (!rc && *curp && (*curp)->p.n_blocks) {
+        const pk_buf *cur = *curp;
+        size_t cap = cur->cap;
+        if (kw->first_buffer) cap = cap / (size_t)kw->n_workers * (size_t)(kw->index + 1);
+        const size_t used = (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES, next = qm2_packed_bound(sh->block + ((size_t)1 << 16));
+        if (cap < used || cap - used < next || cur->p.n_wraps + 8 > QM2_WRAPS_CAP) pk_send(kw, curp);
+    }
+    return rc;
+}
+
+/* A worker: blocks from the shared counter, one pass over each while it is hot in the cache.  FASTQ: packed under a GUESS of
+ * the block's line state (guess_fastq_skip); the pass also yields the block's line count, which is published at once — it
+ * does not depend on the guess — so that nobody ever waits for a block that is still being packed, only (when a buffer is
+ * about to travel) for blocks that have not been READ yet.  The verdict on a guess comes from the line counts before it
+ * (:451-455); a wrong one (a handful of blocks per file at most: quality lines that look like headers) voids the piece and
+ * packs the block again under the right state.  FASTA keeps no state. */
 static void *pk_main(void *arg)
 {
     pk_worker *kw = arg;
     pk_shared *ps = kw->ps;
     pf_shared *sh = &ps->sh;
-    pf_worker *w = &kw->w;
     pk_buf *cur = NULL;
     int failed = 0;
+    kw->first_buffer = 1;
+    if (ps->near_file) (void)pthread_setaffinity_np(pthread_self(), sizeof ps->near_cpus, &ps->near_cpus);      /* (a hint: failure changes nothing) */
     for (;;) {
+        while (kw->n_redo && !failed && !atomic_load(&sh->stop))
+            if (pk_do_block(kw, &cur, kw->redo[--kw->n_redo], 1)) failed = 1;
+        if (failed || atomic_load(&sh->stop)) break;
         const size_t b = atomic_fetch_add(&ps->next_block, 1);
-        if (b >= sh->n_blocks) break;
-        w->block = b;
-        const double t0 = pf_now();
-        int rc = atomic_load(&sh->stop) ? 0 : pf_load(w);
-        if (rc || atomic_load(&sh->stop)) w->lo = w->hi = 0;
-        const double t1 = pf_now();
-        const size_t n = w->hi - w->lo;
-        /* FASTQ: ONE pass over the block while it is hot — packed under a GUESS of its line state, which also tells how many
-         * lines it holds mod 4 (every line start is one step of :451-455: lines = skip_in - skip_out mod 4) — and only then
-         * the wait for the blocks before, whose line count decides.  A wrong guess (a handful of blocks per file at most:
-         * quality lines that look like headers) packs again.  FASTA keeps no state. */
-        line_state st = pf_state(sh, 0);
-        qm2_packed piece;
-        pk_buf *ascii = NULL;
-        int guess = 0, packed_once = 0;
-        memset(&piece, 0, sizeof piece);
-        if (!rc && n) {
-            if (cur && (cur->cap - (size_t)cur->p.n_blocks * QM2_PACKED_BLOCK_BYTES < qm2_packed_bound(n) || cur->p.n_wraps + 8 > QM2_WRAPS_CAP)) { pk_put_full(ps, cur); cur = NULL; }
-            if (!cur) { cur = pk_get_free(ps); if (!cur) break; }
-            guess = sh->fastq ? guess_fastq_skip(w->raw + w->lo, n) : 0;
-            st.skip = guess;
-            if (pk_pack_block(ps, w, cur, &st, &piece, &ascii)) { failed = 1; rc = 1; }
-            packed_once = 1;
-        }
-        const double t2 = pf_now();
-        while (!atomic_load_explicit(&sh->known[b], memory_order_acquire) && !atomic_load(&sh->stop)) sched_yield();
-        const size_t before = sh->lines_before[b];                  /* (mod 4 from here on: all the state there is) */
-        const double t3 = pf_now();
-        const int correct = sh->fastq ? (int)((4 - (before & 3)) & 3) : 0;
-        if (packed_once && !rc && sh->fastq && correct != guess && !atomic_load(&sh->stop)) {
-            if (ascii) { free(ascii->ascii); free(ascii); ascii = NULL; }
-            st = pf_state(sh, before);
-            if (pk_pack_block(ps, w, cur, &st, &piece, &ascii)) { failed = 1; rc = 1; }
-            kw->repacked++;
-        }
-        const size_t lines4 = sh->fastq && packed_once ? (size_t)((correct - st.skip) & 3) : 0;
-        sh->lines_before[b + 1] = (before + lines4) & 3;
-        atomic_store_explicit(&sh->known[b + 1], 1, memory_order_release);
-        kw->t_read += t1 - t0; kw->t_pack += (t2 - t1) + (pf_now() - t3); kw->t_wait += t3 - t2;
-        if (rc) { failed = 1; if (ascii) { free(ascii->ascii); free(ascii); } break; }
-        if (atomic_load(&sh->stop)) { if (ascii) { free(ascii->ascii); free(ascii); } break; }
-        if (!n) continue;
-        if (ascii) pk_put_full(ps, ascii);
-        else {
-            const uint64_t pos0 = 64 * cur->p.n_blocks;
-            uint64_t *wr = cur->wraps + cur->p.n_wraps;
-            for (uint64_t i = 0; i < piece.n_wraps; i++) wr[i] += pos0;
-            cur->p.n_blocks += piece.n_blocks; cur->p.n_newlines += piece.n_newlines; cur->p.n_wraps += piece.n_wraps;
-        }
-        if (st.desync) {                                 /* the blocks behind this one were given a state that is not theirs */
-            pthread_mutex_lock(&ps->mu); ps->desync = 1; pthread_mutex_unlock(&ps->mu);
-            atomic_store(&sh->stop, 1);
+        if (b >= sh->n_blocks) {                         /* the end: what is in hand is settled, which may bring redos */
+            if (cur) pk_settle(kw, cur, 1);
+            if (kw->n_redo) continue;
             break;
         }
+        if (pk_do_block(kw, &cur, b, 0)) { failed = 1; break; }
+        if (cur) pk_settle(kw, cur, 0);
     }
     if (failed) atomic_store(&sh->stop, 1);
+    /* (after a stop the blocks this worker drew but never packed stay unpublished: nobody waits once stop is set) */
+    if (cur) pk_settle(kw, cur, 1);
+    for (int i = 0; i < kw->n_pend; i++) if (kw->pend[i].ascii) { free(kw->pend[i].ascii->ascii); free(kw->pend[i].ascii); }
+    kw->n_pend = 0;
     pthread_mutex_lock(&ps->mu);
     if (failed) ps->failed = 1;
     if (cur) {                                           /* what is in hand goes back, full or not (an empty one is just returned) */
@@ -828,15 +1029,20 @@ static int stream_blocks_packed(int fd, size_t size, const qm2_lines_out *out, i
     sh->n_blocks = (size - sh->start + sh->block - 1) / sh->block;
     sh->lines_before = calloc(sh->n_blocks + 2, sizeof(size_t));
     sh->known = calloc(sh->n_blocks + 2, sizeof(atomic_int));
+    ps.cnt = calloc(sh->n_blocks + 2, 1);
+    ps.have = calloc(sh->n_blocks + 2, sizeof(atomic_int));
+    atomic_flag_clear(&ps.adv_busy);
     pk_worker *ws = calloc((size_t)n_threads, sizeof *ws);
     pthread_t *tids = calloc((size_t)n_threads, sizeof *tids);
     pk_buf *bufs = calloc((size_t)n_threads + 1, sizeof *bufs);
     int rc = 0;
-    if (!sh->lines_before || !sh->known || !ws || !tids || !bufs) { puts("Memory allocation failed"); rc = 1; }
+    if (!sh->lines_before || !sh->known || !ps.cnt || !ps.have || !ws || !tids || !bufs) { puts("Memory allocation failed"); rc = 1; }
     pthread_mutex_init(&ps.mu, NULL);
     pthread_cond_init(&ps.cv_free, NULL);
     pthread_cond_init(&ps.cv_main, NULL);
     int n_workers = 0, n_bufs = 0;
+    int near_node = -1, near_votes = 0;
+    if (!rc) ps.near_file = file_pages_cpus(fd, size, &ps.near_cpus, &near_node, &near_votes);
     if (!rc) {
         atomic_store(&sh->known[0], 1);
         /* the buffers the workers fill: as many as there are workers + 1 (what qm2_stream_reads promises to hold at a time) */
@@ -852,11 +1058,16 @@ static int stream_blocks_packed(int fd, size_t size, const qm2_lines_out *out, i
             ws[t].w.sh = sh;
             ws[t].w.raw_cap = sh->block + ((size_t)1 << 20);
             ws[t].w.raw = malloc(ws[t].w.raw_cap);
-            if (!ws[t].w.raw) break;
+            ws[t].index = t;
+            ws[t].n_workers = n_threads < 1 ? 1 : n_threads;
+            ws[t].cap_redo = 64;                             /* (more wrong guesses than this in one buffer: give up) */
+            ws[t].redo = malloc((size_t)ws[t].cap_redo * sizeof *ws[t].redo);
+            if (!ws[t].w.raw || !ws[t].redo) { free(ws[t].w.raw); free(ws[t].redo); ws[t].w.raw = NULL; ws[t].redo = NULL; break; }
             pthread_mutex_lock(&ps.mu); ps.workers_active++; pthread_mutex_unlock(&ps.mu);
             if (pthread_create(&tids[t], NULL, pk_main, &ws[t])) {
                 pthread_mutex_lock(&ps.mu); ps.workers_active--; pthread_mutex_unlock(&ps.mu);
                 free(ws[t].w.raw); ws[t].w.raw = NULL;
+                free(ws[t].redo); ws[t].redo = NULL;
                 break;
             }
             n_workers++;
@@ -864,14 +1075,19 @@ static int stream_blocks_packed(int fd, size_t size, const qm2_lines_out *out, i
         if (!n_workers && sh->n_blocks) { puts("Memory allocation failed"); rc = 1; }
     }
     /* the calling thread: commit what comes back full, lend the buffer out again */
+    double m_idle = 0, m_commit = 0, m_acquire = 0;
+    const double m_t0 = pf_now();
     while (!rc) {
+        const double mi = pf_now();
         pthread_mutex_lock(&ps.mu);
         while (!ps.full_q && ps.workers_active > 0) pthread_cond_wait(&ps.cv_main, &ps.mu);
         pk_buf *b = ps.full_q;
         if (b) { ps.full_q = b->next; if (!ps.full_q) ps.full_tail = NULL; }
         const int active = ps.workers_active;
         pthread_mutex_unlock(&ps.mu);
+        m_idle += pf_now() - mi;
         if (!b) { if (active == 0) break; continue; }
+        const double mc = pf_now();
         if (b->ascii) {                                      /* lines that did not pack */
             if (out->submit(out->user, b->ascii, b->ascii_len)) rc = 1;
             free(b->ascii);
@@ -880,11 +1096,15 @@ static int stream_blocks_packed(int fd, size_t size, const qm2_lines_out *out, i
         }
         if (b->p.n_blocks ? out->commit_packed(out->user, b->buf, &b->p, b->wraps) : out->commit(out->user, b->buf, 0)) { rc = 1; b->buf = NULL; break; }
         b->buf = NULL;
+        m_commit += pf_now() - mc;
         pthread_mutex_lock(&ps.mu);
         const int more = ps.workers_active > 0;
         pthread_mutex_unlock(&ps.mu);
         if (more) {
-            if (out->acquire(out->user, &b->buf, &b->cap)) { rc = 1; break; }
+            const double ma = pf_now();
+            const int arc = out->acquire(out->user, &b->buf, &b->cap);
+            m_acquire += pf_now() - ma;
+            if (arc) { rc = 1; break; }
             pthread_mutex_lock(&ps.mu);
             b->next = ps.free_q; ps.free_q = b;
             pthread_cond_signal(&ps.cv_free);
@@ -897,12 +1117,13 @@ static int stream_blocks_packed(int fd, size_t size, const qm2_lines_out *out, i
     ps.closing = 1;
     pthread_cond_broadcast(&ps.cv_free);
     pthread_mutex_unlock(&ps.mu);
-    double t_read = 0, t_wait = 0, t_pack = 0;
+    double t_read = 0, t_wait = 0, t_pack = 0, t_buf = 0;
     unsigned long repacked = 0;
+    const double m_loop = pf_now() - m_t0;
     for (int t = 0; t < n_workers; t++) {
         pthread_join(tids[t], NULL);
-        free(ws[t].w.raw);
-        t_read += ws[t].t_read; t_wait += ws[t].t_wait; t_pack += ws[t].t_pack; repacked += ws[t].repacked;
+        free(ws[t].w.raw); free(ws[t].redo); free(ws[t].pend);
+        t_read += ws[t].t_read; t_wait += ws[t].t_wait; t_pack += ws[t].t_pack; t_buf += ws[t].t_buf; repacked += ws[t].repacked;
     }
     for (pk_buf *b = ps.full_q; b;) {                        /* (after an error: pieces nobody committed) */
         pk_buf *nx = b->next;
@@ -910,16 +1131,19 @@ static int stream_blocks_packed(int fd, size_t size, const qm2_lines_out *out, i
         b = nx;
     }
     for (int i = 0; i < n_bufs; i++) if (bufs[i].buf) (void)out->commit(out->user, bufs[i].buf, 0);
+    if (getenv("QM2_READER_TIMING") && ps.near_file)
+        printf("QM2 reader: %d of 64 sampled pages of the file lie on NUMA node %d: the workers run on its %d CPUs\n", near_votes, near_node, CPU_COUNT(&ps.near_cpus));
     if (getenv("QM2_READER_TIMING"))
         printf("QM2 reader: %d workers, %zu blocks of %zu bytes, packed; seconds summed over the workers: pread %.3f, line discipline + packing (one pass, under a guessed line state) %.3f, "
-               "waiting for the line count of the blocks before %.3f; %lu blocks packed again (wrong guess)\n",
-               n_workers, sh->n_blocks, sh->block, t_read, t_pack, t_wait, repacked);
+               "waiting — only when a buffer is about to travel — for the line count of the blocks before %.3f, for a free staging buffer %.3f; %lu blocks packed again (wrong guess); the calling thread's %.3f s: "
+               "waiting for a full buffer %.3f, committing %.3f, acquiring the next %.3f\n",
+               n_workers, sh->n_blocks, sh->block, t_read, t_pack, t_wait, t_buf, repacked, m_loop, m_idle, m_commit, m_acquire);
     if (!rc && ps.failed) rc = 1;
     if (!rc && ps.desync) rc = 3;
     pthread_mutex_destroy(&ps.mu);
     pthread_cond_destroy(&ps.cv_free);
     pthread_cond_destroy(&ps.cv_main);
-    free(sh->lines_before); free(sh->known); free(ws); free(tids); free(bufs);
+    free(sh->lines_before); free(sh->known); free(ps.cnt); free(ps.have); free(ws); free(tids); free(bufs);
     return rc;
 }
 
@@ -963,7 +1187,7 @@ int qm2_stream_reads(const char *path, const qm2_lines_out *out, int n_threads)
         }
     }
 #endif
-    line_state ls = {1, 0, 0, lseek(ring.fd, 0, SEEK_CUR) != (off_t)-1, 0};
+    line_state ls = {1, 0, 0, lseek(ring.fd, 0, SEEK_CUR) != (off_t)-1, 0, 0};
     out_state os = {out, NULL, 0, 0};
     for (int i = 0; i < ring.n_slots; i++) {
         ring.blk[i] = malloc(QM2_RESERVE + QM2_BLOCK + 1);

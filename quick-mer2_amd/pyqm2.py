@@ -53,7 +53,7 @@ class Packed(C.Structure):
 
 
 class LineState(C.Structure):
-    _fields_ = [("fastq", C.c_uint32), ("skip", C.c_uint32), ("desync", C.c_uint32)]
+    _fields_ = [("fastq", C.c_uint32), ("skip", C.c_uint32), ("desync", C.c_uint32), ("lines", C.c_uint32)]
 
 
 class Range(C.Structure):

@@ -125,6 +125,7 @@ static int pk(void *u, char *b, const qm2_packed *p, const uint64_t *w) { (void)
 static int com_f(void *u, char *b, size_t n) { (void)u; if (n) { unsigned long long hdr[3] = {n, 0, 0}; fwrite(hdr, 8, 3, O); fwrite(b, 1, n, O); } free(b); return 0; }
 static int sub_f(void *u, const char *p, size_t n) { (void)u; unsigned long long hdr[3] = {n, 0, 0}; fwrite(hdr, 8, 3, O); fwrite(p, 1, n, O); return 0; }
 int main(int argc, char **argv) { O = fopen(argv[2], "wb"); CAP = (size_t)atol(argv[3]);
+  qm2_reader_note_affinity();   /* (as the CLI does: the block reader then looks where the file's cached pages lie) */
   const int packed = argc > 5 && argv[5][0] == 'p';
   qm2_lines_out out = {acq, packed ? com_f : com, packed ? sub_f : sub, NULL, argc > 5 && !packed ? raw : NULL, packed ? pk : NULL};
   int rc = qm2_stream_reads(argv[1], &out, atoi(argv[4])); fclose(O); return rc; }

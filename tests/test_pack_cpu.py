@@ -156,6 +156,7 @@ def check_reads(text: bytes, fastq, skip):
     assert np.array_equal(codes[:n][~eb], ec[~eb])
     assert p.n_newlines == lines.count(b"\n") + 64 * p.n_blocks - n
     assert (st.skip, bool(st.desync)) == (skip_after, desync)
+    assert st.lines == text.count(b"\n") + (1 if text and not text.endswith(b"\n") else 0)     # whatever the state on entry
     assert list(wraps) == model_wraps(lines)
     return lines
 

@@ -45,6 +45,7 @@ static int com_f(void *u, char *b, size_t n) { Sink *s = u; if (own(s, b)) retur
 static int sub_f(void *u, const char *p, size_t n) { Sink *s = u; unsigned hdr[3] = {0xFFFFFFFDu, (unsigned)n, 0}; fwrite(hdr, 4, 3, s->f); fwrite(p, 1, n, s->f); return 0; }
 int main(int argc, char **argv) {
   if (argc < 7) return 9;
+  qm2_reader_note_affinity();
   const int n = atoi(argv[2]), is_raw = strcmp(argv[5], "raw") == 0, is_packed = strcmp(argv[5], "packed") == 0; Sink S[8]; qm2_sink sinks[8]; char name[600];
   for (int i = 0; i < n; i++) { snprintf(name, sizeof name, "%s.%d", argv[4], i); S[i].id = i; S[i].lent = 0; S[i].f = fopen(name, "wb");
     sinks[i].acquire = acq; sinks[i].commit = is_packed ? com_f : com; sinks[i].submit = is_packed ? sub_f : sub; sinks[i].flush = flu; sinks[i].user = &S[i];

@@ -33,6 +33,21 @@ os.makedirs(work, exist_ok=True)
 os.makedirs(reads_dir, exist_ok=True)
 n, H, k = (3_100_000_000, 1 << 32, 30) if scale == "c3" else (50_818_468, 1 << 28, 30)
 import shutil
+# QM2_E2E_FILES_NEAR=1: this script (which WRITES the test files, i.e. decides on which NUMA node their page-cache pages lie) runs on the
+# CPUs of the GPU's NUMA node, where the CLI's reader threads run too (qm2_bind_near_device); 0 / unset: wherever the scheduler puts it
+# "far": on the CPUs of the OTHER node(s) — the case the reader's look at the file's pages (qm2_reader.c, file_pages_cpus) is for
+if os.environ.get("QM2_E2E_FILES_NEAR") == "1":
+    print("files written from the GPU's NUMA node: %d CPUs" % pyqm2.bind_near_device(0), flush=True)
+elif os.environ.get("QM2_E2E_FILES_NEAR") == "far":
+    all_cpus = os.sched_getaffinity(0)
+    pyqm2.bind_near_device(0)
+    far = all_cpus - os.sched_getaffinity(0)
+    if far:
+        os.sched_setaffinity(0, far)
+        print("files written from the node(s) the GPU does NOT hang off: %d CPUs" % len(far), flush=True)
+    else:
+        os.sched_setaffinity(0, all_cpus)
+        print("one NUMA node only: files written from wherever", flush=True)
 print("scratch free: %.0f GB in %s, %.0f GB in %s" % (shutil.disk_usage(work).free / 1e9, work,
                                                        shutil.disk_usage(reads_dir).free / 1e9, reads_dir), flush=True)
 genome = torch.empty(n, dtype=torch.uint8, device="cuda")

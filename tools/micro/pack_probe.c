@@ -38,7 +38,7 @@ static void *run(void *arg)
         if (j->kind == 3) memcpy(j->out, j->text + off, take);
         else if (j->kind == 0) j->rc |= qm2_pack_lines(j->text + off, take, j->out, j->out_cap, wraps, 64, &p);
         else {
-            qm2_line_state st = {j->kind == 1, j->kind == 1, 0};       /* a piece starts at a header: FASTQ drops one line first */
+            qm2_line_state st = {j->kind == 1, j->kind == 1, 0, 0};      /* a piece starts at a header: FASTQ drops one line first */
             j->rc |= qm2_pack_reads(j->text + off, take, &st, j->out, j->out_cap, wraps, 64, &p);
         }
         j->bases += 64 * p.n_blocks - p.n_newlines;
