@@ -1026,6 +1026,12 @@ extern "C" int qm2_submit(qm2_ctx *c, const char *buf, size_t n)
 }
 
 /* One packed piece, already in pinned slot `s` (blocks from its first byte), behind the current batch's fill. */
+static bool early_flush_enabled()
+{
+    static const bool on = [] { const char *e = getenv("QM2_EARLY_FLUSH"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static int stage_packed(qm2_ctx *c, Slot &s, const qm2_packed &p, const uint64_t *wraps)
 {
     const uint64_t positions = p.n_blocks * 64;
@@ -1046,6 +1052,23 @@ static int stage_packed(qm2_ctx *c, Slot &s, const qm2_packed &p, const uint64_t
     b.packed_nl += p.n_newlines;
     for (uint64_t i = 0; i < p.n_wraps; i++) b.wraps.push_back(wraps[i] + pos0);
     if (b.fill / QM2_PACKED_BLOCK_BYTES * 64 >= c->batch_bytes) return batch_flush(c);
+    /* An idle device does not wait for a whole batch: with a quarter of one in hand and the other batch's kernels finished
+     * (or never started: the first batch of a job), what is there is launched.  Fed slower than it counts, the device works
+     * on quarter batches with the link's latency instead of a whole batch's; fed faster, the other batch is busy whenever
+     * this one is looked at and batches fill up as before.  (Host-fed bench, 8 x 9 G bases: the first launch 65 ms -> 16 ms
+     * after the first byte.)  QM2_EARLY_FLUSH=0 switches it off. */
+    /* (never so early that the piece would be too small for the partitioned pipeline: launch_batch, n >= H / 8) */
+    if (b.fill / QM2_PACKED_BLOCK_BYTES * 64 >= std::max<uint64_t>(c->batch_bytes / 4, c->H / 8) && early_flush_enabled()) {
+        Batch &o = c->batch[c->cur ^ 1];
+        bool idle = !o.busy;
+        if (!idle) {
+            const hipError_t q = hipEventQuery(o.done);
+            if (q == hipSuccess) idle = true;
+            else if (q != hipErrorNotReady) HIP_OK(q);
+            else (void)hipGetLastError();
+        }
+        if (idle) return batch_flush(c);
+    }
     return 0;
 }
 
