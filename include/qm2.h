@@ -449,7 +449,7 @@ int qm2_pack_lines(const char *lines, size_t n, void *dst, size_t dst_bytes, uin
 int qm2_pack_reads(const char *text, size_t n, qm2_line_state *st, void *dst, size_t dst_bytes, uint64_t *wraps,
                    size_t wraps_cap, qm2_packed *out);
 const char *qm2_pack_isa(void);      /* "avx512vbmi2" / "avx512" / "avx2" / "portable": the build of the packers this CPU runs */
-const char *qm2_pack_isa_select(const char *name);   /* force a build (tests run all three; NULL = the widest again); returns what runs */
+const char *qm2_pack_isa_select(const char *name);   /* force a build (tests run all of them; NULL = the widest again); returns what runs */
 int qm2_staging_commit_packed(qm2_ctx *c, char *buf, const qm2_packed *p, const uint64_t *wraps);
 /* qm2_submit with the packing spread over n_threads host threads (0 = qm2_submit): pieces of whole lines, packed into
  * the pinned staging buffers by the threads, committed in order by the calling thread.  Same contract, same result. */

@@ -1,7 +1,7 @@
 """CPU-only checks of the PACKED input format's host side (quick-mer2_amd/csrc/qm2_pack.c; include/qm2.h, "packed
 sequence"): what qm2_pack_lines / qm2_pack_reads write is, position for position, the reference's reset test and
 2-bit code (QuicKmer.c:403-411) of the text the reference's line discipline (:393-398, :451-455) hands to its encoder —
-checked against a plain numpy statement of the format and the oracle's strip, in all three instruction-set builds.
+checked against a plain numpy statement of the format and the oracle's strip, in every instruction-set build (portable, AVX2, AVX-512, AVX-512 VBMI2).
 No GPU call is made here; the device side of the format is pinned by tests/test_emul_cpu.py (unpack16 on the host)."""
 import os
 import tempfile
