@@ -41,7 +41,7 @@ static void *run(void *arg)
         const char *first = memchr(p, '\n', n);                       /* from a line start on, whole lines */
         const char *last = memrchr(p, '\n', n);
         if (!first || last <= first) continue;
-        qm2_line_state st = {1, 0, 0};
+        qm2_line_state st = {1, 0, 0, 0};
         qm2_packed pk;
         if (qm2_pack_reads(first + 1, (size_t)(last - first), &st, out, qm2_packed_bound(j->block + 4096), wraps, 64, &pk)) { puts("pack failed"); exit(1); }
         j->bases += 64 * pk.n_blocks - pk.n_newlines;
