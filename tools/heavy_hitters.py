@@ -40,8 +40,17 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(5)
 
-    def variant(frac_rep, families, frac_poly, base_char="A"):
+    def variant(frac_rep, families, frac_poly, base_char="A", frac_random=0.0):
         buf = base.clone().view(reads, 151)
+        if frac_random:                                   # reads of an unrelated genome: no hits, every walk ends on an empty slot
+            m = int(reads * frac_random)
+            where = torch.randint(0, reads, (m,), device=dev, generator=g)
+            acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+            for a in range(0, m, 5_000_000):
+                w = where[a:a + 5_000_000]
+                seq = acgt[torch.randint(0, 4, (len(w), 151), device=dev, generator=g)]
+                seq[:, 150] = 10
+                buf[w] = seq
         if frac_rep:
             m = int(reads * frac_rep)
             where = torch.randint(0, reads, (m,), device=dev, generator=g)
@@ -62,7 +71,8 @@ def main():
     only = os.environ.get("HH_ONLY")
     for name, args in (("uniform reads", (0, 0, 0)), ("5 % of the reads from 1000 families", (0.05, 1000, 0)),
                        ("5 % from 100 000 families", (0.05, 100_000, 0)), ("20 % from 10 000 families", (0.20, 10_000, 0)),
-                       ("0.5 % poly-A", (0, 0, 0.005)), ("0.5 % poly-C (not in the dictionary)", (0, 0, 0.005, "C")), ("5 % from 1000 families + 0.5 % poly-A", (0.05, 1000, 0.005))):
+                       ("0.5 % poly-A", (0, 0, 0.005)), ("0.5 % poly-C (not in the dictionary)", (0, 0, 0.005, "C")), ("5 % from 1000 families + 0.5 % poly-A", (0.05, 1000, 0.005)),
+                       ("half the reads random sequence", (0, 0, 0, "A", 0.5)), ("half random + 5 % from 1000 families", (0.05, 1000, 0, "A", 0.5))):
         if only and only not in name:
             continue
         buf = variant(*args)
