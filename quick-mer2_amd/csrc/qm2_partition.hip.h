@@ -186,7 +186,10 @@ struct SplitLds {
                                                (dl.x = reserved start - off, dl.y = off + what fits)  */
     uint32_t wsum[kMaxFan / kWave];
     uint32_t spill_n;                       /* runs of this chunk that did not fit their child ...   */
-    uint2    spill_e[kSpillRuns];           /* ... {first element in sorted | how many << 16, place in the spill list} */
+    uint32_t spill_need;                    /* ... their k-mers, summed (every run's place inside the chunk's piece of the spill list) ... */
+    uint32_t spill_room;                    /* ... how many of them the spill list takes, and from where (copy_spills) */
+    unsigned long long spill_base;
+    uint2    spill_e[kSpillRuns];           /* ... {first element in sorted | how many << 16, place inside the chunk's piece} */
 };
 static_assert(kMaxFan % kSplitThreads == 0 || kSplitThreads > kMaxFan, "whole children per thread");
 constexpr int kChildPerThread = kSplitThreads >= kMaxFan ? 1 : kMaxFan / kSplitThreads;
@@ -198,16 +201,35 @@ constexpr int kSplitWgPerCu = kSplitThreads >= 1024 ? 1 : 2;      /* what the LD
 #endif
 
 /* The announced overflow runs of a chunk (sort_chunk), copied to the spill list by the whole workgroup.  Out of line:
- * inlined, its registers pushed values of the chunk loop into scratch and cost the loop 12 % — and it hardly ever runs. */
-__device__ __attribute__((noinline)) void copy_spills(const SplitLds &L, uint64_t *spill)
+ * inlined, its registers pushed values of the chunk loop into scratch and cost the loop 12 % — and it hardly ever runs.
+ * ONE reservation per chunk (thread 0, for the sum of its runs): until round 5 every overflowing run reserved its own place
+ * with a returning atomic on the one global counter, in the middle of the sort — with 5 % of the reads from 1000 repeat
+ * families (a tenth of the finest buckets overflow) that was a million same-address atomics per launch, each of them waited
+ * for by a whole workgroup: split_kmer 24.5 ms against 20.8 on uniform reads, 21.0 with the atomic taken out (timing build).
+ * Returns what this lane's runs lost (the spill list full: the batch is then recounted by the direct kernel). */
+__device__ __attribute__((noinline)) uint32_t copy_spills(SplitLds &L, uint64_t *spill, unsigned long long *spill_count, uint64_t spill_cap)
 {
     /* (the destination by value: a reference to the kernel's SplitDst would move that whole struct into scratch) */
-    const uint32_t ns = L.spill_n < (uint32_t)kSpillRuns ? L.spill_n : (uint32_t)kSpillRuns;
-    for (uint32_t r = 0; r < ns; r++) {
-        const uint2 e = L.spill_e[r];
-        const uint32_t first = e.x & 0xFFFFu, len = e.x >> 16;
-        for (uint32_t x = threadIdx.x; x < len; x += kSplitThreads) spill[(uint64_t)e.y + x] = L.sorted[first + x];
+    if (threadIdx.x == 0) {
+        const uint32_t need = L.spill_need;
+        const unsigned long long sb = atomicAdd(spill_count, (unsigned long long)need);
+        L.spill_base = sb;
+        L.spill_room = sb >= spill_cap ? 0u : (spill_cap - sb < need ? (uint32_t)(spill_cap - sb) : need);     /* (spill_cap < 2^32) */
     }
+    lds_barrier();
+    const uint32_t ns = L.spill_n < (uint32_t)kSpillRuns ? L.spill_n : (uint32_t)kSpillRuns;
+    const uint32_t room = L.spill_room;
+    const unsigned long long base = L.spill_base;
+    /* a wave per run (runs are ~16 k-mers) */
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t lost = 0;
+    for (uint32_t r = wave; r < ns; r += kSplitWaves) {
+        const uint2 e = L.spill_e[r];
+        const uint32_t first = e.x & 0xFFFFu, len = e.x >> 16, at = e.y;
+        for (uint32_t x = lane; x < len; x += kWave) if (at + x < room) spill[base + at + x] = L.sorted[first + x];
+        if (lane == 0 && at + len > room) lost += at >= room ? len : at + len - room;
+    }
+    return lost;
 }
 
 /* Inclusive sum over the wave's 64 lanes in the vector ALU alone (DPP: four shifts inside the rows of 16, then lane 15 and
@@ -258,7 +280,7 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, uint32_t cur, const uint
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     lds_barrier();                 /* hist complete; every wave is done reading the previous L.sorted / L.dl */
     QM2_SORT_STAMP(21);
-    if (tid == 0) L.spill_n = 0;
+    if (tid == 0) { L.spill_n = 0; L.spill_need = 0; }
     /* thread t takes children t, t + kSplitThreads, ... (kChildPerThread of them: consecutive lanes = consecutive
      * children, so the reservations below are the contiguous, full-rate atomic shape) */
     constexpr int C = kChildPerThread;
@@ -331,21 +353,15 @@ __device__ __forceinline__ void sort_chunk(SplitLds &L, uint32_t cur, const uint
                  * one thread doing it alone made 0.5 % poly-A reads cost 30 ms per 50 M reads.  What does not fit the
                  * spill list either (or there is none: qm2_route_device) counts as lost: the caller is told / the
                  * batch is recounted by the direct kernel. */
-                uint32_t fits = 0;                                    /* ... of the run's rest, in the spill list */
-                if (d.spill_cap) {
-                    const unsigned long long sb = atomicAdd(d.spill_count, (unsigned long long)(mine[i] - f[i]));
-                    if (sb < d.spill_cap) {                           /* (spill_cap < 2^32: a quarter of a batch of < 16 GiB) */
-                        fits = d.spill_cap - sb < mine[i] - f[i] ? (uint32_t)(d.spill_cap - sb) : mine[i] - f[i];
-                        L.spill_e[atomicAdd(&L.spill_n, 1u)] = make_uint2((off[i] + f[i]) | (fits << 16), (uint32_t)sb);
-                    }
-                }
-                lost += mine[i] - f[i] - fits;
+                const uint32_t need = mine[i] - f[i];                 /* (< 2^16: a chunk holds <= 16 K k-mers) */
+                if (d.spill_cap) L.spill_e[atomicAdd(&L.spill_n, 1u)] = make_uint2((off[i] + f[i]) | (need << 16), atomicAdd(&L.spill_need, need));
+                else lost += need;
             }
         }
     }
     lds_barrier();
     QM2_SORT_STAMP(26);
-    if (L.spill_n) copy_spills(L, d.spill);               /* workgroup-uniform, rare */
+    if (L.spill_n) lost += copy_spills(L, d.spill, d.spill_count, d.spill_cap);       /* workgroup-uniform, rare */
 }
 
 /* child of a k-mer at a level: `bits` bits of its home slot from bit `shift` on (shift + bits <= log2 H, so
