@@ -82,10 +82,26 @@ def main():
         _, s1 = ctx.finish(want_depth=False)
         per = {a: s1[a] - s0[a] for a in s1}
         p0 = ctx.profile()
+        stamps = None
+        try:                                                 # a -DQM2_STAMPS build (QM2_LIB=...): bucket_count's phases for this variant
+            import ctypes as C
+            stamps = pyqm2.lib().qm2_debug_stamps
+            stamps((C.c_uint64 * 32)())                      # (reading clears)
+        except AttributeError:
+            pass
         for _ in range(3):
             ctx.submit_device(buf.data_ptr(), nbytes)
         ctx.sync()
         p1 = ctx.profile()
+        if stamps:
+            acc = (C.c_uint64 * 32)()
+            stamps(acc)
+            nl, npw = max(1, acc[8]), max(1, acc[9])
+            lt, pt = sum(acc[i] for i in (0, 1, 2, 3, 10)), sum(acc[i] for i in (4, 5, 6, 7, 11))
+            print("    bucket_count per wave (cycles / 3 launches): loaders %.0f = flush %.0f wait_regs %.0f stage %.0f fetch_issue %.0f barrier %.0f | probers %.0f = "
+                  "kmer_arrival_wait %.0f kmer_load_issue %.0f phase_a %.0f phase_b %.0f barrier %.0f" % (
+                      lt / nl / 3, acc[0] / nl / 3, acc[10] / nl / 3, acc[1] / nl / 3, acc[2] / nl / 3, acc[3] / nl / 3,
+                      pt / npw / 3, acc[11] / npw / 3, acc[4] / npw / 3, acc[5] / npw / 3, acc[6] / npw / 3, acc[7] / npw / 3), flush=True)
         ms = {c: round((p1["class_ms"][c] - p0["class_ms"][c]) / 3, 2) for c in p1["class_ms"] if p1["class_ms"][c] - p0["class_ms"][c] > 0.3}
         tot = (p1["kernel_ms"] - p0["kernel_ms"]) / 3
         print("%-44s %6.1f ms per batch = %5.1f G bases/s  %s  fallbacks %d; slots inspected per k-mer %.3f" % (
