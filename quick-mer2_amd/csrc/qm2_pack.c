@@ -51,7 +51,19 @@ static int sink_wraps(pack_sink *s, const uint8_t *line, size_t len, uint64_t po
     return 0;
 }
 
-/* ---- the three builds --------------------------------------------------------------------------------------------- */
+/* The blocks go to a pinned staging buffer that only the copy engine reads: in the x86 builds they are written with
+ * non-temporal stores (movnti, combined to whole lines on the way out) — a plain store first READS the line it is about to
+ * overwrite, a fifth of the DRAM traffic of a host that feeds at the memory system's limit (EXPERIMENTS.md);
+ * qm2_pack_lines / qm2_pack_reads end with an sfence.  QM2_PACK_PLAIN_STORES (compile time) switches it off. */
+#if defined(__x86_64__) && !defined(QM2_PACK_PLAIN_STORES)
+#define QM2_STORE64(p, v) _mm_stream_si64((long long *)(p), (long long)(v))
+#define QM2_STORES_DONE() _mm_sfence()
+#else
+#define QM2_STORE64(p, v) (*(p) = (v))
+#define QM2_STORES_DONE() ((void)0)
+#endif
+
+/* ---- the three builds of qm2_pack_body.h (the VBMI2 pack_reads follows them) ----------------------------------------- */
 
 static inline uint64_t spread_portable(uint32_t x)
 {
@@ -406,6 +418,7 @@ int qm2_pack_lines(const char *lines, size_t n, void *dst, size_t dst_bytes, uin
     }
     uint64_t newlines = 0;
     const size_t nb = im->lines((const uint8_t *)lines, n, (uint64_t *)dst, &newlines);
+    QM2_STORES_DONE();
     out->n_blocks = nb;
     out->n_newlines = newlines + (64 * (uint64_t)nb - n);                        /* + the filler of the last block */
     return 0;
@@ -423,7 +436,9 @@ int qm2_pack_reads(const char *text, size_t n, qm2_line_state *st, void *dst, si
     s.out = (uint64_t *)dst;
     s.cap_blocks = dst_bytes / QM2_PACKED_BLOCK_BYTES;
     s.wraps = wraps; s.wraps_cap = wraps_cap;
-    if (im->reads((const uint8_t *)text, n, st, &s)) return 2;
+    const int rrc = im->reads((const uint8_t *)text, n, st, &s);
+    QM2_STORES_DONE();
+    if (rrc) return 2;
     out->n_blocks = s.n_blocks;
     out->n_newlines = s.n_newlines;
     out->n_wraps = s.n_wraps;

@@ -8,6 +8,7 @@
  *   QM2_GTMASK(p)      c == '>' (lines are dropped for their first byte, QuicKmer.c:398)
  *   QM2_HAVE_PEXT      defined where BMI2 is there: pack_reads then handles a whole 64-byte group at once
  *   QM2_SPREAD(x)      bit q of the 32-bit x -> bit 2q of a 64-bit word
+ *   QM2_STORE64(p, v)  one word of a block into the output (qm2_pack.c: non-temporal in the x86 builds)
  */
 #define QM2_CAT2(a, b) a##_##b
 #define QM2_CAT(a, b) QM2_CAT2(a, b)
@@ -16,9 +17,9 @@
 /* one block = 64 positions: codes of positions 0..31, of 32..63, reset flags (include/qm2.h, "packed sequence") */
 QM2_TARGET static inline void QM2_FN(put_block)(uint64_t *dst, uint64_t hi, uint64_t lo, uint64_t bad)
 {
-    dst[0] = QM2_SPREAD((uint32_t)hi) | (QM2_SPREAD((uint32_t)lo) << 1);
-    dst[1] = QM2_SPREAD((uint32_t)(hi >> 32)) | (QM2_SPREAD((uint32_t)(lo >> 32)) << 1);
-    dst[2] = bad;
+    QM2_STORE64(dst, QM2_SPREAD((uint32_t)hi) | (QM2_SPREAD((uint32_t)lo) << 1));
+    QM2_STORE64(dst + 1, QM2_SPREAD((uint32_t)(hi >> 32)) | (QM2_SPREAD((uint32_t)(lo >> 32)) << 1));
+    QM2_STORE64(dst + 2, bad);
 }
 
 /* positions appended a run at a time: cnt in 1..64, the bits above cnt zero.  The block being filled lives in a LOCAL
