@@ -1196,7 +1196,7 @@ extern "C" int qm2_submit_threads(qm2_ctx *c, const char *buf, size_t n, uint32_
     /* pieces of ~32 MiB of text (what a reader thread of the CLI handles at a time), whole lines */
     const size_t piece_max = std::min<size_t>(piece_cap, (size_t)32 << 20);
     if (piece_max < 4096) return submit_packing(c, buf, n);
-    struct Job { size_t off = 0, len = 0; Slot *slot = nullptr; qm2_packed p = {0, 0, 0}; uint64_t wraps[64]; int rc = 0; bool done = false; bool ascii = false; };
+    struct Job { size_t off = 0, len = 0; Slot *slot = nullptr; qm2_packed p = {0, 0, 0}; uint64_t wraps[64]; int rc = 0; bool done = false; bool ascii = false; bool slot_released = false; };
     std::vector<Job> jobs;
     for (size_t off = 0; off < n;) {
         size_t take = std::min(piece_max, n - off);
@@ -1259,15 +1259,21 @@ extern "C" int qm2_submit_threads(qm2_ctx *c, const char *buf, size_t n, uint32_
         cv_work.notify_one();
         return 0;
     };
+    /* pieces are committed as they get ready, in ANY order (counting does not care): one slow thread — 14 of them on a
+     * 16-CPU share get descheduled now and then — then holds up its own piece only, not the window behind it */
+    std::vector<size_t> open;                     /* issued, not yet committed */
     while (!rc && committed < jobs.size()) {
-        while (!rc && issued < jobs.size() && issued - committed < window) rc = issue_one();
+        while (!rc && issued < jobs.size() && open.size() < window) { open.push_back(issued); rc = issue_one(); if (rc) open.pop_back(); }
         if (rc) break;
-        Job &j = jobs[committed];
+        size_t at = 0;
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv_done.wait(lk, [&] { return j.done; });
+            cv_done.wait(lk, [&] { for (size_t i = 0; i < open.size(); i++) if (jobs[open[i]].done) { at = i; return true; } return false; });
         }
+        Job &j = jobs[open[at]];
+        open.erase(open.begin() + (long)at);
         if (j.slot) j.slot->lent = false;
+        j.slot_released = true;
         if (j.ascii || j.rc == 2) rc = submit_lines(c, buf + j.off, j.len, nullptr);          /* does not pack: the ASCII way */
         else if (j.rc) rc = fail("qm2_submit_threads: packing failed");
         else rc = stage_packed(c, *j.slot, j.p, j.wraps);
@@ -1280,7 +1286,7 @@ extern "C" int qm2_submit_threads(qm2_ctx *c, const char *buf, size_t n, uint32_
     }
     cv_work.notify_all();
     for (auto &t : pool) t.join();
-    for (size_t i = committed; i < issued; i++) if (jobs[i].slot) jobs[i].slot->lent = false;
+    for (size_t i = 0; i < issued; i++) if (jobs[i].slot && !jobs[i].slot_released) jobs[i].slot->lent = false;
     return rc;
 }
 
