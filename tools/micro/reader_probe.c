@@ -24,6 +24,7 @@ static int pk(void *u, char *b, const qm2_packed *p, const uint64_t *w) { (void)
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 int main(int argc, char **argv)
 {
+    qm2_reader_note_affinity();       /* (as the CLI does: the block reader's workers then go where the file's cached pages lie) */
     if (argc >= 4 && !strcmp(argv[1], "make")) {
         FILE *f = fopen(argv[2], "wb");
         if (!f) { perror(argv[2]); return 1; }
