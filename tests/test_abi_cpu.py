@@ -402,6 +402,29 @@ int main(int argc, char **argv) {
                 assert len({(k // per_turn) % n_sinks for k in range(j)}) == min(n_sinks, (j + per_turn - 1) // per_turn)
 
 
+def test_reader_looks_where_the_files_pages_lie(pkg, tmp_path):
+    """csrc/qm2_reader.c, file_pages_cpus: 64 pages of a regular file are mapped (never touched) and move_pages(2) says which
+    NUMA node each lies on; a 3/4 majority sends the block reader's workers there.  Here: the path runs, agrees with itself
+    (the file was just written by this process: one node) and the reader's result is what it is without it."""
+    probe = os.path.join(ROOT, "tools", "micro", "reader_probe")
+    if not os.path.exists(probe):
+        pytest.skip("tools/micro/reader_probe not built")
+    fq = tmp_path / "t.fq"
+    fq.write_bytes(b"".join(b"@r%d\n" % i + b"ACGT" * 37 + b"AC\n+\n" + b"I" * 150 + b"\n" for i in range(30000)))
+    outs = []
+    for env in ({"QM2_READER_TIMING": "1"}, {"QM2_READER_TIMING": "1", "QM2_NO_BIND": "1"}):
+        r = subprocess.run([probe, str(fq), "4", "packed", "1"], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+        txt = r.stdout.decode()
+        assert r.returncode == 0 and " rc=0 " in txt, txt
+        outs.append(txt)
+    m = re.search(r"(\d+) of 64 sampled pages of the file lie on NUMA node (\d+): the workers run on its (\d+) CPUs", outs[0])
+    if m:                                        # (a sandbox may refuse move_pages: then nothing is said and nothing changes)
+        assert int(m.group(1)) >= 48 and int(m.group(3)) >= 1
+    assert "sampled pages" not in outs[1]        # QM2_NO_BIND leaves the affinities alone
+    bases = [re.search(r"= ([0-9.]+) G bases/s", t) is not None for t in outs]
+    assert all(bases)
+
+
 def test_bench_gpus_means_ranks(tmp_path):
     """`python bench.py --gpus N` (the driver's own form): N > 1 without a rank environment starts N ranks of the script under
     torch.distributed.run as a child process — checked with a stand-in launcher — and relays rank 0's one JSON line and the
