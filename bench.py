@@ -950,7 +950,10 @@ def main():
             pctx.submit_threads(None, args.feed_threads, addr=h.ctypes.data, n=h.size)     # ONE call of the C-ABI per step (qm2_submit_threads)
             return h.size * 24 // 64                                                        # (the blocks' bytes, to a piece's rounding; checked against the profile below)
 
-        packed_steps = 2 * args.streamed_steps                 # (the drain of the last device batch is then ~10 % of the region, as in the ASCII one)
+        # ONE JOB of BASELINE.md's size per rank: a 30x human genome = 600 M reads of 150 bases (tutorial.md:146-162) -> 10 steps of the C3 workload;
+        # never fewer than twice the ASCII region's steps (chr22-scale steps are small)
+        job_reads = int(os.environ.get("QM2_BENCH_JOB_READS", "600000000"))
+        packed_steps = max(2 * args.streamed_steps, min(40, -(-job_reads // max(1, wl["reads"]))))
         nbases, moved, sec, allocs, per_rank = run(pctx, feed_packed, packed_steps)
         assert nbases == world * packed_steps * wl["reads"] * rl
         staged_total = pctx.profile()["staged_bytes"]          # (warm-up step included: packed_steps + 1 steps of the same size)
@@ -963,7 +966,9 @@ def main():
                     "pack_isa": pyqm2.lib().qm2_pack_isa().decode(), "cpus_of_the_gpus_numa_node_bound_to": cpus_near,
                     "feed": "qm2_submit_threads(ctx, lines, n, %d): one call per step on a 9 GB buffer of sequence lines in pageable memory; the library's threads pack "
                             "32 MiB pieces into the pinned staging buffers (qm2_pack_lines: 2-bit codes + reset flags, what the CLI's reader threads do behind pread), "
-                            "the calling thread commits them in order; timed from the first call to the return of qm2_finish" % args.feed_threads}
+                            "the calling thread commits them as they get ready; timed from the first call to the return of qm2_finish; the region is ONE JOB of "
+                            "BASELINE.md's size per rank (a 30x human genome, 600 M reads of 150 bases) where the workload's steps allow" % args.feed_threads,
+                    "job_reads": packed_steps * wl["reads"]}
         # ... and what the kernels make of packed input that is already in HBM (the ceiling of the figure above; `value` stays
         # the ASCII-resident rate: there the device does the whole of QuicKmer.c:403-420)
         if rank == 0:
@@ -1028,11 +1033,12 @@ def main():
             return sctx.feed_host_packed(fq.ctypes.data, fq.size, 2 * (rl + 1) + 5, reads=(True, 1), threads=args.feed_threads, piece_text=args.piece_mib << 20)
 
         raw_steps = max(1, args.streamed_steps * 3 // 2)      # (6 x 6.1 GB by default: the drain of the last batch is then < 10 % of the region)
-        nbases, moved, sec, allocs, per_rank = run(sctx, feed_fastq_packed, 2 * raw_steps)
-        assert nbases == world * 2 * raw_steps * m * rl
+        fq_steps = max(2 * raw_steps, min(40, -(-job_reads // max(1, m))))        # (the same job as FASTQ text: 30 steps of 20 M reads)
+        nbases, moved, sec, allocs, per_rank = run(sctx, feed_fastq_packed, fq_steps)
+        assert nbases == world * fq_steps * m * rl
         streamed.update({"streamed_fastq_bases_per_s": round(nbases / sec, 1), "fastq_h2d_GBps": round(moved / sec / 1e9, 2),
-                         "fastq_text_GBps": round(world * 2 * raw_steps * fq.size / sec / 1e9, 2), "fastq_h2d_GBps_per_rank": per_rank,
-                         "fastq_reads_per_step": m, "fastq_steps": 2 * raw_steps, "fastq_allocations_inside": allocs})
+                         "fastq_text_GBps": round(world * fq_steps * fq.size / sec / 1e9, 2), "fastq_h2d_GBps_per_rank": per_rank,
+                         "fastq_reads_per_step": m, "fastq_steps": fq_steps, "fastq_allocations_inside": allocs})
         # ... and as raw text over the link, line discipline on the device (QM2_READER=raw; rounds 2-4's figure)
         nbases, moved, sec, allocs, per_rank = run(sctx, feed_fastq, raw_steps)
         streamed.update({"streamed_raw_fastq_bases_per_s": round(nbases / sec, 1), "raw_fastq_h2d_GBps": round(moved / sec / 1e9, 2),
